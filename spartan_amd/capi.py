@@ -1,0 +1,190 @@
+"""ctypes binding of include/spartan_hip.h. Raises if the HIP library is missing (no fallback)."""
+import ctypes, os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspartan_hip.so")
+sz = ctypes.c_size_t
+vp = ctypes.c_void_p
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class SpartanHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SpartanHipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    L = ctypes.CDLL(LIB_PATH)
+    L.sp_strerror.restype = ctypes.c_char_p
+    L.sp_version.restype = ctypes.c_char_p
+    L.sp_gens_len.restype = sz
+    L.sp_table_len.restype = sz
+    L.sp_gens_len.argtypes = [vp]
+    L.sp_table_len.argtypes = [vp]
+    L.sp_gens_free.argtypes = [vp]
+    L.sp_table_free.argtypes = [vp]
+    L.sp_ctx_destroy.argtypes = [vp]
+    return L
+
+
+lib = _load()
+
+# every symbol include/spartan_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = ["sp_strerror", "sp_version", "sp_ctx_create", "sp_ctx_destroy", "sp_prof_enable", "sp_prof_reset", "sp_prof_read",
+           "sp_gens_upload", "sp_gens_from_uniform", "sp_gens_len", "sp_gens_free", "sp_commit_rows", "sp_commit_rows_dev",
+           "sp_msm_indexed", "sp_table_alloc", "sp_table_upload", "sp_table_write", "sp_table_download", "sp_table_clone",
+           "sp_table_copy", "sp_table_len", "sp_table_free", "sp_eq_expand", "sp_sumcheck_eval", "sp_table_bind_top",
+           "sp_sumcheck_bind_eval", "sp_vecmat", "sp_dot", "sp_evaluate", "sp_table_heads"]
+
+
+def _chk(rc):
+    if rc != 0:
+        raise SpartanHipError(f"spartan_hip error {rc}: {lib.sp_strerror(rc).decode()}")
+
+
+def _u64(buf):
+    """bytes/bytearray/ctypes array of Montgomery limbs -> ctypes pointer"""
+    if isinstance(buf, (bytes, bytearray)):
+        return ctypes.cast(ctypes.create_string_buffer(bytes(buf), len(buf)), u64p)
+    return ctypes.cast(buf, u64p)
+
+
+class Ctx:
+    def __init__(self, device=0):
+        self.h = vp()
+        _chk(lib.sp_ctx_create(ctypes.c_int(device), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib.sp_ctx_destroy(self.h)
+            self.h = vp()
+
+    def prof_enable(self, on=True):
+        _chk(lib.sp_prof_enable(self.h, ctypes.c_int(1 if on else 0)))
+
+    def prof_reset(self):
+        _chk(lib.sp_prof_reset(self.h))
+
+    def prof_read(self):
+        cap = 64
+        names = (ctypes.c_char_p * cap)(); ms = (ctypes.c_double * cap)(); n = (ctypes.c_uint64 * cap)(); by = (ctypes.c_double * cap)()
+        k = lib.sp_prof_read(self.h, names, ms, n, by, ctypes.c_int(cap))
+        return {names[i].decode(): {"ms": ms[i], "launches": int(n[i]), "alg_bytes": by[i]} for i in range(min(k, cap))}
+
+
+class Gens:
+    def __init__(self, ctx, compressed=None, uniform=None):
+        self.ctx = ctx
+        self.h = vp()
+        if compressed is not None:
+            n = len(compressed) // 32
+            _chk(lib.sp_gens_upload(ctx.h, compressed, sz(n), ctypes.byref(self.h)))
+            self.compressed = bytes(compressed)
+        else:
+            n = len(uniform) // 64
+            out = (ctypes.c_uint8 * (32 * n))()
+            _chk(lib.sp_gens_from_uniform(ctx.h, uniform, sz(n), out, ctypes.byref(self.h)))
+            self.compressed = bytes(out)
+        self.n = n
+
+    def free(self):
+        if self.h:
+            lib.sp_gens_free(self.h)
+            self.h = vp()
+
+    def commit_rows(self, Z, rows, cols, blinds=None, g_off=0, h_idx=None):
+        out = (ctypes.c_uint8 * (32 * rows))()
+        if h_idx is None:
+            h_idx = self.n - 1
+        if isinstance(Z, Table):
+            _chk(lib.sp_commit_rows_dev(self.ctx.h, self.h, sz(g_off), sz(h_idx), Z.h, sz(0), sz(rows), sz(cols),
+                                        _u64(blinds) if blinds is not None else None, out))
+        else:
+            _chk(lib.sp_commit_rows(self.ctx.h, self.h, sz(g_off), sz(h_idx), _u64(Z), sz(rows), sz(cols),
+                                    _u64(blinds) if blinds is not None else None, out))
+        return bytes(out)
+
+    def msm_indexed(self, idx, S, rows=1):
+        cols = len(idx)
+        arr = (ctypes.c_uint32 * cols)(*idx)
+        out = (ctypes.c_uint8 * (32 * rows))()
+        _chk(lib.sp_msm_indexed(self.ctx.h, self.h, arr, sz(cols), _u64(S), sz(rows), out))
+        return bytes(out)
+
+
+class Table:
+    def __init__(self, ctx, h):
+        self.ctx = ctx
+        self.h = h
+
+    @staticmethod
+    def upload(ctx, Z, n):
+        h = vp()
+        _chk(lib.sp_table_upload(ctx.h, _u64(Z), sz(n), ctypes.byref(h)))
+        return Table(ctx, h)
+
+    @staticmethod
+    def eq(ctx, r, ell):
+        h = vp()
+        _chk(lib.sp_eq_expand(ctx.h, _u64(r), sz(ell), ctypes.byref(h)))
+        return Table(ctx, h)
+
+    def __len__(self):
+        return lib.sp_table_len(self.h)
+
+    def download(self, n=None, off=0):
+        n = len(self) if n is None else n
+        out = (ctypes.c_uint64 * (4 * n))()
+        _chk(lib.sp_table_download(self.ctx.h, self.h, sz(off), sz(n), out))
+        return out
+
+    def free(self):
+        if self.h:
+            lib.sp_table_free(self.h)
+            self.h = vp()
+
+
+def sumcheck_eval(ctx, kind, tabs):
+    arr = (vp * len(tabs))(*[t.h for t in tabs])
+    out = (ctypes.c_uint64 * 12)()
+    _chk(lib.sp_sumcheck_eval(ctx.h, ctypes.c_int(kind), arr, sz(len(tabs)), out))
+    return out
+
+
+def sumcheck_bind_eval(ctx, kind, tabs, r):
+    arr = (vp * len(tabs))(*[t.h for t in tabs])
+    out = (ctypes.c_uint64 * 12)()
+    _chk(lib.sp_sumcheck_bind_eval(ctx.h, ctypes.c_int(kind), arr, sz(len(tabs)), _u64(r), out))
+    return out
+
+
+def bind_top(ctx, tabs, r):
+    arr = (vp * len(tabs))(*[t.h for t in tabs])
+    _chk(lib.sp_table_bind_top(ctx.h, arr, sz(len(tabs)), _u64(r)))
+
+
+def vecmat(ctx, L, Lsz, Z):
+    R = len(Z) // Lsz
+    out = (ctypes.c_uint64 * (4 * R))()
+    _chk(lib.sp_vecmat(ctx.h, _u64(L), sz(Lsz), Z.h, out))
+    return out
+
+
+def dot(ctx, a, b, n, a_off=0, b_off=0):
+    out = (ctypes.c_uint64 * 4)()
+    _chk(lib.sp_dot(ctx.h, a.h, sz(a_off), b.h, sz(b_off), sz(n), out))
+    return out
+
+
+def evaluate(ctx, Z, r, ell):
+    out = (ctypes.c_uint64 * 4)()
+    _chk(lib.sp_evaluate(ctx.h, Z.h, _u64(r), sz(ell), out))
+    return out
+
+
+def heads(ctx, tabs):
+    arr = (vp * len(tabs))(*[t.h for t in tabs])
+    out = (ctypes.c_uint64 * (4 * len(tabs)))()
+    _chk(lib.sp_table_heads(ctx.h, arr, sz(len(tabs)), out))
+    return out

@@ -1,0 +1,154 @@
+// spartan_amd: ristretto255 group arithmetic (host+device).
+//
+// libspartan's GroupElement is curve25519-dalek's RistrettoPoint (reference: src/group.rs:6-7); the only
+// stable wire form is the 32-byte CompressedRistretto. This file implements, from RFC 9496 §4, what the
+// prover path needs: decode (generators arrive compressed over the C ABI), encode (every commitment leaves
+// compressed), the one-way map (MultiCommitGens::new = SHAKE256 stream -> from_uniform_bytes,
+// src/commitments.rs:15-33), and twisted-Edwards (a=-1) extended-coordinate addition in the two forms the
+// MSM kernels use: full add (add-2008-hwcd-3) and mixed add against a precomputed affine "Niels" entry
+// (y+x, y-x, 2dxy) — 7 field multiplications.
+#pragma once
+#include "field.hpp"
+
+namespace sp {
+
+SP_HD Fp fp_D() { return Fp{{0x75eb4dca135978a3ULL, 0x00700a4d4141d8abULL, 0x8cc740797779e898ULL, 0x52036cee2b6ffe73ULL}}; }
+SP_HD Fp fp_D2() { return Fp{{0xebd69b9426b2f159ULL, 0x00e0149a8283b156ULL, 0x198e80f2eef3d130ULL, 0x2406d9dc56dffce7ULL}}; }
+SP_HD Fp fp_ONE_MINUS_D_SQ() { return Fp{{0xe27c09c1945fc176ULL, 0x2c81a138cd5e350fULL, 0x9994abddbe70dfe4ULL, 0x029072a8b2b3e0d7ULL}}; }
+SP_HD Fp fp_D_MINUS_ONE_SQ() { return Fp{{0x31ad5aaa44ed4d20ULL, 0xd29e4a2cb01e1999ULL, 0x4cdcd32f529b4eebULL, 0x5968b37af66c2241ULL}}; }
+SP_HD Fp fp_SQRT_M1() { return Fp{{0xc4ee1b274a0ea0b0ULL, 0x2f431806ad2fe478ULL, 0x2b4d00993dfbd7a7ULL, 0x2b8324804fc1df0bULL}}; }
+SP_HD Fp fp_SQRT_AD_MINUS_ONE() { return Fp{{0x7e97f6a0497b2e1bULL, 0xaf9d8e0c1b7854bdULL, 0x0f3cfcc931f5d1fdULL, 0x376931bf2b8348acULL}}; }
+SP_HD Fp fp_INVSQRT_A_MINUS_D() { return Fp{{0x99c8fdaa805d40eaULL, 0x9d2f16175a4172beULL, 0x16c27b91fe01d840ULL, 0x786c8905cfaffca2ULL}}; }
+
+struct Pt {  // extended coordinates: x = X/Z, y = Y/Z, T = XY/Z
+  Fp X, Y, Z, T;
+};
+struct Niels {  // affine point prepared for mixed addition
+  Fp yp, ym, t2d;  // y+x, y-x, 2*d*x*y
+};
+
+SP_HD Pt pt_identity() { return Pt{fp_zero(), fp_one(), fp_one(), fp_zero()}; }
+
+// RFC 9496 §4.2 SQRT_RATIO_M1
+SP_HD bool fp_sqrt_ratio_m1(const Fp& u, const Fp& v, Fp* out) {
+  Fp v3 = fp_mul(fp_sqr(v), v);
+  Fp v7 = fp_mul(fp_sqr(v3), v);
+  Fp r = fp_mul(fp_mul(u, v3), fp_pow_p58(fp_mul(u, v7)));
+  Fp check = fp_mul(v, fp_sqr(r));
+  Fp neg_u = fp_neg(u);
+  bool correct_sign = fp_eq(check, u);
+  bool flipped = fp_eq(check, neg_u);
+  bool flipped_i = fp_eq(check, fp_mul(neg_u, fp_SQRT_M1()));
+  Fp r_i = fp_mul(r, fp_SQRT_M1());
+  r = fp_select(r, r_i, flipped || flipped_i);
+  *out = fp_abs(r);
+  return correct_sign || flipped;
+}
+
+SP_HD Pt pt_add(const Pt& p, const Pt& q) {
+  Fp A = fp_mul(fp_sub(p.Y, p.X), fp_sub(q.Y, q.X));
+  Fp B = fp_mul(fp_add(p.Y, p.X), fp_add(q.Y, q.X));
+  Fp C = fp_mul(fp_mul(p.T, fp_D2()), q.T);
+  Fp Dd = fp_mul(fp_add(p.Z, p.Z), q.Z);
+  Fp E = fp_sub(B, A), F = fp_sub(Dd, C), G = fp_add(Dd, C), H = fp_add(B, A);
+  return Pt{fp_mul(E, F), fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
+}
+// p + n (neg=false) or p - n (neg=true)
+SP_HD Pt pt_madd(const Pt& p, const Niels& n, bool neg) {
+  Fp yp = fp_select(n.yp, n.ym, neg), ym = fp_select(n.ym, n.yp, neg);
+  Fp A = fp_mul(fp_sub(p.Y, p.X), ym);
+  Fp B = fp_mul(fp_add(p.Y, p.X), yp);
+  Fp C = fp_mul(p.T, n.t2d);
+  Fp Dd = fp_add(p.Z, p.Z);
+  Fp E = fp_sub(B, A), H = fp_add(B, A);
+  Fp F = neg ? fp_add(Dd, C) : fp_sub(Dd, C);
+  Fp G = neg ? fp_sub(Dd, C) : fp_add(Dd, C);
+  return Pt{fp_mul(E, F), fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
+}
+SP_HD Pt pt_dbl(const Pt& p) {  // dbl-2008-hwcd, a = -1
+  Fp A = fp_sqr(p.X), B = fp_sqr(p.Y);
+  Fp Zs = fp_sqr(p.Z);
+  Fp C = fp_add(Zs, Zs);
+  Fp Dd = fp_neg(A);
+  Fp E = fp_sub(fp_sub(fp_sqr(fp_add(p.X, p.Y)), A), B);
+  Fp G = fp_add(Dd, B), F = fp_sub(G, C), H = fp_sub(Dd, B);
+  return Pt{fp_mul(E, F), fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
+}
+SP_HD Pt pt_neg(const Pt& p) { return Pt{fp_neg(p.X), p.Y, p.Z, fp_neg(p.T)}; }
+// affine Niels form of p given 1/Z
+SP_HD Niels pt_to_niels(const Pt& p, const Fp& zinv) {
+  Fp x = fp_mul(p.X, zinv), y = fp_mul(p.Y, zinv);
+  Niels n;
+  n.yp = fp_add(y, x);
+  n.ym = fp_sub(y, x);
+  n.t2d = fp_mul(fp_mul(x, y), fp_D2());
+  return n;
+}
+
+// RFC 9496 §4.3.2 Encode
+SP_HD void pt_compress(const Pt& p, uint8_t out[32]) {
+  Fp u1 = fp_mul(fp_add(p.Z, p.Y), fp_sub(p.Z, p.Y));
+  Fp u2 = fp_mul(p.X, p.Y);
+  Fp invsqrt;
+  fp_sqrt_ratio_m1(fp_one(), fp_mul(u1, fp_sqr(u2)), &invsqrt);
+  Fp den1 = fp_mul(invsqrt, u1), den2 = fp_mul(invsqrt, u2);
+  Fp z_inv = fp_mul(fp_mul(den1, den2), p.T);
+  Fp ix0 = fp_mul(p.X, fp_SQRT_M1()), iy0 = fp_mul(p.Y, fp_SQRT_M1());
+  Fp ench = fp_mul(den1, fp_INVSQRT_A_MINUS_D());
+  bool rotate = fp_is_negative(fp_mul(p.T, z_inv));
+  Fp x = fp_select(p.X, iy0, rotate);
+  Fp y = fp_select(p.Y, ix0, rotate);
+  Fp den_inv = fp_select(den2, ench, rotate);
+  y = fp_cneg(y, fp_is_negative(fp_mul(x, z_inv)));
+  Fp s = fp_abs(fp_mul(den_inv, fp_sub(p.Z, y)));
+  fp_to_bytes(s, out);
+}
+// RFC 9496 §4.3.1 Decode
+SP_HD bool pt_decompress(const uint8_t in[32], Pt* out) {
+  Fp s = fp_from_bytes(in);
+  uint8_t chk[32];
+  fp_to_bytes(s, chk);
+  bool canonical = true;
+  for (int i = 0; i < 32; i++) canonical = canonical && (chk[i] == in[i]);
+  if (!canonical || (in[0] & 1)) return false;
+  Fp ss = fp_sqr(s);
+  Fp u1 = fp_sub(fp_one(), ss), u2 = fp_add(fp_one(), ss);
+  Fp u2s = fp_sqr(u2);
+  Fp v = fp_sub(fp_neg(fp_mul(fp_D(), fp_sqr(u1))), u2s);
+  Fp invsqrt;
+  bool was_square = fp_sqrt_ratio_m1(fp_one(), fp_mul(v, u2s), &invsqrt);
+  Fp den_x = fp_mul(invsqrt, u2);
+  Fp den_y = fp_mul(fp_mul(invsqrt, den_x), v);
+  Fp x = fp_abs(fp_mul(fp_add(s, s), den_x));
+  Fp y = fp_mul(u1, den_y);
+  Fp t = fp_mul(x, y);
+  if (!was_square || fp_is_negative(t) || fp_is_zero(y)) return false;
+  *out = Pt{x, y, fp_one(), t};
+  return true;
+}
+// RFC 9496 §4.3.4 MAP
+SP_HD Pt pt_elligator(const Fp& t) {
+  Fp one = fp_one();
+  Fp r = fp_mul(fp_SQRT_M1(), fp_sqr(t));
+  Fp u = fp_mul(fp_add(r, one), fp_ONE_MINUS_D_SQ());
+  Fp v = fp_mul(fp_sub(fp_neg(one), fp_mul(r, fp_D())), fp_add(r, fp_D()));
+  Fp s;
+  bool was_square = fp_sqrt_ratio_m1(u, v, &s);
+  Fp s_prime = fp_neg(fp_abs(fp_mul(s, t)));
+  s = fp_select(s_prime, s, was_square);
+  Fp c = fp_select(r, fp_neg(one), was_square);
+  Fp N = fp_sub(fp_mul(fp_mul(c, fp_sub(r, one)), fp_D_MINUS_ONE_SQ()), v);
+  Fp w0 = fp_mul(fp_add(s, s), v);
+  Fp w1 = fp_mul(N, fp_SQRT_AD_MINUS_ONE());
+  Fp s2 = fp_sqr(s);
+  Fp w2 = fp_sub(one, s2);
+  Fp w3 = fp_add(one, s2);
+  return Pt{fp_mul(w0, w3), fp_mul(w2, w1), fp_mul(w1, w3), fp_mul(w0, w2)};
+}
+// dalek RistrettoPoint::from_uniform_bytes (= RFC 9496 one-way map), src/commitments.rs:25
+SP_HD Pt pt_from_uniform_bytes(const uint8_t b[64]) {
+  Fp t1 = fp_from_bytes(b), t2 = fp_from_bytes(b + 32);
+  return pt_add(pt_elligator(t1), pt_elligator(t2));
+}
+
+}  // namespace sp

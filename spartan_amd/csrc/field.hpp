@@ -1,0 +1,364 @@
+// spartan_amd: field arithmetic shared by the HIP kernels and the host-side prover driver.
+//
+//   Fq  scalar field of ristretto255, q = 2^252 + 27742317777372353535851937790883648493.
+//       In-memory form is exactly libspartan's `Scalar([u64;4])`: little-endian limbs of the Montgomery
+//       residue x*2^256 mod q, always fully reduced to [0,q) (reference: src/scalar/ristretto255.rs:199,
+//       248-328, 642-760), so device buffers are bit-compatible with a Rust `&[Scalar]`.
+//   Fp  base field of edwards25519, p = 2^255 - 19. 4x64 saturated limbs, weakly reduced (any value in
+//       [0,2^256) congruent to the element); 2^256 = 38 (mod p) folds carries. Chosen from
+//       bench/ubench_fpmul.hip on MI355X: 4x64 via __int128 = 190 Gmul/s vs 151 (8x32) / 154 (10x25.5).
+//
+// Everything is SP_HD (host+device) so the very same source is unit-tested on the CPU against the oracle
+// (tests/csrc/hostcheck.cc) and then runs on gfx950.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SP_HD __host__ __device__ __forceinline__
+#define SP_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define SP_HD inline
+#define SP_HD_NOINLINE
+#endif
+
+namespace sp {
+
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------ Fq
+struct Fq {
+  uint64_t l[4];
+};
+
+#define SP_Q0 0x5812631a5cf5d3edULL
+#define SP_Q1 0x14def9dea2f79cd6ULL
+#define SP_Q2 0x0000000000000000ULL
+#define SP_Q3 0x1000000000000000ULL
+#define SP_QINV 0xd2b51da312547e1bULL /* -(q^-1) mod 2^64, ristretto255.rs:304 */
+
+SP_HD Fq fq_zero() { return Fq{{0, 0, 0, 0}}; }
+SP_HD Fq fq_one() {  // R mod q, ristretto255.rs:307-312
+  return Fq{{0xd6ec31748d98951dULL, 0xc6ef5bf4737dcf70ULL, 0xfffffffffffffffeULL, 0x0fffffffffffffffULL}};
+}
+SP_HD Fq fq_R2() {  // ristretto255.rs:315-320
+  return Fq{{0xa40611e3449c0f01ULL, 0xd00e1ba768859347ULL, 0xceec73d217f5be65ULL, 0x0399411b7c309a3dULL}};
+}
+SP_HD Fq fq_R3() {  // ristretto255.rs:323-328
+  return Fq{{0x2a9e49687b83a2dbULL, 0x278324e6aef7f3ecULL, 0x8065dc6c04ec5b65ULL, 0x0e530b773599cec7ULL}};
+}
+SP_HD bool fq_is_zero(const Fq& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+SP_HD bool fq_eq(const Fq& a, const Fq& b) {
+  return ((a.l[0] ^ b.l[0]) | (a.l[1] ^ b.l[1]) | (a.l[2] ^ b.l[2]) | (a.l[3] ^ b.l[3])) == 0;
+}
+
+// t - q if t >= q else t   (t < 2q)
+SP_HD Fq fq_csub(const Fq& t) {
+  const uint64_t Q[4] = {SP_Q0, SP_Q1, SP_Q2, SP_Q3};
+  Fq d;
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u128 x = (u128)t.l[i] - Q[i] - borrow;
+    d.l[i] = (uint64_t)x;
+    borrow = (uint64_t)(x >> 64) & 1;
+  }
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
+  return r;
+}
+SP_HD Fq fq_add(const Fq& a, const Fq& b) {  // ristretto255.rs:736-745
+  Fq s;
+  u128 c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.l[i] + b.l[i];
+    s.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  return fq_csub(s);  // a,b < q < 2^253: no carry out
+}
+SP_HD Fq fq_sub(const Fq& a, const Fq& b) {  // ristretto255.rs:718-733
+  const uint64_t Q[4] = {SP_Q0, SP_Q1, SP_Q2, SP_Q3};
+  Fq d;
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u128 x = (u128)a.l[i] - b.l[i] - borrow;
+    d.l[i] = (uint64_t)x;
+    borrow = (uint64_t)(x >> 64) & 1;
+  }
+  uint64_t mask = 0 - borrow;
+  u128 c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u128)d.l[i] + (Q[i] & mask);
+    d.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  return d;
+}
+SP_HD Fq fq_neg(const Fq& a) { return fq_sub(fq_zero(), a); }  // 0-0 = 0 stays canonical
+SP_HD Fq fq_dbl(const Fq& a) { return fq_add(a, a); }
+
+// Montgomery reduction of a 512-bit value (< q*2^256): returns t/2^256 mod q in [0,q). ristretto255.rs:642-686
+SP_HD Fq fq_mont_reduce(const uint64_t tin[8]) {
+  const uint64_t Q[4] = {SP_Q0, SP_Q1, SP_Q2, SP_Q3};
+  uint64_t r[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) r[i] = tin[i];
+  uint64_t carry2 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint64_t k = r[i] * SP_QINV;
+    u128 c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c += (u128)k * Q[j] + r[i + j];
+      r[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += (u128)r[i + 4] + carry2;
+    r[i + 4] = (uint64_t)c;
+    carry2 = (uint64_t)(c >> 64);
+  }
+  Fq t = {{r[4], r[5], r[6], r[7]}};
+  return fq_csub(t);
+}
+SP_HD Fq fq_mul(const Fq& a, const Fq& b) {  // ristretto255.rs:690-714
+  uint64_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a.l[i] * b.l[j] + r[i + j];
+      r[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    r[i + 4] = (uint64_t)c;
+  }
+  return fq_mont_reduce(r);
+}
+SP_HD Fq fq_sqr(const Fq& a) { return fq_mul(a, a); }
+// Montgomery form -> canonical integer limbs (Scalar::to_bytes, ristretto255.rs:419-431)
+SP_HD Fq fq_from_mont(const Fq& a) {
+  uint64_t r[8] = {a.l[0], a.l[1], a.l[2], a.l[3], 0, 0, 0, 0};
+  return fq_mont_reduce(r);
+}
+SP_HD Fq fq_to_mont(const Fq& canonical) { return fq_mul(canonical, fq_R2()); }
+SP_HD Fq fq_from_u64(uint64_t v) { return fq_mul(Fq{{v, 0, 0, 0}}, fq_R2()); }  // ristretto255.rs:222-226
+SP_HD Fq fq_from_u512(const uint64_t w[8]) {                                      // ristretto255.rs:448-466
+  Fq d0 = {{w[0], w[1], w[2], w[3]}}, d1 = {{w[4], w[5], w[6], w[7]}};
+  return fq_add(fq_mul(d0, fq_R2()), fq_mul(d1, fq_R3()));
+}
+SP_HD Fq fq_pow(const Fq& a, const uint64_t e[4]) {
+  Fq res = fq_one();
+  for (int w = 3; w >= 0; w--)
+    for (int i = 63; i >= 0; i--) {
+      res = fq_sqr(res);
+      if ((e[w] >> i) & 1) res = fq_mul(res, a);
+    }
+  return res;
+}
+SP_HD Fq fq_invert(const Fq& a) {  // value of ristretto255.rs:541-595: a^(q-2)
+  const uint64_t e[4] = {SP_Q0 - 2, SP_Q1, SP_Q2, SP_Q3};
+  return fq_pow(a, e);
+}
+
+SP_HD Fq operator+(const Fq& a, const Fq& b) { return fq_add(a, b); }
+SP_HD Fq operator-(const Fq& a, const Fq& b) { return fq_sub(a, b); }
+SP_HD Fq operator*(const Fq& a, const Fq& b) { return fq_mul(a, b); }
+SP_HD Fq operator-(const Fq& a) { return fq_neg(a); }
+SP_HD bool operator==(const Fq& a, const Fq& b) { return fq_eq(a, b); }
+SP_HD bool operator!=(const Fq& a, const Fq& b) { return !fq_eq(a, b); }
+SP_HD Fq& operator+=(Fq& a, const Fq& b) { a = fq_add(a, b); return a; }
+SP_HD Fq& operator-=(Fq& a, const Fq& b) { a = fq_sub(a, b); return a; }
+SP_HD Fq& operator*=(Fq& a, const Fq& b) { a = fq_mul(a, b); return a; }
+
+// ------------------------------------------------------------------ Fp
+struct Fp {
+  uint64_t v[4];
+};
+
+SP_HD Fp fp_zero() { return Fp{{0, 0, 0, 0}}; }
+SP_HD Fp fp_one() { return Fp{{1, 0, 0, 0}}; }
+
+// add `c` (< 2^64) * 1 into limb 0 with full carry propagation; returns carry out of limb 3
+SP_HD uint64_t fp_add_small(Fp& r, uint64_t x) {
+  u128 c = (u128)r.v[0] + x;
+  r.v[0] = (uint64_t)c;
+  c >>= 64;
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    c += r.v[i];
+    r.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  return (uint64_t)c;
+}
+SP_HD Fp fp_add(const Fp& a, const Fp& b) {
+  Fp r;
+  u128 c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.v[i] + b.v[i];
+    r.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  uint64_t c2 = fp_add_small(r, 38 * (uint64_t)c);  // 2^256 = 38
+  r.v[0] += 38 * c2;                                // second wrap leaves r < 38: cannot carry
+  return r;
+}
+SP_HD Fp fp_sub(const Fp& a, const Fp& b) {
+  Fp r;
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u128 x = (u128)a.v[i] - b.v[i] - borrow;
+    r.v[i] = (uint64_t)x;
+    borrow = (uint64_t)(x >> 64) & 1;
+  }
+  // a - b + 2^256 = a - b + 38 (mod p): take 38 back out
+  uint64_t s = 38 * borrow, b2 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u128 x = (u128)r.v[i] - (i == 0 ? s : 0) - b2;
+    r.v[i] = (uint64_t)x;
+    b2 = (uint64_t)(x >> 64) & 1;
+  }
+  r.v[0] -= 38 * b2;  // r wrapped to >= 2^256-38: subtracting 38 again cannot borrow
+  return r;
+}
+SP_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
+
+SP_HD Fp fp_reduce512(const uint64_t t[8]) {
+  // lo + 38*hi
+  Fp r;
+  u128 c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u128)t[i + 4] * 38 + t[i];
+    r.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  uint64_t c2 = fp_add_small(r, 38 * (uint64_t)c);  // c < 39
+  r.v[0] += 38 * c2;
+  return r;
+}
+SP_HD Fp fp_mul(const Fp& a, const Fp& b) {
+  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a.v[i] * b.v[j] + t[i + j];
+      t[i + j] = (uint64_t)c;
+      c >>= 64;
+    }
+    t[i + 4] = (uint64_t)c;
+  }
+  return fp_reduce512(t);
+}
+SP_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
+SP_HD Fp fp_mul_small(const Fp& a, uint64_t k) {  // k < 2^32
+  Fp r;
+  u128 c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.v[i] * k;
+    r.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  uint64_t c2 = fp_add_small(r, 38 * (uint64_t)c);
+  r.v[0] += 38 * c2;
+  return r;
+}
+// canonical representative in [0,p)
+SP_HD Fp fp_canon(const Fp& a) {
+  Fp t = a;
+  // fold bit 255: t = (t mod 2^255) + 19*(t >> 255)   -> t < 2^255 + 19
+  uint64_t top = t.v[3] >> 63;
+  t.v[3] &= 0x7fffffffffffffffULL;
+  fp_add_small(t, 19 * top);
+  // now t < 2^255 + 19 ; subtract p if t >= p  <=>  (t + 19) has bit 255 set
+  Fp u = t;
+  fp_add_small(u, 19);
+  uint64_t ge = u.v[3] >> 63;
+  u.v[3] &= 0x7fffffffffffffffULL;
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r.v[i] = ge ? u.v[i] : t.v[i];
+  return r;
+}
+SP_HD void fp_to_bytes(const Fp& a, uint8_t out[32]) {
+  Fp c = fp_canon(a);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(c.v[i] >> (8 * k));
+}
+SP_HD Fp fp_from_bytes(const uint8_t b[32]) {  // top bit masked (value mod 2^255), as dalek/RFC 9496
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint64_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) w |= (uint64_t)b[8 * i + k] << (8 * k);
+    r.v[i] = w;
+  }
+  r.v[3] &= 0x7fffffffffffffffULL;
+  return r;
+}
+SP_HD bool fp_is_zero(const Fp& a) {
+  Fp c = fp_canon(a);
+  return (c.v[0] | c.v[1] | c.v[2] | c.v[3]) == 0;
+}
+SP_HD bool fp_eq(const Fp& a, const Fp& b) { return fp_is_zero(fp_sub(a, b)); }
+SP_HD bool fp_is_negative(const Fp& a) { return fp_canon(a).v[0] & 1; }  // RFC 9496 §4.1
+SP_HD Fp fp_cneg(const Fp& a, bool neg) {
+  Fp n = fp_neg(a), r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r.v[i] = neg ? n.v[i] : a.v[i];
+  return r;
+}
+SP_HD Fp fp_abs(const Fp& a) { return fp_cneg(a, fp_is_negative(a)); }
+SP_HD Fp fp_select(const Fp& a, const Fp& b, bool take_b) {
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 4; i++) r.v[i] = take_b ? b.v[i] : a.v[i];
+  return r;
+}
+SP_HD Fp fp_pow2k(Fp a, int k) {
+  for (int i = 0; i < k; i++) a = fp_sqr(a);
+  return a;
+}
+// z^(2^250-1) and z^11, shared by inversion and the (p-5)/8 power
+SP_HD void fp_pow_ladder(const Fp& z, Fp* z2_250_0, Fp* z11) {
+  Fp z2 = fp_sqr(z);
+  Fp z9 = fp_mul(fp_pow2k(z2, 2), z);
+  *z11 = fp_mul(z9, z2);
+  Fp z2_5_0 = fp_mul(fp_sqr(*z11), z9);
+  Fp z2_10_0 = fp_mul(fp_pow2k(z2_5_0, 5), z2_5_0);
+  Fp z2_20_0 = fp_mul(fp_pow2k(z2_10_0, 10), z2_10_0);
+  Fp z2_40_0 = fp_mul(fp_pow2k(z2_20_0, 20), z2_20_0);
+  Fp z2_50_0 = fp_mul(fp_pow2k(z2_40_0, 10), z2_10_0);
+  Fp z2_100_0 = fp_mul(fp_pow2k(z2_50_0, 50), z2_50_0);
+  Fp z2_200_0 = fp_mul(fp_pow2k(z2_100_0, 100), z2_100_0);
+  *z2_250_0 = fp_mul(fp_pow2k(z2_200_0, 50), z2_50_0);
+}
+SP_HD Fp fp_invert(const Fp& z) {  // z^(p-2)
+  Fp t, z11;
+  fp_pow_ladder(z, &t, &z11);
+  return fp_mul(fp_pow2k(t, 5), z11);
+}
+SP_HD Fp fp_pow_p58(const Fp& z) {  // z^((p-5)/8)
+  Fp t, z11;
+  fp_pow_ladder(z, &t, &z11);
+  return fp_mul(fp_pow2k(t, 2), z);
+}
+
+}  // namespace sp

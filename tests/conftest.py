@@ -1,0 +1,22 @@
+import os, sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from tests import helpers
+    return helpers.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def hc():
+    from tests import helpers
+    return helpers.load_hostcheck()

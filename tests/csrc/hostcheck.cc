@@ -1,0 +1,60 @@
+// TEST INFRASTRUCTURE (not part of the product): compiles spartan_amd/csrc/{field,curve,msm}.hpp for the
+// host so the exact arithmetic source that runs on gfx950 can be checked against the oracle on a CPU-only
+// machine. Never loaded by spartan_amd itself.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../spartan_amd/csrc/msm.hpp"
+
+using namespace sp;
+static Fq L(const uint64_t* p) { Fq x; memcpy(x.l, p, 32); return x; }
+static void O(const Fq& x, uint64_t* o) { memcpy(o, x.l, 32); }
+
+extern "C" {
+void hc_fq_mul(const uint64_t* a, const uint64_t* b, uint64_t* o) { O(fq_mul(L(a), L(b)), o); }
+void hc_fq_add(const uint64_t* a, const uint64_t* b, uint64_t* o) { O(fq_add(L(a), L(b)), o); }
+void hc_fq_sub(const uint64_t* a, const uint64_t* b, uint64_t* o) { O(fq_sub(L(a), L(b)), o); }
+void hc_fq_neg(const uint64_t* a, uint64_t* o) { O(fq_neg(L(a)), o); }
+void hc_fq_invert(const uint64_t* a, uint64_t* o) { O(fq_invert(L(a)), o); }
+void hc_fq_from_mont(const uint64_t* a, uint64_t* o) { O(fq_from_mont(L(a)), o); }
+void hc_fq_from_u512(const uint64_t* w, uint64_t* o) { O(fq_from_u512(w), o); }
+void hc_fq_from_u64(uint64_t v, uint64_t* o) { O(fq_from_u64(v), o); }
+
+// Fp: bytes in (any 32 bytes, top bit masked) -> canonical bytes out
+void hc_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* o) { fp_to_bytes(fp_mul(fp_from_bytes(a), fp_from_bytes(b)), o); }
+void hc_fp_add(const uint8_t* a, const uint8_t* b, uint8_t* o) { fp_to_bytes(fp_add(fp_from_bytes(a), fp_from_bytes(b)), o); }
+void hc_fp_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) { fp_to_bytes(fp_sub(fp_from_bytes(a), fp_from_bytes(b)), o); }
+void hc_fp_invert(const uint8_t* a, uint8_t* o) { fp_to_bytes(fp_invert(fp_from_bytes(a)), o); }
+// raw 256-bit limbs (exercises weakly-reduced inputs >= p, >= 2^255)
+void hc_fp_mul_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_mul(x, y), o); }
+void hc_fp_add_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_add(x, y), o); }
+void hc_fp_sub_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_sub(x, y), o); }
+
+int hc_pt_recompress(const uint8_t* in, uint8_t* out) { Pt p; if (!pt_decompress(in, &p)) return 0; pt_compress(p, out); return 1; }
+void hc_pt_from_uniform(const uint8_t* in64, uint8_t* out) { pt_compress(pt_from_uniform_bytes(in64), out); }
+int hc_pt_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { Pt p, q; if (!pt_decompress(a, &p) || !pt_decompress(b, &q)) return 0; pt_compress(pt_add(p, q), out); return 1; }
+int hc_pt_dbl(const uint8_t* a, uint8_t* out) { Pt p; if (!pt_decompress(a, &p)) return 0; pt_compress(pt_dbl(p), out); return 1; }
+
+// fixed-base table MSM exactly as the device does it: build tables like k_table_build, accumulate like k_msm_rows
+int hc_msm_fixed(const uint8_t* pts_comp, size_t n, const uint64_t* scalars, uint8_t* out) {
+  std::vector<Niels> table(n * MSM_PT_ENTRIES);
+  for (size_t i = 0; i < n; i++) {
+    Pt P;
+    if (!pt_decompress(pts_comp + 32 * i, &P)) return 0;
+    Pt base = P;
+    for (int w = 0; w < MSM_NWIN; w++) {
+      Pt acc = base;
+      for (int m = 1; m <= MSM_TENT; m++) {
+        table[msm_tidx(i, w, m)] = pt_to_niels(acc, fp_invert(acc.Z));
+        if (m < MSM_TENT) acc = pt_add(acc, base);
+      }
+      for (int k = 0; k < MSM_WBITS; k++) base = pt_dbl(base);
+    }
+  }
+  Pt acc = pt_identity();
+  for (size_t i = 0; i < n; i++) msm_accumulate(acc, L(scalars + 4 * i), table.data(), i);
+  pt_compress(acc, out);
+  return 1;
+}
+}

@@ -1,0 +1,88 @@
+"""Test-side helpers: ctypes loaders for the ORACLE (oracle/liboracle.so), the host-compiled arithmetic
+check shim (tests/csrc/libhostcheck.so) and Python big-int ground truth. Test infrastructure only."""
+import ctypes, os, subprocess, random
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = 2**252 + 27742317777372353535851937790883648493
+P = 2**255 - 19
+R = 2**256 % Q
+RINV = pow(R, Q - 2, Q)
+u64x4 = ctypes.c_uint64 * 4
+vp = ctypes.c_void_p
+sz = ctypes.c_size_t
+
+
+def _build_if_missing(path, cmd, cwd=ROOT):
+    if not os.path.exists(path):
+        subprocess.check_call(cmd, cwd=cwd, shell=True)
+
+
+def load_oracle():
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    _build_if_missing(so, "make -C oracle")
+    L = ctypes.CDLL(so)
+    for f in ("orc_instance_synthetic", "orc_instance_new", "orc_snark_gens_new", "orc_nizk_gens_new", "orc_snark_encode",
+              "orc_snark_prove", "orc_nizk_prove"):
+        getattr(L, f).restype = vp
+    for f in ("orc_proof_bytes", "orc_instance_nnz", "orc_instance_shape_bincode", "orc_encode_comm", "orc_merlin_script"):
+        getattr(L, f).restype = sz
+    return L
+
+
+def load_hostcheck():
+    so = os.path.join(ROOT, "tests", "csrc", "libhostcheck.so")
+    src = os.path.join(ROOT, "tests", "csrc", "hostcheck.cc")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call("g++ -O2 -std=c++17 -fPIC -shared -Wno-unknown-pragmas tests/csrc/hostcheck.cc -o tests/csrc/libhostcheck.so",
+                              cwd=ROOT, shell=True)
+    return ctypes.CDLL(so)
+
+
+# ---- scalar helpers: python int (canonical value) <-> Montgomery limbs
+def to_mont_limbs(x):
+    m = (x % Q) * R % Q
+    return u64x4(*[(m >> (64 * i)) & (2**64 - 1) for i in range(4)])
+
+
+def from_mont_limbs(l):
+    m = sum(int(l[i]) << (64 * i) for i in range(4))
+    assert m < Q, "limbs not fully reduced"
+    return m * RINV % Q
+
+
+def mont_array(vals):
+    arr = (ctypes.c_uint64 * (4 * len(vals)))()
+    for k, x in enumerate(vals):
+        m = (x % Q) * R % Q
+        for i in range(4):
+            arr[4 * k + i] = (m >> (64 * i)) & (2**64 - 1)
+    return arr
+
+
+def from_mont_array(arr, n):
+    out = []
+    for k in range(n):
+        m = sum(int(arr[4 * k + i]) << (64 * i) for i in range(4))
+        assert m < Q
+        out.append(m * RINV % Q)
+    return out
+
+
+def rand_scalars(rng, n, kind="uniform"):
+    if kind == "uniform":
+        return [rng.randrange(Q) for _ in range(n)]
+    if kind == "small":
+        return [rng.randrange(1 << 20) for _ in range(n)]
+    if kind == "sparse":
+        return [rng.randrange(Q) if rng.random() < 0.5 else 0 for _ in range(n)]
+    if kind == "edge":
+        pool = [0, 1, Q - 1, 2**252, 2**252 - 1, 127, 128, 129, 255, 256, (Q - 1) // 2, 0x80 * sum(256**i for i in range(31))]
+        return [pool[rng.randrange(len(pool))] for _ in range(n)]
+    raise ValueError(kind)
+
+
+def gens_bytes(orc, n, label=b"gens_r1cs_sat"):
+    """compressed generators of MultiCommitGens::new(n, label): n points G then h (oracle)."""
+    buf = (ctypes.c_uint8 * (32 * (n + 1)))()
+    orc.orc_multi_commit_gens(sz(n), label, buf)
+    return bytes(buf)

@@ -1,0 +1,160 @@
+"""Parity of every HIP kernel behind the C ABI against the oracle, on seeded inputs (bit-exact)."""
+import ctypes, random
+import pytest
+from tests.helpers import *
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from spartan_amd import capi
+    c = capi.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def gens40(ctx, orc):
+    from spartan_amd import capi
+    g = capi.Gens(ctx, compressed=gens_bytes(orc, 39))  # 40 points: G[0..39), h = P[39]
+    yield g
+    g.free()
+
+
+def test_gens_from_uniform_matches_oracle(ctx, orc):
+    import hashlib
+    from spartan_amd import capi
+    from tests.test_oracle_pins import BASEPOINT
+    label = b"gens_r1cs_sat"
+    n = 9
+    stream = hashlib.shake_256(label + bytes.fromhex(BASEPOINT)).digest(64 * n)
+    g = capi.Gens(ctx, uniform=stream)
+    assert g.compressed == gens_bytes(orc, n - 1, label)
+    g.free()
+
+
+def test_gens_upload_rejects_bad_point(ctx, orc):
+    from spartan_amd import capi
+    good = gens_bytes(orc, 3)
+    bad = good[:32] + bytes.fromhex("00ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff") + good[64:]
+    with pytest.raises(capi.SpartanHipError, match="-4"):
+        capi.Gens(ctx, compressed=bad)
+
+
+@pytest.mark.parametrize("rows,cols,kind,blind", [(1, 1, "uniform", False), (1, 5, "edge", True), (4, 8, "uniform", True), (32, 32, "uniform", True),
+                                                  (3, 39, "sparse", False), (64, 16, "small", True), (130, 39, "uniform", True)])
+def test_commit_rows_matches_oracle(ctx, orc, gens40, rows, cols, kind, blind):
+    rng = random.Random(rows * 1000 + cols)
+    Z = rand_scalars(rng, rows * cols, kind)
+    bl = rand_scalars(rng, rows, "uniform") if blind else None
+    g = gens40.compressed
+    got = gens40.commit_rows(mont_array(Z), rows, cols, mont_array(bl) if blind else None, g_off=0, h_idx=39)
+    want = (ctypes.c_uint8 * (32 * rows))()
+    rc = orc.orc_commit_rows(g[:32 * cols], sz(cols), g[32 * 39:32 * 40], mont_array(Z), sz(rows), sz(cols), mont_array(bl) if blind else None, want)
+    assert rc == 0
+    assert got == bytes(want)
+
+
+def test_commit_rows_dev_and_offset(ctx, orc, gens40):
+    from spartan_amd import capi
+    rng = random.Random(5)
+    rows, cols = 8, 16
+    Z = rand_scalars(rng, rows * cols)
+    t = capi.Table.upload(ctx, mont_array(Z), rows * cols)
+    got = gens40.commit_rows(t, rows, cols, None, g_off=3, h_idx=39)
+    g = gens40.compressed
+    want = (ctypes.c_uint8 * (32 * rows))()
+    assert orc.orc_commit_rows(g[32 * 3:32 * (3 + cols)], sz(cols), g[32 * 39:], mont_array(Z), sz(rows), sz(cols), None, want) == 0
+    assert got == bytes(want)
+    t.free()
+
+
+def test_msm_indexed_matches_oracle(ctx, orc, gens40):
+    rng = random.Random(6)
+    idx = [39, 0, 7, 7, 20]
+    S = rand_scalars(rng, 2 * len(idx))
+    got = gens40.msm_indexed(idx, mont_array(S), rows=2)
+    g = gens40.compressed
+    pts = b"".join(g[32 * i:32 * i + 32] for i in idx)
+    out = (ctypes.c_uint8 * 32)()
+    for r in range(2):
+        assert orc.orc_pt_msm(mont_array(S[r * 5:(r + 1) * 5]), pts, sz(5), out) == 1
+        assert got[32 * r:32 * r + 32] == bytes(out)
+
+
+@pytest.mark.parametrize("ell", [1, 3, 4, 5, 11])
+def test_eq_expand_matches_oracle(ctx, orc, ell):
+    from spartan_amd import capi
+    rng = random.Random(ell)
+    r = rand_scalars(rng, ell)
+    t = capi.Table.eq(ctx, mont_array(r), ell)
+    want = (ctypes.c_uint64 * (4 << ell))()
+    orc.orc_eq_evals(mont_array(r), sz(ell), want)
+    assert list(t.download()) == list(want)
+    t.free()
+
+
+@pytest.mark.parametrize("kind,ntabs", [(0, 2), (1, 3), (2, 4)])
+@pytest.mark.parametrize("ell", [1, 2, 6, 13])
+def test_sumcheck_eval_bind_matches_oracle(ctx, orc, kind, ntabs, ell):
+    from spartan_amd import capi
+    rng = random.Random(kind * 100 + ell)
+    n = 1 << ell
+    vals = [rand_scalars(rng, n) for _ in range(ntabs)]
+    tabs = [capi.Table.upload(ctx, mont_array(v), n) for v in vals]
+    host = [mont_array(v) for v in vals] + [None] * (4 - ntabs)
+    length = n
+    first = True
+    while length >= 2:
+        want = (ctypes.c_uint64 * 12)()
+        orc.orc_sumcheck_eval(ctypes.c_int(kind), host[0], host[1], host[2], host[3], sz(length), want)
+        if first:
+            got = capi.sumcheck_eval(ctx, kind, tabs)
+        nv = 8 if kind == 0 else 12
+        assert list(got)[:nv] == list(want)[:nv], f"len {length}"
+        r = mont_array([rng.randrange(Q)])
+        for k in range(ntabs):
+            orc.orc_bound_top(host[k], sz(length), r)
+        length //= 2
+        if length >= 2 and (ell % 2 == 0 or length > 4):
+            got = capi.sumcheck_bind_eval(ctx, kind, tabs, r)   # fused path
+            first = False
+        else:
+            capi.bind_top(ctx, tabs, r)                         # unfused path
+            first = True
+        for k in range(ntabs):
+            assert len(tabs[k]) == length
+            assert list(tabs[k].download(length)) == list(host[k])[:4 * length]
+    hd = capi.heads(ctx, tabs)
+    for k in range(ntabs):
+        assert list(hd)[4 * k:4 * k + 4] == list(host[k])[:4]
+    for t in tabs:
+        t.free()
+
+
+@pytest.mark.parametrize("v", [2, 5, 10, 13])
+def test_vecmat_dot_evaluate_match_oracle(ctx, orc, v):
+    from spartan_amd import capi
+    rng = random.Random(v)
+    n = 1 << v
+    Z = rand_scalars(rng, n)
+    Ls = 1 << (v // 2)
+    Lv = rand_scalars(rng, Ls)
+    t = capi.Table.upload(ctx, mont_array(Z), n)
+    got = capi.vecmat(ctx, mont_array(Lv), Ls, t)
+    want = (ctypes.c_uint64 * (4 * (n // Ls)))()
+    orc.orc_bound_vecmat(mont_array(Z), sz(v), mont_array(Lv), want)
+    assert list(got) == list(want)
+    B = rand_scalars(rng, n)
+    tb = capi.Table.upload(ctx, mont_array(B), n)
+    d = capi.dot(ctx, t, tb, n)
+    assert from_mont_limbs(d) == sum(a * b for a, b in zip(Z, B)) % Q
+    r = rand_scalars(rng, v)
+    e = capi.evaluate(ctx, t, mont_array(r), v)
+    chi = (ctypes.c_uint64 * (4 * n))()
+    orc.orc_eq_evals(mont_array(r), sz(v), chi)
+    w = u64x4()
+    orc.orc_dot(mont_array(Z), chi, sz(n), w)
+    assert list(e) == list(w)
+    t.free(); tb.free()
