@@ -104,6 +104,72 @@ int32_t sp_evaluate(sp_ctx* ctx, const sp_table* Z, const uint64_t* r, size_t el
 /* Read element 0 of each table (final claims after the last round: poly[0]). */
 int32_t sp_table_heads(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, uint64_t* out /*4*ntabs*/);
 
+/* ---- sparse matrices: SparseMatPolynomial (src/sparse_mlpoly.rs:19-38, 429-481) ----------------------
+ * Entries (row, col, val). Upload keeps a row-sorted (CSR) and a column-sorted (CSC) copy on the device so
+ * both products are gather-only (F_q has no atomic add). */
+typedef struct sp_sparse sp_sparse;
+int32_t sp_sparse_upload(sp_ctx* ctx, const uint64_t* rows, const uint64_t* cols, const uint64_t* vals /*4*nnz*/, size_t nnz,
+                         size_t num_rows, size_t num_cols, sp_sparse** out);
+void sp_sparse_free(sp_sparse* m);
+/* multiply_vec (sparse_mlpoly.rs:454-464): out[row] = sum val * z[col]; out has num_rows elements. */
+int32_t sp_sparse_mulvec(sp_ctx* ctx, const sp_sparse* m, const sp_table* z, sp_table** out);
+/* compute_eval_table_sparse (sparse_mlpoly.rs:466-481) for nm matrices, combined as r1csproof.rs:275-283 does:
+ * out[col] = sum_k w[k] * sum_{(row,col,val) in M_k} rx[row] * val ; out has num_cols elements. */
+int32_t sp_sparse_eval_table(sp_ctx* ctx, const sp_sparse* const* ms, const uint64_t* w /*4*nm*/, size_t nm, const sp_table* rx,
+                             sp_table** out);
+/* evaluate_with_tables (sparse_mlpoly.rs:429-438): sum tx[row] * ty[col] * val. */
+int32_t sp_sparse_evaluate(sp_ctx* ctx, const sp_sparse* m, const sp_table* tx, const sp_table* ty, uint64_t out[4]);
+
+/* ---- inner-product argument: BulletReductionProof::prove (src/nizk/bullet.rs:32-132) -----------------
+ * The folded generators G^(k) are never materialised: G^(k)[i] = sum_p s_k[p] * G[p*n_k + i] with
+ * s_{k+1}[2p] = s_k[p]*u^-1, s_{k+1}[2p+1] = s_k[p]*u, so every round's L and R are fixed-base MSMs over the
+ * ORIGINAL generators P[g_off .. g_off+n) with scalar vectors s (x) a — same group elements, same bytes.
+ * Q = q_scale * P[q_idx] (DotProductProofLog scales gens_1 by r, src/nizk/mod.rs:479-480), H = P[h_idx]. */
+typedef struct sp_ipa sp_ipa;
+int32_t sp_ipa_begin(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
+                     const uint64_t* a /*4*n*/, const uint64_t* b /*4*n*/, sp_ipa** out);
+/* bullet.rs:72-100: c_L, c_R, L = <a_L,G_R> + c_L Q + blind_L H, R = <a_R,G_L> + c_R Q + blind_R H, compressed. */
+int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]);
+/* bullet.rs:105-109: fold a, b (and the generator coefficients s) with the round challenge. */
+int32_t sp_ipa_round_fold(sp_ipa* ipa, const uint64_t u[4], const uint64_t u_inv[4]);
+/* bullet.rs:121-131: a_hat = a[0], b_hat = b[0], g_hat = G^(last)[0] (compressed; may be NULL). */
+int32_t sp_ipa_finish(sp_ipa* ipa, uint64_t a_hat[4], uint64_t b_hat[4], uint8_t* g_hat);
+/* commit(d, r) under {G: g_hat, h: H}: d * g_hat + r * H, compressed (nizk/mod.rs:496-501 `delta`). */
+int32_t sp_ipa_commit_ghat(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint8_t out[32]);
+void sp_ipa_free(sp_ipa* ipa);
+
+/* ---- SPARK: sparse-polynomial evaluation proof building blocks (src/sparse_mlpoly.rs, src/product_tree.rs) ---- */
+typedef struct sp_index sp_index; /* device-resident Vec<usize> (AddrTimestamps::ops_addr_usize, sparse_mlpoly.rs:213-219) */
+int32_t sp_index_upload(sp_ctx* ctx, const uint64_t* idx, size_t n, sp_index** out);
+void sp_index_free(sp_index* ix);
+/* DensePolynomial::from_usize (dense_mlpoly.rs:274-280) written into dst[dst_off ..]. */
+int32_t sp_table_from_index(sp_ctx* ctx, const sp_index* ix, sp_table* dst, size_t dst_off);
+/* Non-owning view of elements [off, off+len) of a table (DensePolynomial::split, dense_mlpoly.rs:140-146). The
+ * parent must outlive the view; free the view with sp_table_free. */
+int32_t sp_table_view(sp_ctx* ctx, const sp_table* parent, size_t off, size_t len, sp_table** out);
+/* AddrTimestamps::deref_mem (sparse_mlpoly.rs:256-265): dst[dst_off + i] = mem[addr[i]]. */
+int32_t sp_gather(sp_ctx* ctx, const sp_table* mem, const sp_index* addr, sp_table* dst, size_t dst_off);
+/* Layers::build_hash_layer (sparse_mlpoly.rs:529-604):
+ *   dst[dst_off+i] = (ts[i] + ts_inc) * r_hash^2 + val[i] * r_hash + addr[i] - r_multiset,  i < n
+ * addr == NULL means the identity (addr[i] = i); ts == NULL means 0. */
+int32_t sp_hash_layer(sp_ctx* ctx, const sp_table* addr, const sp_table* val, const sp_table* ts, int ts_inc, size_t n,
+                      const uint64_t r_hash[4], const uint64_t r_multiset[4], sp_table* dst, size_t dst_off);
+/* ProductCircuit::new (product_tree.rs:36-56). `store` has 2n elements with the n leaves in [0,n); layer k
+ * (n/2^k elements, left half then right half) is written at offset 2n - 2n/2^k for k = 1..log2(n)-1. */
+int32_t sp_product_tree(sp_ctx* ctx, sp_table* store, size_t n);
+/* prove_cubic_batched evaluations (sumcheck.rs:287-357): for each instance k, the sums of A_k*B_k*C_k at
+ * t = 0, 2, 3 over the current length -> out[4*(3k + {0,1,2})]. Tables may repeat across instances. */
+int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out);
+/* Fused round: bind every A_k and B_k at r (in place, halving them), evaluate the next round on the bound
+ * values; C tables are read and bound on the fly but NOT written — bind the distinct C tables afterwards
+ * with sp_table_bind_top. Requires current length >= 4. */
+int32_t sp_sumcheck_bind_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst,
+                                      const uint64_t r[4], uint64_t* out);
+/* out[k] = <chi, T_k> for k < nt (the ~23 DensePolynomial::evaluate calls of HashLayerProof::prove share chi). */
+int32_t sp_dot_many(sp_ctx* ctx, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out /*4*nt*/);
+/* DotProductCircuit::evaluate (product_tree.rs:84-88): sum l[i]*r[i]*w[i] over n elements from the given offsets. */
+int32_t sp_dot3(sp_ctx* ctx, const sp_table* l, const sp_table* r, const sp_table* w, size_t off, size_t n, uint64_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,413 @@
+// spartan_amd: context, generators (window tables), fixed-base MSM, device tables.
+#include "internal.hpp"
+
+const char* kProfNames[PF_COUNT] = {"gens_table_build", "msm_rows_fixed", "msm_reduce_compress", "eq_expand", "sumcheck_eval",
+                                    "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "misc"};
+
+int32_t ensure(void** p, size_t* cap, size_t need) {
+  if (*cap >= need) return SP_OK;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  size_t want = need + need / 4 + 4096;
+  HIPCHK(hipMalloc(p, want));
+  *cap = want;
+  return SP_OK;
+}
+int32_t ensure_pinned(sp_ctx* c, size_t need) {
+  if (c->pinned_cap >= need) return SP_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));  // an async copy may still read the old buffer
+  if (c->pinned) HIPCHK(hipHostFree(c->pinned));
+  c->pinned = nullptr;
+  c->pinned_cap = 0;
+  size_t want = need * 2 + 4096;
+  HIPCHK(hipHostMalloc((void**)&c->pinned, want, hipHostMallocDefault));
+  c->pinned_cap = want;
+  return SP_OK;
+}
+void prof_drain(sp_ctx* c) {
+  if (c->pending.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& r : c->pending) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    c->prof_ms[r.fam] += ms;
+    c->prof_n[r.fam] += 1;
+    c->free_events.push_back(r.e0);
+    c->free_events.push_back(r.e1);
+  }
+  c->pending.clear();
+}
+// copy small host data to the device staging buffer at byte offset off
+int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes) {
+  SPCHK(ensure_pinned(c, off + bytes));
+  memcpy(c->pinned + off, src, bytes);
+  HIPCHK(hipMemcpyAsync((uint8_t*)c->dstage + off, c->pinned + off, bytes, hipMemcpyHostToDevice, c->stream));
+  return SP_OK;
+}
+int32_t ensure_dstage(sp_ctx* c, size_t need) {
+  if (c->dstage_cap >= need) return SP_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ensure(&c->dstage, &c->dstage_cap, need);
+}
+// device -> host through pinned memory, synchronous
+int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes) {
+  SPCHK(ensure_pinned(c, bytes));
+  HIPCHK(hipMemcpyAsync(c->pinned, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(hdst, c->pinned, bytes);
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ generators
+// stage 1: decode / map points. mode 0: compressed in (32 B); mode 1: uniform in (64 B) -> also writes compressed.
+__global__ void k_points_load(const uint8_t* __restrict__ in, int mode, size_t n, Pt* __restrict__ pts, uint8_t* __restrict__ comp_out,
+                              int* __restrict__ bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Pt p;
+  if (mode == 0) {
+    uint8_t b[32];
+    for (int k = 0; k < 32; k++) b[k] = in[32 * i + k];
+    if (!pt_decompress(b, &p)) {
+      atomicExch(bad, 1);
+      p = pt_identity();
+    }
+  } else {
+    uint8_t b[64];
+    for (int k = 0; k < 64; k++) b[k] = in[64 * i + k];
+    p = pt_from_uniform_bytes(b);
+    if (comp_out) {
+      uint8_t c[32];
+      pt_compress(p, c);
+      for (int k = 0; k < 32; k++) comp_out[32 * i + k] = c[k];
+    }
+  }
+  pts[i] = p;
+}
+// stage 2: one thread per (point, window): entries k * 2^(8w) * P, k = 1..128, affine Niels.
+__global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __restrict__ table) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * MSM_NWIN) return;
+  size_t pt = t / MSM_NWIN;
+  int w = (int)(t % MSM_NWIN);
+  Pt base = pts[pt];
+  for (int k = 0; k < MSM_WBITS * w; k++) base = pt_dbl(base);
+  Pt acc = base;
+  for (int m = 1; m <= MSM_TENT; m++) {
+    Fp zinv = fp_invert(acc.Z);
+    table[msm_tidx(pt, w, m)] = pt_to_niels(acc, zinv);
+    if (m < MSM_TENT) acc = pt_add(acc, base);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ MSM
+// thread <-> (row, strip): accumulates sum_{j in strip} Z[row][j] * P[col(j)] into one extended point.
+// Lanes run fastest over rows so a wave shares the generator (and its 12 KiB window sub-table) whenever
+// rows >= 64: table gathers then hit L1/L2, while the scalar load (32 B per 32 additions) is the strided one.
+__global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
+                                                  size_t nstrips, const Niels* __restrict__ table, size_t g_off,
+                                                  const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx,
+                                                  Pt* __restrict__ partial) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * nstrips) return;
+  size_t row = t % rows, s = t / rows;
+  Pt acc = pt_identity();
+  size_t j0 = s * strip, j1 = j0 + strip;
+  if (j1 > cols) j1 = cols;
+  for (size_t j = j0; j < j1; j++) {
+    Fq sc = ld_fq(Z + row * z_row_stride + j);
+    size_t pt = idx ? (size_t)idx[j] : g_off + j;
+    msm_accumulate(acc, sc, table, pt);
+  }
+  if (blinds && s == 0) msm_accumulate(acc, ld_fq(blinds + row), table, h_idx);
+  partial[row * nstrips + s] = acc;
+}
+// one block per row: sum the row's strip partials, compress.
+__global__ void __launch_bounds__(256) k_msm_reduce(const Pt* __restrict__ partial, size_t nstrips, uint8_t* __restrict__ out) {
+  __shared__ Pt sm[256];
+  size_t row = blockIdx.x;
+  int t = threadIdx.x;
+  Pt acc = pt_identity();
+  bool any = false;
+  for (size_t s = t; s < nstrips; s += 256) {
+    Pt p = partial[row * nstrips + s];
+    acc = any ? pt_add(acc, p) : p;
+    any = true;
+  }
+  sm[t] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s && (size_t)(t + s) < nstrips) sm[t] = pt_add(sm[t], sm[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    uint8_t c[32];
+    pt_compress(sm[0], c);
+    for (int k = 0; k < 32; k++) out[32 * row + k] = c[k];
+  }
+}
+
+
+extern "C" {
+
+const char* sp_strerror(int32_t s) {
+  switch (s) {
+    case SP_OK: return "ok";
+    case SP_EINVAL: return "invalid argument";
+    case SP_ENOMEM: return "out of device memory";
+    case SP_EHIP: return "HIP runtime error or no gfx950 device";
+    case SP_EPOINT: return "invalid ristretto255 encoding";
+    default: return "unknown";
+  }
+}
+const char* sp_version(void) { return "spartan_amd 0.1 (gfx950)"; }
+
+int32_t sp_ctx_create(int device_id, sp_ctx** out) {
+  if (!out) return SP_EINVAL;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "spartan_hip: no HIP device available (this library has no CPU fallback)\n");
+    return SP_EHIP;
+  }
+  if (device_id < 0 || device_id >= ndev) return SP_EINVAL;
+  HIPCHK(hipSetDevice(device_id));
+  sp_ctx* c = new (std::nothrow) sp_ctx();
+  if (!c) return SP_ENOMEM;
+  c->dev = device_id;
+  c->scratch = c->scratch2 = c->dstage = nullptr;
+  c->scratch_cap = c->scratch2_cap = c->dstage_cap = 0;
+  c->pinned = nullptr;
+  c->pinned_cap = 0;
+  c->prof_on = 0;
+  memset(c->prof_ms, 0, sizeof c->prof_ms);
+  memset(c->prof_n, 0, sizeof c->prof_n);
+  memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  *out = c;
+  return SP_OK;
+}
+void sp_ctx_destroy(sp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  prof_drain(c);
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->scratch2) (void)hipFree(c->scratch2);
+  if (c->dstage) (void)hipFree(c->dstage);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+int32_t sp_prof_enable(sp_ctx* c, int on) {
+  if (!c) return SP_EINVAL;
+  prof_drain(c);
+  c->prof_on = on;
+  return SP_OK;
+}
+int32_t sp_prof_reset(sp_ctx* c) {
+  if (!c) return SP_EINVAL;
+  prof_drain(c);
+  memset(c->prof_ms, 0, sizeof c->prof_ms);
+  memset(c->prof_n, 0, sizeof c->prof_n);
+  memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+  return SP_OK;
+}
+int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap) {
+  if (!c) return SP_EINVAL;
+  prof_drain(c);
+  for (int i = 0; i < PF_COUNT && i < cap; i++) {
+    if (names) names[i] = kProfNames[i];
+    if (total_ms) total_ms[i] = c->prof_ms[i];
+    if (launches) launches[i] = c->prof_n[i];
+    if (alg_bytes) alg_bytes[i] = c->prof_bytes[i];
+  }
+  return PF_COUNT;
+}
+
+
+static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint8_t* comp_out, sp_gens** out) {
+  if (!c || !in || !out || n == 0) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t in_bytes = (mode == 0 ? 32 : 64) * n;
+  // scratch layout: [in bytes][pad][Pt n][comp 32n][bad int]
+  size_t off_pts = (in_bytes + 255) & ~(size_t)255;
+  size_t off_comp = off_pts + n * sizeof(Pt);
+  size_t off_bad = off_comp + ((32 * n + 255) & ~(size_t)255);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, off_bad + 256));
+  uint8_t* base = (uint8_t*)c->scratch;
+  HIPCHK(hipMemcpyAsync(base, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(base + off_bad, 0, 4, c->stream));
+  Niels* table = nullptr;
+  HIPCHK(hipMalloc((void**)&table, n * MSM_PT_ENTRIES * sizeof(Niels)));
+  {
+    ProfScope ps(c, PF_GENS_TABLE, (double)n * MSM_PT_ENTRIES * sizeof(Niels));
+    hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
+                       (mode == 1 && comp_out) ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
+    size_t nt = n * MSM_NWIN;
+    hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table);
+  }
+  int bad = 0;
+  int32_t rc = fetch_out(c, base + off_bad, &bad, 4);
+  if (rc == SP_OK && mode == 1 && comp_out) rc = fetch_out(c, base + off_comp, comp_out, 32 * n);
+  if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = SP_EHIP;
+  if (rc != SP_OK || bad) {
+    (void)hipFree(table);
+    return rc != SP_OK ? rc : SP_EPOINT;
+  }
+  sp_gens* g = new (std::nothrow) sp_gens();
+  if (!g) { (void)hipFree(table); return SP_ENOMEM; }
+  g->ctx = c;
+  g->n = n;
+  g->table = table;
+  *out = g;
+  return SP_OK;
+}
+int32_t sp_gens_upload(sp_ctx* c, const uint8_t* compressed, size_t n, sp_gens** out) { return gens_build(c, compressed, 0, n, nullptr, out); }
+int32_t sp_gens_from_uniform(sp_ctx* c, const uint8_t* uniform, size_t n, uint8_t* compressed_out, sp_gens** out) {
+  return gens_build(c, uniform, 1, n, compressed_out, out);
+}
+size_t sp_gens_len(const sp_gens* g) { return g ? g->n : 0; }
+void sp_gens_free(sp_gens* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->dev);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  (void)hipFree(g->table);
+  delete g;
+}
+
+// core: Z on device (row stride in elements), optional idx (device), optional blinds (device)
+int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
+                          const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
+  size_t total = rows * cols;
+  size_t strip = total / 131072;
+  if (strip < 1) strip = 1;
+  if (strip > cols) strip = cols;
+  size_t nstrips = (cols + strip - 1) / strip;
+  size_t part_bytes = rows * nstrips * sizeof(Pt);
+  size_t off_out = (part_bytes + 255) & ~(size_t)255;
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, off_out + 32 * rows));
+  Pt* partial = (Pt*)c->scratch;
+  uint8_t* dout = (uint8_t*)c->scratch + off_out;
+  size_t nthreads = rows * nstrips;
+  {
+    ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
+    hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols, strip, nstrips,
+                       (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
+  }
+  {
+    ProfScope ps(c, PF_MSM_REDUCE, (double)part_bytes);
+    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)rows), dim3(256), 0, c->stream, (const Pt*)partial, nstrips, dout);
+  }
+  SPCHK(fetch_out(c, dout, out_host, 32 * rows));
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  return SP_OK;
+}
+
+int32_t sp_commit_rows_dev(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
+                           const uint64_t* blinds, uint8_t* out) {
+  if (!c || !g || !Z || !out || rows == 0 || cols == 0) return SP_EINVAL;
+  if (g_off + cols > g->n || (blinds && h_idx >= g->n) || z_off + rows * cols > Z->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  const Fq* dbl = nullptr;
+  if (blinds) {
+    SPCHK(ensure_dstage(c, 32 * rows));
+    SPCHK(stage_in(c, 0, blinds, 32 * rows));
+    dbl = (const Fq*)c->dstage;
+  }
+  return msm_launch(c, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, dbl, h_idx, out);
+}
+int32_t sp_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const uint64_t* Z, size_t rows, size_t cols,
+                       const uint64_t* blinds, uint8_t* out) {
+  if (!c || !g || !Z || !out || rows == 0 || cols == 0) return SP_EINVAL;
+  if (g_off + cols > g->n || (blinds && h_idx >= g->n)) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t zb = 32 * rows * cols;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  SPCHK(ensure(&c->scratch2, &c->scratch2_cap, zb + 32 * rows));
+  HIPCHK(hipMemcpyAsync(c->scratch2, Z, zb, hipMemcpyHostToDevice, c->stream));
+  const Fq* dbl = nullptr;
+  if (blinds) {
+    HIPCHK(hipMemcpyAsync((uint8_t*)c->scratch2 + zb, blinds, 32 * rows, hipMemcpyHostToDevice, c->stream));
+    dbl = (const Fq*)((uint8_t*)c->scratch2 + zb);
+  }
+  return msm_launch(c, g, (const Fq*)c->scratch2, cols, rows, cols, g_off, nullptr, dbl, h_idx, out);
+}
+int32_t sp_msm_indexed(sp_ctx* c, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out) {
+  if (!c || !g || !idx || !S || !out || rows == 0 || cols == 0) return SP_EINVAL;
+  for (size_t j = 0; j < cols; j++)
+    if (idx[j] >= g->n) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t sb = 32 * rows * cols, ib = (4 * cols + 31) & ~(size_t)31;
+  SPCHK(ensure_dstage(c, sb + ib));
+  SPCHK(stage_in(c, 0, S, sb));
+  SPCHK(stage_in(c, sb, idx, 4 * cols));
+  return msm_launch(c, g, (const Fq*)c->dstage, cols, rows, cols, 0, (const uint32_t*)((uint8_t*)c->dstage + sb), nullptr, 0, out);
+}
+
+// ---- tables
+int32_t sp_table_alloc(sp_ctx* c, size_t len, sp_table** out) {
+  if (!c || !out || len == 0) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  sp_table* t = new (std::nothrow) sp_table();
+  if (!t) return SP_ENOMEM;
+  t->ctx = c;
+  t->cap = t->len = len;
+  t->owner = 1;
+  t->d = nullptr;
+  hipError_t e = hipMalloc((void**)&t->d, 32 * len);
+  if (e != hipSuccess) { delete t; return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP; }
+  e = hipMemsetAsync(t->d, 0, 32 * len, c->stream);
+  if (e != hipSuccess) { (void)hipFree(t->d); delete t; return SP_EHIP; }
+  *out = t;
+  return SP_OK;
+}
+int32_t sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* Z, size_t len) {
+  if (!c || !t || !Z || off + len > t->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(t->d + off, Z, 32 * len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // caller may reuse Z immediately
+  return SP_OK;
+}
+int32_t sp_table_upload(sp_ctx* c, const uint64_t* Z, size_t len, sp_table** out) {
+  if (!Z) return SP_EINVAL;
+  SPCHK(sp_table_alloc(c, len, out));
+  int32_t rc = sp_table_write(c, *out, 0, Z, len);
+  if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; }
+  return rc;
+}
+int32_t sp_table_download(sp_ctx* c, const sp_table* t, size_t off, size_t len, uint64_t* out) {
+  if (!c || !t || !out || off + len > t->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(out, t->d + off, 32 * len, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return SP_OK;
+}
+int32_t sp_table_clone(sp_ctx* c, const sp_table* t, sp_table** out) {
+  if (!t) return SP_EINVAL;
+  SPCHK(sp_table_alloc(c, t->cap, out));
+  (*out)->len = t->len;
+  HIPCHK(hipMemcpyAsync((*out)->d, t->d, 32 * t->cap, hipMemcpyDeviceToDevice, c->stream));
+  return SP_OK;
+}
+int32_t sp_table_copy(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t len) {
+  if (!c || !dst || !src || dst_off + len > dst->cap || src_off + len > src->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(dst->d + dst_off, src->d + src_off, 32 * len, hipMemcpyDeviceToDevice, c->stream));
+  return SP_OK;
+}
+size_t sp_table_len(const sp_table* t) { return t ? t->len : 0; }
+void sp_table_free(sp_table* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->dev);
+  if (t->owner) {
+    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipFree(t->d);
+  }
+  delete t;
+}
+
+
+}  // extern "C"

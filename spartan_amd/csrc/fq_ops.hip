@@ -1,0 +1,355 @@
+// spartan_amd: F_q streaming kernels (eq tables, sum-check evaluate/bind, vector-matrix, dot products).
+#include "internal.hpp"
+
+// ------------------------------------------------------------------------------------------------ F_q streaming kernels
+// chi table: thread computes 2^LOWB consecutive entries. r[0] <-> most significant index bit.
+constexpr int EQ_LOWB = 4;
+__device__ __forceinline__ Fq eq_prefix(const Fq* __restrict__ r, size_t ell, int lowb, size_t hi) {
+  // product over the (ell - lowb) high bits of index `hi` (hi = index >> lowb)
+  Fq acc = fq_one();
+  int nh = (int)ell - lowb;
+  for (int k = 0; k < nh; k++) {
+    Fq rk = ld_fq(r + k);
+    bool bit = (hi >> (nh - 1 - k)) & 1;
+    acc = fq_mul(acc, bit ? rk : fq_sub(fq_one(), rk));
+  }
+  return acc;
+}
+__device__ __forceinline__ void eq_expand_low(Fq (&v)[1 << EQ_LOWB], const Fq* __restrict__ r, size_t ell, int lowb, const Fq& prefix) {
+  v[0] = prefix;
+  int size = 1;
+  for (int k = 0; k < lowb; k++) {
+    Fq rk = ld_fq(r + (ell - lowb + k));
+    for (int i = size - 1; i >= 0; i--) {
+      Fq hi = fq_mul(v[i], rk);
+      v[2 * i + 1] = hi;
+      v[2 * i] = fq_sub(v[i], hi);
+    }
+    size *= 2;
+  }
+}
+__global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r, size_t ell, int lowb, Fq* __restrict__ out) {
+  size_t nthreads = (size_t)1 << (ell - lowb);
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nthreads) return;
+  Fq v[1 << EQ_LOWB];
+  eq_expand_low(v, r, ell, lowb, eq_prefix(r, ell, lowb, t));
+  int cnt = 1 << lowb;
+  for (int i = 0; i < cnt; i++) st_fq(out + (t << lowb) + i, v[i]);
+}
+// <Z, chi(r)> without materialising chi; per-block partials.
+__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r, size_t ell, int lowb,
+                                                  Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  size_t nthreads = (size_t)1 << (ell - lowb);
+  Fq acc[1] = {fq_zero()};
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * blockDim.x) {
+    Fq v[1 << EQ_LOWB];
+    eq_expand_low(v, r, ell, lowb, eq_prefix(r, ell, lowb, t));
+    int cnt = 1 << lowb;
+    for (int i = 0; i < cnt; i++) acc[0] = fq_add(acc[0], fq_mul(v[i], ld_fq(Z + (t << lowb) + i)));
+  }
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
+}
+
+struct Tabs4 {
+  Fq* p[4];
+};
+// sum-check evaluations at t = 0, 2, 3 of the line through (T[i], T[i+half]); per-block partial sums.
+template <int KIND>
+__device__ __forceinline__ void sc_point(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c0, const Fq& c1, const Fq& d0,
+                                         const Fq& d1, Fq& e0, Fq& e2, Fq& e3) {
+  Fq a2 = fq_sub(fq_dbl(a1), a0), b2 = fq_sub(fq_dbl(b1), b0);
+  if (KIND == 0) {
+    e0 = fq_add(e0, fq_mul(a0, b0));
+    e2 = fq_add(e2, fq_mul(a2, b2));
+    return;
+  }
+  Fq a3 = fq_sub(fq_add(a2, a1), a0), b3 = fq_sub(fq_add(b2, b1), b0);
+  Fq c2 = fq_sub(fq_dbl(c1), c0), c3 = fq_sub(fq_add(c2, c1), c0);
+  if (KIND == 1) {
+    e0 = fq_add(e0, fq_mul(fq_mul(a0, b0), c0));
+    e2 = fq_add(e2, fq_mul(fq_mul(a2, b2), c2));
+    e3 = fq_add(e3, fq_mul(fq_mul(a3, b3), c3));
+    return;
+  }
+  Fq d2 = fq_sub(fq_dbl(d1), d0), d3 = fq_sub(fq_add(d2, d1), d0);
+  e0 = fq_add(e0, fq_mul(a0, fq_sub(fq_mul(b0, c0), d0)));
+  e2 = fq_add(e2, fq_mul(a2, fq_sub(fq_mul(b2, c2), d2)));
+  e3 = fq_add(e3, fq_mul(a3, fq_sub(fq_mul(b3, c3), d3)));
+}
+template <int KIND>
+__global__ void __launch_bounds__(256) k_sc_eval(Tabs4 T, size_t half, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
+  Fq z = fq_zero();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    Fq a0 = ld_fq(T.p[0] + i), a1 = ld_fq(T.p[0] + half + i), b0 = ld_fq(T.p[1] + i), b1 = ld_fq(T.p[1] + half + i);
+    Fq c0 = z, c1 = z, d0 = z, d1 = z;
+    if (KIND >= 1) { c0 = ld_fq(T.p[2] + i); c1 = ld_fq(T.p[2] + half + i); }
+    if (KIND == 2) { d0 = ld_fq(T.p[3] + i); d1 = ld_fq(T.p[3] + half + i); }
+    sc_point<KIND>(a0, a1, b0, b1, c0, c1, d0, d1, e[0], e[1], e[2]);
+  }
+  block_sum_fq<3>(e, sm);
+  if (threadIdx.x == 0) {
+    st_fq(partials + 3 * blockIdx.x + 0, e[0]);
+    st_fq(partials + 3 * blockIdx.x + 1, e[1]);
+    st_fq(partials + 3 * blockIdx.x + 2, e[2]);
+  }
+}
+// fused bind(r) + evaluate next round. quarter = len/4. Thread i < quarter reads T[i], T[i+q], T[i+2q], T[i+3q],
+// writes the bound values T'[i] = T[i] + r (T[i+2q]-T[i]) and T'[i+q], and evaluates the round on (T'[i], T'[i+q]).
+template <int KIND>
+__global__ void __launch_bounds__(256) k_sc_bind_eval(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  constexpr int NT = KIND == 0 ? 2 : (KIND == 1 ? 3 : 4);
+  Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quarter; i += (size_t)gridDim.x * blockDim.x) {
+    Fq lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+      Fq x0 = ld_fq(T.p[k] + i), x1 = ld_fq(T.p[k] + quarter + i), x2 = ld_fq(T.p[k] + 2 * quarter + i), x3 = ld_fq(T.p[k] + 3 * quarter + i);
+      lo[k] = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
+      hi[k] = fq_add(x1, fq_mul(r, fq_sub(x3, x1)));
+      st_fq(T.p[k] + i, lo[k]);
+      st_fq(T.p[k] + quarter + i, hi[k]);
+    }
+    Fq z = fq_zero();
+    sc_point<KIND>(lo[0], hi[0], lo[1], hi[1], NT > 2 ? lo[2] : z, NT > 2 ? hi[2] : z, NT > 3 ? lo[3] : z, NT > 3 ? hi[3] : z, e[0], e[1], e[2]);
+  }
+  block_sum_fq<3>(e, sm);
+  if (threadIdx.x == 0) {
+    st_fq(partials + 3 * blockIdx.x + 0, e[0]);
+    st_fq(partials + 3 * blockIdx.x + 1, e[1]);
+    st_fq(partials + 3 * blockIdx.x + 2, e[2]);
+  }
+}
+__global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t half, Fq r) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    for (int k = 0; k < ntabs; k++) {
+      Fq x0 = ld_fq(T.p[k] + i), x1 = ld_fq(T.p[k] + half + i);
+      st_fq(T.p[k] + i, fq_add(x0, fq_mul(r, fq_sub(x1, x0))));
+    }
+  }
+}
+// partials[nblk][K] -> out[K] ; single block
+__global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
+  __shared__ Fq sm[256];
+  for (int k = 0; k < K; k++) {
+    Fq acc[1] = {fq_zero()};
+    for (size_t b = threadIdx.x; b < nblk; b += 256) acc[0] = fq_add(acc[0], ld_fq(partials + b * K + k));
+    block_sum_fq<1>(acc, sm);
+    if (threadIdx.x == 0) st_fq(out + k, acc[0]);
+  }
+}
+// out[i] (+)= sum_{j in chunk} L[j] * Z[j*R + i] ; grid (R/256, nchunks) ; partial[chunk][i]
+__global__ void __launch_bounds__(256) k_vecmat(const Fq* __restrict__ L, size_t Lsz, const Fq* __restrict__ Z, size_t R, size_t jchunk,
+                                                Fq* __restrict__ partial) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  size_t j0 = (size_t)blockIdx.y * jchunk, j1 = j0 + jchunk;
+  if (j1 > Lsz) j1 = Lsz;
+  Fq acc = fq_zero();
+  for (size_t j = j0; j < j1; j++) acc = fq_add(acc, fq_mul(ld_fq(L + j), ld_fq(Z + j * R + i)));
+  st_fq(partial + (size_t)blockIdx.y * R + i, acc);
+}
+__global__ void __launch_bounds__(256) k_colsum(const Fq* __restrict__ partial, size_t nchunks, size_t R, Fq* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  Fq acc = fq_zero();
+  for (size_t c = 0; c < nchunks; c++) acc = fq_add(acc, ld_fq(partial + c * R + i));
+  st_fq(out + i, acc);
+}
+__global__ void __launch_bounds__(256) k_dot(const Fq* __restrict__ a, const Fq* __restrict__ b, size_t n, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  Fq acc[1] = {fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fq_add(acc[0], fq_mul(ld_fq(a + i), ld_fq(b + i)));
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
+}
+__global__ void k_gather_heads(Tabs4 T, int ntabs, Fq* __restrict__ out) {
+  int k = threadIdx.x;
+  if (k < ntabs) st_fq(out + k, ld_fq(T.p[k]));
+}
+
+
+int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out) {
+  Fq* dres = partials + nblk * K;
+  {
+    ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * K));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, dres);
+  }
+  SPCHK(fetch_out(c, dres, out, 32 * K));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+
+extern "C" {
+
+int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
+  if (!c || !r || !out || ell == 0 || ell > 40) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ensure_dstage(c, 32 * ell));
+  SPCHK(stage_in(c, 0, r, 32 * ell));
+  size_t len = (size_t)1 << ell;
+  SPCHK(sp_table_alloc(c, len, out));
+  int lowb = ell < (size_t)EQ_LOWB ? (int)ell : EQ_LOWB;
+  size_t nthreads = len >> lowb;
+  {
+    ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
+    hipLaunchKernelGGL(k_eq_expand, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, (const Fq*)c->dstage, ell, lowb, (*out)->d);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));  // dstage reusable
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+
+static int32_t tabs_check(sp_ctx* c, sp_table* const* tabs, size_t ntabs, size_t need, Tabs4* T, size_t* len) {
+  if (!c || !tabs || ntabs != need) return SP_EINVAL;
+  size_t l = tabs[0] ? tabs[0]->len : 0;
+  for (size_t k = 0; k < ntabs; k++) {
+    if (!tabs[k] || tabs[k]->len != l) return SP_EINVAL;
+    T->p[k] = tabs[k]->d;
+  }
+  for (size_t k = ntabs; k < 4; k++) T->p[k] = nullptr;
+  if (l < 2 || !is_pow2(l)) return SP_EINVAL;
+  *len = l;
+  return SP_OK;
+}
+int32_t sp_sumcheck_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntabs, uint64_t* out_evals) {
+  if (kind < 0 || kind > 2 || !out_evals) return SP_EINVAL;
+  Tabs4 T;
+  size_t len;
+  SPCHK(tabs_check(c, tabs, ntabs, kind == 0 ? 2 : (kind == 1 ? 3 : 4), &T, &len));
+  HIPCHK(hipSetDevice(c->dev));
+  size_t half = len / 2, nblk = grid_for(half, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_SC_EVAL, 32.0 * (double)len * (double)ntabs);
+    if (kind == 0) hipLaunchKernelGGL(k_sc_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
+    if (kind == 1) hipLaunchKernelGGL(k_sc_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
+    if (kind == 2) hipLaunchKernelGGL(k_sc_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
+  }
+  uint64_t e[12];
+  SPCHK(reduce_and_fetch(c, partials, nblk, 3, e));
+  memcpy(out_evals, e, 32);
+  memcpy(out_evals + 4, e + 4, 32);
+  if (kind != 0) memcpy(out_evals + 8, e + 8, 32);
+  return SP_OK;
+}
+int32_t sp_table_bind_top(sp_ctx* c, sp_table* const* tabs, size_t ntabs, const uint64_t r[4]) {
+  if (!c || !tabs || !r || ntabs == 0) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  Fq rr;
+  memcpy(rr.l, r, 32);
+  for (size_t k0 = 0; k0 < ntabs; k0 += 4) {
+    size_t nk = ntabs - k0 < 4 ? ntabs - k0 : 4;
+    Tabs4 T = {{nullptr, nullptr, nullptr, nullptr}};
+    size_t len = tabs[k0] ? tabs[k0]->len : 0;
+    for (size_t k = 0; k < nk; k++) {
+      if (!tabs[k0 + k] || tabs[k0 + k]->len != len) return SP_EINVAL;
+      T.p[k] = tabs[k0 + k]->d;
+    }
+    if (len < 2 || !is_pow2(len)) return SP_EINVAL;
+    size_t half = len / 2;
+    {
+      ProfScope ps(c, PF_SC_BIND, 48.0 * (double)len * (double)nk);
+      hipLaunchKernelGGL(k_bind_top, dim3((unsigned)grid_for(half)), dim3(256), 0, c->stream, T, (int)nk, half, rr);
+    }
+    for (size_t k = 0; k < nk; k++) tabs[k0 + k]->len = half;
+  }
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals) {
+  if (kind < 0 || kind > 2 || !out_evals || !r) return SP_EINVAL;
+  Tabs4 T;
+  size_t len;
+  SPCHK(tabs_check(c, tabs, ntabs, kind == 0 ? 2 : (kind == 1 ? 3 : 4), &T, &len));
+  if (len < 4) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  Fq rr;
+  memcpy(rr.l, r, 32);
+  size_t quarter = len / 4, nblk = grid_for(quarter, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
+    if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (kind == 2) hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+  }
+  for (size_t k = 0; k < ntabs; k++) tabs[k]->len = len / 2;
+  uint64_t e[12];
+  SPCHK(reduce_and_fetch(c, partials, nblk, 3, e));
+  memcpy(out_evals, e, 32);
+  memcpy(out_evals + 4, e + 4, 32);
+  if (kind != 0) memcpy(out_evals + 8, e + 8, 32);
+  return SP_OK;
+}
+int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, uint64_t* out) {
+  if (!c || !L || !Z || !out || Lsz == 0 || Z->len % Lsz) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t R = Z->len / Lsz;
+  SPCHK(ensure_dstage(c, 32 * Lsz));
+  SPCHK(stage_in(c, 0, L, 32 * Lsz));
+  size_t nchunks = Lsz < 64 ? 1 : 64;
+  while (nchunks > 1 && (R / 256 + 1) * nchunks > 4096) nchunks /= 2;
+  size_t jchunk = (Lsz + nchunks - 1) / nchunks;
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nchunks * R + R)));
+  Fq* partial = (Fq*)c->scratch;
+  Fq* dres = partial + nchunks * R;
+  {
+    ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R);
+    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 255) / 256), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
+                       (const Fq*)Z->d, R, jchunk, partial);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, dres);
+  }
+  SPCHK(fetch_out(c, dres, out, 32 * R));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]) {
+  if (!c || !a || !b || !out || n == 0 || a_off + n > a->cap || b_off + n > b->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t nblk = grid_for(n, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_DOT, 64.0 * (double)n);
+    hipLaunchKernelGGL(k_dot, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)(a->d + a_off), (const Fq*)(b->d + b_off), n, partials);
+  }
+  return reduce_and_fetch(c, partials, nblk, 1, out);
+}
+int32_t sp_evaluate(sp_ctx* c, const sp_table* Z, const uint64_t* r, size_t ell, uint64_t out[4]) {
+  if (!c || !Z || !r || !out || ell == 0 || ell > 40 || Z->len != ((size_t)1 << ell)) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ensure_dstage(c, 32 * ell));
+  SPCHK(stage_in(c, 0, r, 32 * ell));
+  int lowb = ell < (size_t)EQ_LOWB ? (int)ell : EQ_LOWB;
+  size_t nthreads = Z->len >> lowb, nblk = grid_for(nthreads, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_DOT, 32.0 * (double)Z->len);
+    hipLaunchKernelGGL(k_evaluate, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)Z->d, (const Fq*)c->dstage, ell, lowb, partials);
+  }
+  return reduce_and_fetch(c, partials, nblk, 1, out);
+}
+int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t* out) {
+  if (!c || !tabs || !out || ntabs == 0) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 4));
+  for (size_t k0 = 0; k0 < ntabs; k0 += 4) {
+    size_t nk = ntabs - k0 < 4 ? ntabs - k0 : 4;
+    Tabs4 T = {{nullptr, nullptr, nullptr, nullptr}};
+    for (size_t k = 0; k < nk; k++) {
+      if (!tabs[k0 + k]) return SP_EINVAL;
+      T.p[k] = tabs[k0 + k]->d;
+    }
+    hipLaunchKernelGGL(k_gather_heads, dim3(1), dim3(64), 0, c->stream, T, (int)nk, (Fq*)c->scratch);
+    SPCHK(fetch_out(c, c->scratch, out + 4 * k0, 32 * nk));
+  }
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+
+}  // extern "C"

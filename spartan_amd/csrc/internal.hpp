@@ -1,0 +1,173 @@
+// spartan_amd: internal declarations shared by the HIP translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/spartan_hip.h"
+#include "curve.hpp"
+#include "field.hpp"
+#include "msm.hpp"
+
+using namespace sp;
+
+// ------------------------------------------------------------------------------------------------ host structs
+enum ProfFamily {
+  PF_GENS_TABLE = 0,
+  PF_MSM_ROWS,
+  PF_MSM_REDUCE,
+  PF_EQ_EXPAND,
+  PF_SC_EVAL,
+  PF_SC_BIND,
+  PF_SC_BIND_EVAL,
+  PF_VECMAT,
+  PF_DOT,
+  PF_REDUCE,
+  PF_SPARSE,
+  PF_IPA,
+  PF_SPARK,
+  PF_MISC,
+  PF_COUNT
+};
+extern const char* kProfNames[PF_COUNT];
+
+struct ProfRec {
+  hipEvent_t e0, e1;
+  int fam;
+};
+
+struct sp_ctx {
+  int dev;
+  hipStream_t stream;
+  // scratch
+  void* scratch;
+  size_t scratch_cap;
+  void* scratch2;
+  size_t scratch2_cap;
+  uint8_t* pinned;  // host pinned staging
+  size_t pinned_cap;
+  void* dstage;  // device staging for small host inputs
+  size_t dstage_cap;
+  // profiling
+  int prof_on;
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> free_events;
+  double prof_ms[PF_COUNT];
+  uint64_t prof_n[PF_COUNT];
+  double prof_bytes[PF_COUNT];
+};
+struct sp_gens {
+  sp_ctx* ctx;
+  size_t n;
+  Niels* table;  // [n][32][128]
+};
+struct sp_table {
+  sp_ctx* ctx;
+  Fq* d;
+  size_t cap, len;
+  int owner;  // 0 for views (sp_table_view)
+};
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) {                                                                         \
+      fprintf(stderr, "spartan_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP;                                       \
+    }                                                                                               \
+  } while (0)
+#define SPCHK(x)              \
+  do {                        \
+    int32_t r_ = (x);         \
+    if (r_ != SP_OK) return r_; \
+  } while (0)
+
+
+struct ProfScope {
+  sp_ctx* c;
+  int fam;
+  hipEvent_t e0, e1;
+  bool on;
+  ProfScope(sp_ctx* c_, int fam_, double bytes) : c(c_), fam(fam_), on(c_->prof_on != 0) {
+    if (!on) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->free_events.empty()) {
+        e = c->free_events.back();
+        c->free_events.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    e0 = get();
+    e1 = get();
+    c->prof_bytes[fam] += bytes;
+    (void)hipEventRecord(e0, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->pending.push_back(ProfRec{e0, e1, fam});
+  }
+};
+
+
+int32_t ensure(void** p, size_t* cap, size_t need);
+int32_t ensure_pinned(sp_ctx* c, size_t need);
+void prof_drain(sp_ctx* c);
+int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes);   // host -> c->dstage (+off), async
+int32_t ensure_dstage(sp_ctx* c, size_t need);
+int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes);  // device -> host, synchronous
+int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out);
+// fixed-base MSM core: Z on device (row stride in elements), optional idx / blinds (device); out on host, synchronous
+extern "C" int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
+                              const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host);
+
+static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {
+  size_t b = (work + 255) / 256;
+  if (b < 1) b = 1;
+  return b > maxblocks ? maxblocks : b;
+}
+static inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+static inline size_t ilog2(size_t x) {
+  size_t l = 0;
+  while (((size_t)1 << l) < x) l++;
+  return l;
+}
+
+__device__ __forceinline__ Fq ld_fq(const Fq* p) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);
+  ulonglong2 a = q[0], b = q[1];
+  return Fq{{a.x, a.y, b.x, b.y}};
+}
+__device__ __forceinline__ void st_fq(Fq* p, const Fq& v) {
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(p);
+  q[0] = make_ulonglong2(v.l[0], v.l[1]);
+  q[1] = make_ulonglong2(v.l[2], v.l[3]);
+}
+
+// block-wide sum of K Fq values per thread; result valid in thread 0. blockDim.x == 256.
+template <int K>
+__device__ __forceinline__ void block_sum_fq(Fq (&v)[K], Fq* smem /*256*/) {
+  int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    __syncthreads();
+    smem[t] = v[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) smem[t] = fq_add(smem[t], smem[t + s]);
+      __syncthreads();
+    }
+    v[k] = smem[0];
+  }
+}
+
+
+// partials[nblk][K] -> out[K] ; single block (defined in fq_ops.hip)
+__global__ void k_reduce_partials(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out);

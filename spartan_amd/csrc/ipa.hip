@@ -1,0 +1,159 @@
+// spartan_amd: Bulletproofs-style inner-product reduction (BulletReductionProof::prove, src/nizk/bullet.rs:32-132)
+// with device-resident a, b and generator-coefficient vector s. See include/spartan_hip.h for the algebra:
+// the folded generator vector is never built; every L/R is a fixed-base MSM over the uploaded generators.
+#include "internal.hpp"
+
+struct sp_ipa {
+  sp_ctx* ctx;
+  const sp_gens* g;
+  size_t n0, n_cur, g_off, q_idx, h_idx;
+  Fq q_scale;
+  Fq *a, *b, *s, *s2, *rows;  // device: a[n0], b[n0], s[n0], s2[n0], rows[2][n0+2]
+  uint32_t* idx;              // device: n0+2 generator indices
+};
+
+// single block. rows[0] = scalars of L, rows[1] = scalars of R over (G[0..n0), Qbase, H).
+__global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
+                                                     size_t n0, Fq q_scale, Fq blind_L, Fq blind_R, Fq* __restrict__ rows) {
+  __shared__ Fq sm[256];
+  size_t h = n_cur / 2;
+  Fq c[2] = {fq_zero(), fq_zero()};
+  for (size_t i = threadIdx.x; i < h; i += 256) {
+    c[0] = fq_add(c[0], fq_mul(ld_fq(a + i), ld_fq(b + h + i)));  // c_L = <a_L, b_R>  (bullet.rs:80)
+    c[1] = fq_add(c[1], fq_mul(ld_fq(a + h + i), ld_fq(b + i)));  // c_R = <a_R, b_L>  (bullet.rs:81)
+  }
+  block_sum_fq<2>(c, sm);
+  size_t stride = n0 + 2;
+  for (size_t j = threadIdx.x; j < n0; j += 256) {
+    size_t p = j / n_cur, i = j % n_cur;
+    Fq sp_ = ld_fq(s + p);
+    Fq l = fq_zero(), r = fq_zero();
+    if (i >= h) l = fq_mul(ld_fq(a + (i - h)), sp_);  // a_L[i-h] * G_R[i-h]
+    else r = fq_mul(ld_fq(a + h + i), sp_);           // a_R[i] * G_L[i]
+    st_fq(rows + j, l);
+    st_fq(rows + stride + j, r);
+  }
+  if (threadIdx.x == 0) {
+    st_fq(rows + n0, fq_mul(c[0], q_scale));
+    st_fq(rows + n0 + 1, blind_L);
+    st_fq(rows + stride + n0, fq_mul(c[1], q_scale));
+    st_fq(rows + stride + n0 + 1, blind_R);
+  }
+}
+// bullet.rs:105-109 (a, b) and the coefficient update replacing the G fold
+__global__ void __launch_bounds__(256) k_ipa_fold(Fq* __restrict__ a, Fq* __restrict__ b, const Fq* __restrict__ s, Fq* __restrict__ s_new,
+                                                  size_t n_cur, size_t n0, Fq u, Fq u_inv) {
+  size_t h = n_cur / 2;
+  for (size_t i = threadIdx.x; i < h; i += 256) {
+    Fq al = ld_fq(a + i), ar = ld_fq(a + h + i), bl = ld_fq(b + i), br = ld_fq(b + h + i);
+    st_fq(a + i, fq_add(fq_mul(al, u), fq_mul(u_inv, ar)));
+    st_fq(b + i, fq_add(fq_mul(bl, u_inv), fq_mul(u, br)));
+  }
+  size_t np = n0 / n_cur;
+  for (size_t p = threadIdx.x; p < np; p += 256) {
+    Fq sp_ = ld_fq(s + p);
+    st_fq(s_new + 2 * p, fq_mul(sp_, u_inv));
+    st_fq(s_new + 2 * p + 1, fq_mul(sp_, u));
+  }
+}
+__global__ void __launch_bounds__(256) k_ipa_ghat_row(const Fq* __restrict__ s, size_t n0, Fq d, Fq r, Fq* __restrict__ row) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0; j += (size_t)gridDim.x * blockDim.x) st_fq(row + j, fq_mul(ld_fq(s + j), d));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st_fq(row + n0, fq_zero());
+    st_fq(row + n0 + 1, r);
+  }
+}
+
+static Fq limbs(const uint64_t* p) {
+  Fq x;
+  memcpy(x.l, p, 32);
+  return x;
+}
+
+extern "C" {
+
+void sp_ipa_free(sp_ipa* ipa) {
+  if (!ipa) return;
+  (void)hipSetDevice(ipa->ctx->dev);
+  (void)hipStreamSynchronize(ipa->ctx->stream);
+  if (ipa->a) (void)hipFree(ipa->a);  // one allocation backs a, b, s, s2, rows, idx
+  delete ipa;
+}
+int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
+                     const uint64_t* a, const uint64_t* b, sp_ipa** out) {
+  if (!c || !g || !q_scale || !a || !b || !out || !is_pow2(n) || g_off + n > g->n || q_idx >= g->n || h_idx >= g->n) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  sp_ipa* ipa = new (std::nothrow) sp_ipa();
+  if (!ipa) return SP_ENOMEM;
+  ipa->ctx = c; ipa->g = g; ipa->n0 = ipa->n_cur = n; ipa->g_off = g_off; ipa->q_idx = q_idx; ipa->h_idx = h_idx;
+  ipa->q_scale = limbs(q_scale);
+  size_t fq_count = 4 * n + 2 * (n + 2);
+  uint8_t* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, 32 * fq_count + 4 * (n + 2));
+  if (e != hipSuccess) { delete ipa; return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP; }
+  ipa->a = (Fq*)base; ipa->b = ipa->a + n; ipa->s = ipa->b + n; ipa->s2 = ipa->s + n; ipa->rows = ipa->s2 + n;
+  ipa->idx = (uint32_t*)(ipa->rows + 2 * (n + 2));
+  std::vector<uint32_t> idx(n + 2);
+  for (size_t j = 0; j < n; j++) idx[j] = (uint32_t)(g_off + j);
+  idx[n] = (uint32_t)q_idx;
+  idx[n + 1] = (uint32_t)h_idx;
+  Fq one = fq_one();
+  if (hipMemcpy(ipa->a, a, 32 * n, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ipa->b, b, 32 * n, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ipa->s, &one, 32, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice) != hipSuccess) {
+    sp_ipa_free(ipa);
+    return SP_EHIP;
+  }
+  *out = ipa;
+  return SP_OK;
+}
+int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
+  if (!ipa || !blind_L || !blind_R || !L_out || !R_out || ipa->n_cur < 2) return SP_EINVAL;
+  sp_ctx* c = ipa->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  {
+    ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);
+    hipLaunchKernelGGL(k_ipa_prepare, dim3(1), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
+                       ipa->n0, ipa->q_scale, limbs(blind_L), limbs(blind_R), ipa->rows);
+  }
+  uint8_t lr[64];
+  SPCHK(msm_launch(c, ipa->g, ipa->rows, ipa->n0 + 2, 2, ipa->n0 + 2, 0, ipa->idx, nullptr, 0, lr));
+  memcpy(L_out, lr, 32);
+  memcpy(R_out, lr + 32, 32);
+  return SP_OK;
+}
+int32_t sp_ipa_round_fold(sp_ipa* ipa, const uint64_t u[4], const uint64_t u_inv[4]) {
+  if (!ipa || !u || !u_inv || ipa->n_cur < 2) return SP_EINVAL;
+  sp_ctx* c = ipa->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  {
+    ProfScope ps(c, PF_IPA, 32.0 * 3 * (double)ipa->n_cur);
+    hipLaunchKernelGGL(k_ipa_fold, dim3(1), dim3(256), 0, c->stream, ipa->a, ipa->b, (const Fq*)ipa->s, ipa->s2, ipa->n_cur, ipa->n0, limbs(u),
+                       limbs(u_inv));
+  }
+  Fq* t = ipa->s; ipa->s = ipa->s2; ipa->s2 = t;
+  ipa->n_cur /= 2;
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_ipa_finish(sp_ipa* ipa, uint64_t a_hat[4], uint64_t b_hat[4], uint8_t* g_hat) {
+  if (!ipa || !a_hat || !b_hat || ipa->n_cur != 1) return SP_EINVAL;
+  sp_ctx* c = ipa->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(fetch_out(c, ipa->a, a_hat, 32));
+  SPCHK(fetch_out(c, ipa->b, b_hat, 32));
+  if (g_hat) SPCHK(msm_launch(c, ipa->g, ipa->s, ipa->n0, 1, ipa->n0, ipa->g_off, nullptr, nullptr, 0, g_hat));
+  return SP_OK;
+}
+int32_t sp_ipa_commit_ghat(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint8_t out[32]) {
+  if (!ipa || !d || !r || !out || ipa->n_cur != 1) return SP_EINVAL;
+  sp_ctx* c = ipa->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  {
+    ProfScope ps(c, PF_IPA, 64.0 * (double)ipa->n0);
+    hipLaunchKernelGGL(k_ipa_ghat_row, dim3((unsigned)grid_for(ipa->n0, 64)), dim3(256), 0, c->stream, (const Fq*)ipa->s, ipa->n0, limbs(d),
+                       limbs(r), ipa->rows);
+  }
+  return msm_launch(c, ipa->g, ipa->rows, ipa->n0 + 2, 1, ipa->n0 + 2, 0, ipa->idx, nullptr, 0, out);
+}
+
+}  // extern "C"

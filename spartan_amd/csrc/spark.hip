@@ -1,0 +1,290 @@
+// spartan_amd: device building blocks of the SPARK sparse-polynomial evaluation proof
+// (src/sparse_mlpoly.rs, src/product_tree.rs): gathers, hash layers, product trees, batched cubic sum-check.
+// All of it is F_q streaming work (no group operations), HBM/ALU-bound.
+#include "internal.hpp"
+
+struct sp_index {
+  sp_ctx* ctx;
+  uint32_t* d;
+  size_t n;
+};
+
+__global__ void __launch_bounds__(256) k_from_index(const uint32_t* __restrict__ ix, size_t n, Fq* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(dst + i, fq_from_u64(ix[i]));
+}
+__global__ void __launch_bounds__(256) k_gather(const Fq* __restrict__ mem, const uint32_t* __restrict__ addr, size_t n, Fq* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(dst + i, ld_fq(mem + addr[i]));
+}
+__global__ void __launch_bounds__(256) k_hash_layer(const Fq* __restrict__ addr, const Fq* __restrict__ val, const Fq* __restrict__ ts, int ts_inc,
+                                                    size_t n, Fq r_hash, Fq r_hash_sqr, Fq r_multiset, Fq* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fq a = addr ? ld_fq(addr + i) : fq_from_u64((uint64_t)i);
+    Fq t = ts ? ld_fq(ts + i) : fq_zero();
+    if (ts_inc) t = fq_add(t, fq_one());
+    Fq h = fq_add(fq_add(fq_mul(t, r_hash_sqr), fq_mul(ld_fq(val + i), r_hash)), a);
+    st_fq(dst + i, fq_sub(h, r_multiset));
+  }
+}
+__global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, size_t half, Fq* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+    st_fq(out + i, fq_mul(ld_fq(in + i), ld_fq(in + half + i)));
+}
+
+struct Triple {
+  Fq *a, *b, *c;
+};
+__device__ __forceinline__ void cubic_point(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c0, const Fq& c1, Fq (&e)[3]) {
+  Fq a2 = fq_sub(fq_dbl(a1), a0), b2 = fq_sub(fq_dbl(b1), b0), c2 = fq_sub(fq_dbl(c1), c0);
+  Fq a3 = fq_sub(fq_add(a2, a1), a0), b3 = fq_sub(fq_add(b2, b1), b0), c3 = fq_sub(fq_add(c2, c1), c0);
+  e[0] = fq_add(e[0], fq_mul(fq_mul(a0, b0), c0));
+  e[1] = fq_add(e[1], fq_mul(fq_mul(a2, b2), c2));
+  e[2] = fq_add(e[2], fq_mul(fq_mul(a3, b3), c3));
+}
+// grid (nblk, ninst): partials[(inst*nblk + blk)*3 + {0,1,2}]
+__global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __restrict__ T, size_t half, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  Triple t = T[blockIdx.y];
+  Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+    cubic_point(ld_fq(t.a + i), ld_fq(t.a + half + i), ld_fq(t.b + i), ld_fq(t.b + half + i), ld_fq(t.c + i), ld_fq(t.c + half + i), e);
+  block_sum_fq<3>(e, sm);
+  if (threadIdx.x == 0) {
+    Fq* p = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+    st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]);
+  }
+}
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  Triple t = T[blockIdx.y];
+  Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quarter; i += (size_t)gridDim.x * blockDim.x) {
+    Fq lo[3], hi[3];
+    Fq* ptr[3] = {t.a, t.b, t.c};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      Fq x0 = ld_fq(ptr[k] + i), x1 = ld_fq(ptr[k] + quarter + i), x2 = ld_fq(ptr[k] + 2 * quarter + i), x3 = ld_fq(ptr[k] + 3 * quarter + i);
+      lo[k] = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
+      hi[k] = fq_add(x1, fq_mul(r, fq_sub(x3, x1)));
+      if (k < 2) {  // C is shared between instances: bound separately afterwards
+        st_fq(ptr[k] + i, lo[k]);
+        st_fq(ptr[k] + quarter + i, hi[k]);
+      }
+    }
+    cubic_point(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], e);
+  }
+  block_sum_fq<3>(e, sm);
+  if (threadIdx.x == 0) {
+    Fq* p = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+    st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]);
+  }
+}
+// partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
+__global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
+  __shared__ Fq sm[256];
+  const Fq* p = partials + (size_t)blockIdx.x * nblk * K;
+  for (int k = 0; k < K; k++) {
+    Fq acc[1] = {fq_zero()};
+    for (size_t b = threadIdx.x; b < nblk; b += 256) acc[0] = fq_add(acc[0], ld_fq(p + b * K + k));
+    block_sum_fq<1>(acc, sm);
+    if (threadIdx.x == 0) st_fq(out + (size_t)blockIdx.x * K + k, acc[0]);
+  }
+}
+// grid (nblk, nt): partials[t*nblk + blk] = partial <chi, T_t>
+__global__ void __launch_bounds__(256) k_dot_many(const Fq* __restrict__ chi, Fq* const* __restrict__ tabs, size_t n, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  const Fq* t = tabs[blockIdx.y];
+  Fq acc[1] = {fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fq_add(acc[0], fq_mul(ld_fq(chi + i), ld_fq(t + i)));
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc[0]);
+}
+__global__ void __launch_bounds__(256) k_dot3(const Fq* __restrict__ l, const Fq* __restrict__ r, const Fq* __restrict__ w, size_t n,
+                                              Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  Fq acc[1] = {fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fq_add(acc[0], fq_mul(fq_mul(ld_fq(l + i), ld_fq(r + i)), ld_fq(w + i)));
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
+}
+
+static Fq limbs(const uint64_t* p) {
+  Fq x;
+  memcpy(x.l, p, 32);
+  return x;
+}
+
+extern "C" {
+
+int32_t sp_index_upload(sp_ctx* c, const uint64_t* idx, size_t n, sp_index** out) {
+  if (!c || !idx || !out || n == 0) return SP_EINVAL;
+  std::vector<uint32_t> v(n);
+  for (size_t i = 0; i < n; i++) {
+    if (idx[i] > 0xffffffffULL) return SP_EINVAL;
+    v[i] = (uint32_t)idx[i];
+  }
+  HIPCHK(hipSetDevice(c->dev));
+  sp_index* ix = new (std::nothrow) sp_index();
+  if (!ix) return SP_ENOMEM;
+  ix->ctx = c; ix->n = n; ix->d = nullptr;
+  hipError_t e = hipMalloc((void**)&ix->d, 4 * n);
+  if (e == hipSuccess) e = hipMemcpy(ix->d, v.data(), 4 * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (ix->d) (void)hipFree(ix->d); delete ix; return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP; }
+  *out = ix;
+  return SP_OK;
+}
+void sp_index_free(sp_index* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->ctx->dev);
+  (void)hipStreamSynchronize(ix->ctx->stream);
+  (void)hipFree(ix->d);
+  delete ix;
+}
+int32_t sp_table_from_index(sp_ctx* c, const sp_index* ix, sp_table* dst, size_t dst_off) {
+  if (!c || !ix || !dst || dst_off + ix->n > dst->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  ProfScope ps(c, PF_SPARK, 36.0 * (double)ix->n);
+  hipLaunchKernelGGL(k_from_index, dim3((unsigned)grid_for(ix->n)), dim3(256), 0, c->stream, (const uint32_t*)ix->d, ix->n, dst->d + dst_off);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_table_view(sp_ctx* c, const sp_table* parent, size_t off, size_t len, sp_table** out) {
+  if (!c || !parent || !out || len == 0 || off + len > parent->cap) return SP_EINVAL;
+  sp_table* t = new (std::nothrow) sp_table();
+  if (!t) return SP_ENOMEM;
+  t->ctx = c; t->d = parent->d + off; t->cap = t->len = len; t->owner = 0;
+  *out = t;
+  return SP_OK;
+}
+int32_t sp_gather(sp_ctx* c, const sp_table* mem, const sp_index* addr, sp_table* dst, size_t dst_off) {
+  if (!c || !mem || !addr || !dst || dst_off + addr->n > dst->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  ProfScope ps(c, PF_SPARK, 68.0 * (double)addr->n);
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)grid_for(addr->n)), dim3(256), 0, c->stream, (const Fq*)mem->d, (const uint32_t*)addr->d, addr->n,
+                     dst->d + dst_off);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_hash_layer(sp_ctx* c, const sp_table* addr, const sp_table* val, const sp_table* ts, int ts_inc, size_t n, const uint64_t r_hash[4],
+                      const uint64_t r_multiset[4], sp_table* dst, size_t dst_off) {
+  if (!c || !val || !dst || !r_hash || !r_multiset || n == 0 || val->cap < n || (addr && addr->cap < n) || (ts && ts->cap < n) ||
+      dst_off + n > dst->cap)
+    return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  Fq rh = limbs(r_hash), rm = limbs(r_multiset);
+  Fq rh2 = fq_mul(rh, rh);
+  ProfScope ps(c, PF_SPARK, 32.0 * (double)n * (2 + (addr ? 1 : 0) + (ts ? 1 : 0)));
+  hipLaunchKernelGGL(k_hash_layer, dim3((unsigned)grid_for(n)), dim3(256), 0, c->stream, addr ? (const Fq*)addr->d : (const Fq*)nullptr,
+                     (const Fq*)val->d, ts ? (const Fq*)ts->d : (const Fq*)nullptr, ts_inc, n, rh, rh2, rm, dst->d + dst_off);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_product_tree(sp_ctx* c, sp_table* store, size_t n) {
+  if (!c || !store || !is_pow2(n) || n < 2 || store->cap < 2 * n) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t off = 0, len = n;
+  while (len > 2) {
+    size_t half = len / 2, noff = off + len;
+    ProfScope ps(c, PF_SPARK, 48.0 * (double)len);
+    hipLaunchKernelGGL(k_prod_layer, dim3((unsigned)grid_for(half)), dim3(256), 0, c->stream, (const Fq*)(store->d + off), half, store->d + noff);
+    off = noff;
+    len = half;
+  }
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+
+static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t* len_out) {
+  if (!c || !A || !B || !C || ninst == 0 || ninst > 64) return SP_EINVAL;
+  size_t len = A[0] ? A[0]->len : 0;
+  std::vector<Triple> T(ninst);
+  for (size_t k = 0; k < ninst; k++) {
+    if (!A[k] || !B[k] || !C[k] || A[k]->len != len || B[k]->len != len || C[k]->len != len) return SP_EINVAL;
+    T[k] = Triple{A[k]->d, B[k]->d, C[k]->d};
+  }
+  if (len < 2 || !is_pow2(len)) return SP_EINVAL;
+  SPCHK(ensure_dstage(c, sizeof(Triple) * ninst));
+  SPCHK(stage_in(c, 0, T.data(), sizeof(Triple) * ninst));
+  *len_out = len;
+  return SP_OK;
+}
+static int32_t batched_finish(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out) {
+  Fq* dres = partials + ninst * nblk * 3;
+  {
+    ProfScope ps(c, PF_REDUCE, 96.0 * (double)(nblk * ninst));
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, dres);
+  }
+  SPCHK(fetch_out(c, dres, out, 96 * ninst));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out) {
+  if (!out) return SP_EINVAL;
+  size_t len;
+  HIPCHK(hipSetDevice(c ? c->dev : 0));
+  SPCHK(batched_setup(c, A, B, C, ninst, &len));
+  size_t half = len / 2, nblk = grid_for(half, 256);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst);
+    hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->dstage, half, partials);
+  }
+  return batched_finish(c, partials, nblk, ninst, out);
+}
+int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t r[4],
+                                      uint64_t* out) {
+  if (!out || !r) return SP_EINVAL;
+  size_t len;
+  HIPCHK(hipSetDevice(c ? c->dev : 0));
+  SPCHK(batched_setup(c, A, B, C, ninst, &len));
+  if (len < 4) return SP_EINVAL;
+  size_t quarter = len / 4, nblk = grid_for(quarter, 256);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst);
+    hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->dstage, quarter,
+                       limbs(r), partials);
+  }
+  // A_k and B_k are now bound (distinct tables assumed for A and B)
+  for (size_t k = 0; k < ninst; k++) { A[k]->len = len / 2; B[k]->len = len / 2; }
+  return batched_finish(c, partials, nblk, ninst, out);
+}
+int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out) {
+  if (!c || !chi || !tabs || !out || nt == 0 || nt > 64) return SP_EINVAL;
+  size_t n = chi->len;
+  std::vector<Fq*> ptrs(nt);
+  for (size_t k = 0; k < nt; k++) {
+    if (!tabs[k] || tabs[k]->cap < n) return SP_EINVAL;
+    ptrs[k] = tabs[k]->d;
+  }
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ensure_dstage(c, 8 * nt));
+  SPCHK(stage_in(c, 0, ptrs.data(), 8 * nt));
+  size_t nblk = grid_for(n, 256);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1) * nt));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_DOT, 32.0 * (double)n * (double)(nt + 1));
+    hipLaunchKernelGGL(k_dot_many, dim3((unsigned)nblk, (unsigned)nt), dim3(256), 0, c->stream, (const Fq*)chi->d, (Fq* const*)c->dstage, n, partials);
+  }
+  Fq* dres = partials + nt * nblk;
+  {
+    ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * nt));
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, dres);
+  }
+  SPCHK(fetch_out(c, dres, out, 32 * nt));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_dot3(sp_ctx* c, const sp_table* l, const sp_table* r, const sp_table* w, size_t off, size_t n, uint64_t out[4]) {
+  if (!c || !l || !r || !w || !out || n == 0 || off + n > l->cap || off + n > r->cap || off + n > w->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t nblk = grid_for(n, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
+  Fq* partials = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_DOT, 96.0 * (double)n);
+    hipLaunchKernelGGL(k_dot3, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)(l->d + off), (const Fq*)(r->d + off), (const Fq*)(w->d + off), n,
+                       partials);
+  }
+  return reduce_and_fetch(c, partials, nblk, 1, out);
+}
+
+}  // extern "C"

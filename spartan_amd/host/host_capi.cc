@@ -1,0 +1,167 @@
+// spartan_amd host driver: C entry points over libspartan.hpp for ctypes (tests/, bench.py). Exceptions are
+// turned into NULL / error strings here; nothing throws across the boundary.
+#include <cstring>
+#include <string>
+
+#include "libspartan.hpp"
+
+using namespace spz;
+
+namespace {
+thread_local std::string g_err;
+struct EncH { ComputationCommitment comm; ComputationDecommitment decomm; };
+struct ProofH { std::vector<uint8_t> bytes; };
+FqVec limbs_vec(const uint64_t* p, size_t n) { FqVec v(n); if (n) memcpy(v[0].l, p, 32 * n); return v; }
+void fill_times(const ProveTimes& t, double* o) {
+  if (!o) return;
+  o[0] = t.polycommit; o[1] = t.sc_phase_one; o[2] = t.sc_phase_two; o[3] = t.polyeval; o[4] = t.r1cs_sat; o[5] = t.eval_sparse_polys;
+  o[6] = t.commit_nondet_witness; o[7] = t.build_layered_network; o[8] = t.evalproof_layered_network; o[9] = t.total;
+}
+template <typename F>
+auto guard(F f) -> decltype(f()) {
+  try {
+    g_err.clear();
+    return f();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+}  // namespace
+
+extern "C" {
+const char* spz_last_error() { return g_err.c_str(); }
+void* spz_ctx_new(int device) { return guard([&]() -> void* { return new Ctx(device); }); }
+void spz_ctx_free(void* c) { delete (Ctx*)c; }
+sp_ctx* spz_ctx_raw(void* c) { return ((Ctx*)c)->h; }
+
+// Instance::new (lib.rs:121-128): entries of A, B, C back to back as (row, col, [u8;32] canonical little-endian value).
+// Errors mirror R1CSError: "InvalidIndex", "InvalidScalar" (spz_last_error()).
+void* spz_instance_new(void* ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const size_t nnz[3], const uint64_t* rows,
+                       const uint64_t* cols, const uint8_t* vals) {
+  return guard([&]() -> void* {
+    std::vector<SparseEntry> m[3];
+    size_t off = 0;
+    for (int k = 0; k < 3; k++)
+      for (size_t i = 0; i < nnz[k]; i++, off++) {
+        SparseEntry e;
+        e.row = rows[off]; e.col = cols[off];
+        sp::Fq raw;
+        memcpy(raw.l, vals + 32 * off, 32);
+        // Scalar::from_bytes (ristretto255.rs:390-416): reject encodings >= q
+        static const uint64_t Q[4] = {SP_Q0, SP_Q1, SP_Q2, SP_Q3};
+        bool lt = false;
+        for (int w = 3; w >= 0; w--) {
+          if (raw.l[w] != Q[w]) { lt = raw.l[w] < Q[w]; break; }
+        }
+        if (!lt) throw Error("InvalidScalar");
+        e.val = sp::fq_to_mont(raw);
+        m[k].push_back(e);
+      }
+    return new Instance(*(Ctx*)ctx, num_cons, num_vars, num_inputs, m[0], m[1], m[2]);
+  });
+}
+// Instance::produce_synthetic_r1cs with a seed; vars (num_vars) and inputs (num_inputs) are written out
+void* spz_instance_synthetic(void* ctx, size_t num_cons, size_t num_vars, size_t num_inputs, uint64_t seed, uint64_t* vars_out, uint64_t* inputs_out) {
+  return guard([&]() -> void* {
+    FqVec v, in;
+    std::unique_ptr<Instance> p = Instance::produce_synthetic_r1cs(*(Ctx*)ctx, num_cons, num_vars, num_inputs, seed, &v, &in);
+    if (vars_out) memcpy(vars_out, v[0].l, 32 * v.size());
+    if (inputs_out && !in.empty()) memcpy(inputs_out, in[0].l, 32 * in.size());
+    return p.release();
+  });
+}
+void spz_seed_scalar(const char* domain, uint64_t seed, uint64_t out[4]) { Fq s = seed_scalar(domain, seed); memcpy(out, s.l, 32); }
+void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->digest.assign(d, d + n); }
+void spz_instance_free(void* i) { delete (Instance*)i; }
+void* spz_snark_gens_new(void* ctx, size_t nc, size_t nv, size_t ni, size_t nnz) {
+  return guard([&]() -> void* { return new SNARKGens(*(Ctx*)ctx, nc, nv, ni, nnz); });
+}
+void spz_snark_gens_free(void* g) { delete (SNARKGens*)g; }
+void* spz_nizk_gens_new(void* ctx, size_t nc, size_t nv, size_t ni) {
+  return guard([&]() -> void* { return new NIZKGens(*(Ctx*)ctx, nc, nv, ni); });
+}
+void spz_nizk_gens_free(void* g) { delete (NIZKGens*)g; }
+// compressed points of the two generator streams (for parity checks against the oracle's MultiCommitGens)
+size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
+  const std::vector<uint8_t>& v = which == 0 ? ((SNARKGens*)g)->stream_sat.compressed : ((SNARKGens*)g)->stream_eval.compressed;
+  if (out && cap >= v.size()) memcpy(out, v.data(), v.size());
+  return v.size();
+}
+void* spz_snark_encode(void* ctx, void* inst, void* gens) {
+  return guard([&]() -> void* {
+    EncH* e = new EncH;
+    try {
+      SNARK::encode(*(Ctx*)ctx, *(Instance*)inst, *(SNARKGens*)gens, &e->comm, &e->decomm);
+    } catch (...) {
+      delete e;
+      throw;
+    }
+    return e;
+  });
+}
+void spz_encode_free(void* e) { delete (EncH*)e; }
+size_t spz_encode_comm(void* ev, int which, uint8_t* out, size_t cap) {
+  EncH* e = (EncH*)ev;
+  const PolyCommitment& c = which == 0 ? e->comm.comm.comm_comb_ops : e->comm.comm.comm_comb_mem;
+  if (out && cap >= 32 * c.C.size())
+    for (size_t i = 0; i < c.C.size(); i++) memcpy(out + 32 * i, c.C[i].data(), 32);
+  return c.C.size();
+}
+void* spz_snark_prove(void* ctx, void* inst, void* gens, void* enc, const uint64_t* vars, size_t nvars, const uint64_t* inputs, size_t ninputs,
+                      const char* transcript_label, const uint64_t tape_seed[4], double* times10) {
+  return guard([&]() -> void* {
+    Transcript t(transcript_label);
+    Fq seed;
+    memcpy(seed.l, tape_seed, 32);
+    ProveTimes tm;
+    EncH* e = (EncH*)enc;
+    SNARK p = SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, limbs_vec(vars, nvars), limbs_vec(inputs, ninputs), *(SNARKGens*)gens, t,
+                           seed, &tm);
+    fill_times(tm, times10);
+    ProofH* h = new ProofH;
+    h->bytes = p.serialize();
+    return h;
+  });
+}
+void* spz_nizk_prove(void* ctx, void* inst, void* gens, const uint64_t* vars, size_t nvars, const uint64_t* inputs, size_t ninputs,
+                     const char* transcript_label, const uint64_t tape_seed[4], double* times10) {
+  return guard([&]() -> void* {
+    Transcript t(transcript_label);
+    Fq seed;
+    memcpy(seed.l, tape_seed, 32);
+    ProveTimes tm;
+    NIZK p = NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, limbs_vec(vars, nvars), limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t, seed, &tm);
+    fill_times(tm, times10);
+    ProofH* h = new ProofH;
+    h->bytes = p.serialize();
+    return h;
+  });
+}
+size_t spz_proof_bytes(void* p, uint8_t* out, size_t cap) {
+  ProofH* h = (ProofH*)p;
+  if (out && cap >= h->bytes.size()) memcpy(out, h->bytes.data(), h->bytes.size());
+  return h->bytes.size();
+}
+void spz_proof_free(void* p) { delete (ProofH*)p; }
+
+// host-side Fiat–Shamir pieces exposed for CPU tests (no GPU needed)
+void spz_shake256(const uint8_t* in, size_t n, uint8_t* out, size_t outlen) { Shake256 s; s.absorb(in, n); s.squeeze(out, outlen); }
+size_t spz_merlin_script(const char* tlabel, size_t nops, const int* kinds, const char* const* labels, const uint8_t* const* datas, const size_t* lens,
+                         uint8_t* out) {
+  Transcript t(tlabel);
+  size_t o = 0;
+  for (size_t i = 0; i < nops; i++) {
+    if (kinds[i] == 0) t.append_message(labels[i], datas[i], lens[i]);
+    else if (kinds[i] == 1) { t.challenge_bytes(labels[i], out + o, lens[i]); o += lens[i]; }
+    else { uint64_t x; memcpy(&x, datas[i], 8); t.append_u64(labels[i], x); }
+  }
+  return o;
+}
+void spz_tape_draws(const uint64_t seed[4], const char* label, size_t n, uint64_t* out) {
+  Fq s;
+  memcpy(s.l, seed, 32);
+  RandomTape tape("proof", s);
+  for (size_t i = 0; i < n; i++) { Fq x = tape.random_scalar(label); memcpy(out + 4 * i, x.l, 32); }
+}
+}

@@ -1,0 +1,221 @@
+// spartan_amd host driver: C++ mirror of libspartan's public API (src/lib.rs) for the prover path, on top of
+// the C ABI in include/spartan_hip.h. It exists because no Rust toolchain is available here; in the drop-in
+// deployment this layer IS libspartan (Rust) with the `gpu` feature. Names and argument
+// meaning follow the reference: Instance, VarsAssignment/InputsAssignment, SNARKGens, NIZKGens,
+// ComputationCommitment/Decommitment, SNARK::{encode,prove}, NIZK::prove. Verifiers are out of scope
+// (SURVEY.md §2.1); tests verify the emitted bytes with the oracle's restated verifier.
+//
+// All field/group work of the prover runs on the GPU through sp_* calls; the host keeps only what the
+// reference keeps next to its Transcript: Fiat–Shamir, O(log n)-sized scalar bookkeeping, and serialization.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/spartan_hip.h"
+#include "transcript.hpp"
+
+namespace spz {
+
+typedef std::array<uint8_t, 32> CP;  // CompressedGroup (src/group.rs:7)
+typedef std::vector<Fq> FqVec;
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// ---- device handles (RAII) ----
+struct Ctx {
+  sp_ctx* h = nullptr;
+  explicit Ctx(int device);
+  ~Ctx();
+  Ctx(const Ctx&) = delete;
+};
+struct DevTable {  // DensePolynomial with Z resident in HBM (src/dense_mlpoly.rs:14-18)
+  sp_ctx* c = nullptr;
+  sp_table* h = nullptr;
+  DevTable() {}
+  DevTable(sp_ctx* c_, sp_table* h_) : c(c_), h(h_) {}
+  DevTable(DevTable&& o) noexcept : c(o.c), h(o.h) { o.h = nullptr; }
+  DevTable& operator=(DevTable&& o) noexcept;
+  DevTable(const DevTable&) = delete;
+  ~DevTable();
+  size_t len() const { return sp_table_len(h); }
+};
+
+// MultiCommitGens (src/commitments.rs:8-13) as a view into a device generator stream
+struct MultiCommitGens {
+  sp_gens* g = nullptr;
+  std::vector<uint32_t> G;  // stream indices of G[0..n)
+  uint32_t h = 0;           // stream index of h
+  size_t n() const { return G.size(); }
+};
+struct DotProductProofGens {  // src/nizk/mod.rs:408-419
+  size_t n;
+  MultiCommitGens gens_n, gens_1;
+};
+struct PolyCommitmentGens {  // src/dense_mlpoly.rs:25-36
+  DotProductProofGens gens;
+};
+struct GensStream {  // one SHAKE256 stream of points (label), uploaded once with its window tables
+  sp_ctx* c = nullptr;
+  sp_gens* g = nullptr;
+  std::vector<uint8_t> compressed;
+  GensStream() {}
+  GensStream(sp_ctx* c, const char* label, size_t npoints);
+  GensStream(GensStream&& o) noexcept : c(o.c), g(o.g), compressed(std::move(o.compressed)) { o.g = nullptr; }
+  GensStream& operator=(GensStream&& o) noexcept;
+  ~GensStream();
+  MultiCommitGens multi_commit_gens(size_t n) const;        // MultiCommitGens::new(n, label)
+  DotProductProofGens dot_product_gens(size_t n) const;     // DotProductProofGens::new(n, label)
+  PolyCommitmentGens poly_commitment_gens(size_t num_vars) const;
+};
+struct R1CSSumcheckGens { MultiCommitGens gens_1, gens_3, gens_4; };  // src/r1csproof.rs:39-60
+struct R1CSGens {                                                      // src/r1csproof.rs:62-74
+  R1CSSumcheckGens gens_sc;
+  PolyCommitmentGens gens_pc;
+};
+struct SparseMatPolyCommitmentGens { PolyCommitmentGens gens_ops, gens_mem, gens_derefs; };  // src/sparse_mlpoly.rs:302-337
+
+struct NIZKGens {  // src/lib.rs:468-486
+  GensStream stream_sat;
+  R1CSGens gens_r1cs_sat;
+  NIZKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs);
+};
+struct SNARKGens {  // src/lib.rs:276-309
+  GensStream stream_sat, stream_eval;
+  R1CSGens gens_r1cs_sat;
+  SparseMatPolyCommitmentGens gens_r1cs_eval;
+  SNARKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, size_t num_nz_entries);
+};
+
+// ---- instance ----
+struct SparseEntry { uint64_t row, col; Fq val; };
+struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the matrices resident on the device
+  sp_ctx* c = nullptr;
+  size_t num_cons = 0, num_vars = 0, num_inputs = 0;
+  std::vector<SparseEntry> A, B, C;
+  sp_sparse *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  std::vector<uint8_t> digest;  // R1CSShapeDigest bytes (zlib(bincode(shape)) in the reference, r1cs.rs:154-158): opaque input
+  // Instance::new (lib.rs:121-228): padding of num_cons / num_vars and the column shift are applied here.
+  Instance(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const std::vector<SparseEntry>& A,
+           const std::vector<SparseEntry>& B, const std::vector<SparseEntry>& C);
+  ~Instance();
+  Instance(const Instance&) = delete;
+  // Instance::produce_synthetic_r1cs (lib.rs:262-273 -> r1cs.rs:160-238) with the OsRng replaced by a SHAKE256
+  // stream keyed by `seed` ("spartan-synthetic-r1cs" || LE64(seed)); returns the satisfying assignment.
+  static std::unique_ptr<Instance> produce_synthetic_r1cs(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, uint64_t seed,
+                                                          FqVec* vars, FqVec* inputs);
+};
+// from_bytes_wide(SHAKE256(domain || LE64(seed))[0..64]): the documented seed -> scalar map used for RandomTape seeds
+Fq seed_scalar(const char* domain, uint64_t seed);
+
+// ---- proof structs: field order == bincode order (same as the reference's serde derives) ----
+struct PolyCommitment { std::vector<CP> C; };                                   // dense_mlpoly.rs:38-41
+struct KnowledgeProof { CP alpha; Fq z1, z2; };                                 // nizk/mod.rs:15-20
+struct EqualityProof { CP alpha; Fq z; };                                       // :77-81
+struct ProductProof { CP alpha, beta, delta; Fq z[5]; };                        // :146-152
+struct DotProductProof { CP delta, beta; FqVec z; Fq z_delta, z_beta; };        // :292-299
+struct BulletReductionProof { std::vector<CP> L_vec, R_vec; };                  // bullet.rs:15-19
+struct DotProductProofLog { BulletReductionProof bullet; CP delta, beta; Fq z1, z2; };  // nizk/mod.rs:421-428
+struct PolyEvalProof { DotProductProofLog proof; };                             // dense_mlpoly.rs:303-306
+struct ZKSumcheckInstanceProof { std::vector<CP> comm_polys, comm_evals; std::vector<DotProductProof> proofs; };  // sumcheck.rs:64-69
+struct SumcheckInstanceProof { std::vector<FqVec> compressed_polys; };          // sumcheck.rs:17-20
+struct R1CSProof {                                                              // r1csproof.rs:21-37
+  PolyCommitment comm_vars;
+  ZKSumcheckInstanceProof sc_proof_phase1;
+  CP claims_phase2[4];
+  KnowledgeProof pok_claims_phase2;
+  ProductProof proof_prod;
+  EqualityProof proof_eq_sc_phase1;
+  ZKSumcheckInstanceProof sc_proof_phase2;
+  CP comm_vars_at_ry;
+  PolyEvalProof proof_eval_vars_at_ry;
+  EqualityProof proof_eq_sc_phase2;
+};
+struct LayerProofBatched { SumcheckInstanceProof proof; FqVec claims_prod_left, claims_prod_right; };  // product_tree.rs:133-139
+struct ProductCircuitEvalProofBatched { std::vector<LayerProofBatched> proof; FqVec claims_dotp[3]; };  // :162-166
+struct ProductLayerProof {                                                      // sparse_mlpoly.rs:1021-1028
+  Fq row_init; FqVec row_read, row_write; Fq row_audit;
+  Fq col_init; FqVec col_read, col_write; Fq col_audit;
+  FqVec eval_val[2];
+  ProductCircuitEvalProofBatched proof_mem, proof_ops;
+};
+struct HashLayerProof {                                                         // :680-689
+  FqVec row_addr, row_read_ts; Fq row_audit_ts;
+  FqVec col_addr, col_read_ts; Fq col_audit_ts;
+  FqVec eval_val;
+  FqVec eval_derefs[2];
+  PolyEvalProof proof_ops, proof_mem, proof_derefs;
+};
+struct SparseMatPolyEvalProof {                                                 // :1418-1422, :1307-1311
+  PolyCommitment comm_derefs;
+  ProductLayerProof proof_prod_layer;
+  HashLayerProof proof_hash_layer;
+};
+
+// ---- SPARK dense representation on the device (sparse_mlpoly.rs:213-276) ----
+struct DevIndex {  // Vec<usize> resident on the device
+  sp_ctx* c = nullptr;
+  sp_index* h = nullptr;
+  DevIndex() {}
+  DevIndex(sp_ctx* c_, sp_index* h_) : c(c_), h(h_) {}
+  DevIndex(DevIndex&& o) noexcept : c(o.c), h(o.h) { o.h = nullptr; }
+  DevIndex& operator=(DevIndex&& o) noexcept;
+  DevIndex(const DevIndex&) = delete;
+  ~DevIndex();
+};
+struct AddrTimestamps {
+  std::vector<DevIndex> ops_addr_usize;
+  std::vector<DevTable> ops_addr, read_ts;
+  DevTable audit_ts;
+};
+struct MultiSparseMatPolynomialAsDense {
+  size_t batch_size = 0, num_ops = 0, num_mem_cells = 0;
+  std::vector<DevTable> val;
+  AddrTimestamps row, col;
+  DevTable comb_ops, comb_mem;
+};
+struct SparseMatPolyCommitment {  // :339-346
+  size_t batch_size, num_ops, num_mem_cells;
+  PolyCommitment comm_comb_ops, comm_comb_mem;
+};
+struct ComputationCommitment {  // lib.rs:44-48 -> r1cs.rs:50-56
+  size_t num_cons, num_vars, num_inputs;
+  SparseMatPolyCommitment comm;
+};
+struct ComputationDecommitment {  // lib.rs:50-54 -> r1cs.rs:67-70
+  MultiSparseMatPolynomialAsDense dense;
+};
+
+struct ProveTimes {  // span names follow src/timer.rs call sites
+  double polycommit = 0, sc_phase_one = 0, sc_phase_two = 0, polyeval = 0, r1cs_sat = 0, eval_sparse_polys = 0, commit_nondet_witness = 0,
+         build_layered_network = 0, evalproof_layered_network = 0, total = 0;
+};
+
+struct SNARK {  // lib.rs:311-467
+  R1CSProof r1cs_sat_proof;
+  Fq inst_evals[3];
+  SparseMatPolyEvalProof r1cs_eval_proof;
+  // SNARK::encode (lib.rs:325-336)
+  static void encode(Ctx& ctx, const Instance& inst, const SNARKGens& gens, ComputationCommitment* comm, ComputationDecommitment* decomm);
+  // SNARK::prove (lib.rs:339-420). `tape_seed` replaces the OsRng draw of RandomTape::new (random.rs:13-15).
+  static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
+                     const FqVec& vars, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript, const Fq& tape_seed,
+                     ProveTimes* times = nullptr);
+  std::vector<uint8_t> serialize() const;  // bincode 1.3 default encoding
+};
+struct NIZK {  // lib.rs:488-587
+  R1CSProof r1cs_sat_proof;
+  FqVec rx, ry;
+  static NIZK prove(Ctx& ctx, const Instance& inst, const FqVec& vars, const FqVec& inputs, const NIZKGens& gens, Transcript& transcript,
+                    const Fq& tape_seed, ProveTimes* times = nullptr);
+  std::vector<uint8_t> serialize() const;
+};
+
+std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p);
+
+}  // namespace spz

@@ -1,0 +1,724 @@
+// spartan_amd host driver: the prover of libspartan (src/lib.rs, r1csproof.rs, sumcheck.rs, nizk/, dense_mlpoly.rs,
+// sparse_mlpoly.rs, product_tree.rs) re-expressed over device-resident tables and fixed-base MSMs.
+// Every group operation and every O(N) field pass is an sp_* call (HIP); see libspartan.hpp.
+#include "libspartan.hpp"
+
+#include <chrono>
+#include <cstdio>
+
+namespace spz {
+using namespace sp;
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define SPX(call)                                                                                        \
+  do {                                                                                                   \
+    int32_t rc_ = (call);                                                                                \
+    if (rc_ != SP_OK) throw Error(std::string(#call) + " failed: " + sp_strerror(rc_) + " (" + std::to_string(rc_) + ")"); \
+  } while (0)
+#define REQUIRE(cond)                                                    \
+  do {                                                                   \
+    if (!(cond)) throw Error(std::string("requirement failed: ") + #cond); \
+  } while (0)
+
+static inline const uint64_t* U(const Fq& x) { return x.l; }
+static inline const uint64_t* U(const FqVec& v) { return v.empty() ? nullptr : v[0].l; }
+static inline uint64_t* U(FqVec& v) { return v.empty() ? nullptr : v[0].l; }
+static size_t pow2(size_t e) { return (size_t)1 << e; }
+static size_t log_2(size_t n) {  // math.rs:21-29: ceil for non powers of two
+  size_t l = 0;
+  while (((size_t)1 << l) < n) l++;
+  return l;
+}
+static size_t next_pow2(size_t n) { return pow2(log_2(n == 0 ? 1 : n)); }
+
+// ------------------------------------------------------------------ handles
+Ctx::Ctx(int device) { SPX(sp_ctx_create(device, &h)); }
+Ctx::~Ctx() { sp_ctx_destroy(h); }
+DevTable::~DevTable() { sp_table_free(h); }
+DevTable& DevTable::operator=(DevTable&& o) noexcept {
+  if (this != &o) { sp_table_free(h); c = o.c; h = o.h; o.h = nullptr; }
+  return *this;
+}
+DevIndex::~DevIndex() { sp_index_free(h); }
+DevIndex& DevIndex::operator=(DevIndex&& o) noexcept {
+  if (this != &o) { sp_index_free(h); c = o.c; h = o.h; o.h = nullptr; }
+  return *this;
+}
+GensStream::~GensStream() { sp_gens_free(g); }
+GensStream& GensStream::operator=(GensStream&& o) noexcept {
+  if (this != &o) { sp_gens_free(g); c = o.c; g = o.g; compressed = std::move(o.compressed); o.g = nullptr; }
+  return *this;
+}
+
+static DevTable tab_alloc(sp_ctx* c, size_t len) { sp_table* t; SPX(sp_table_alloc(c, len, &t)); return DevTable(c, t); }
+static DevTable tab_upload(sp_ctx* c, const FqVec& v) { sp_table* t; SPX(sp_table_upload(c, U(v), v.size(), &t)); return DevTable(c, t); }
+static DevTable tab_view(sp_ctx* c, const DevTable& p, size_t off, size_t len) { sp_table* t; SPX(sp_table_view(c, p.h, off, len, &t)); return DevTable(c, t); }
+static DevTable tab_clone(sp_ctx* c, const DevTable& p) { sp_table* t; SPX(sp_table_clone(c, p.h, &t)); return DevTable(c, t); }
+static DevTable tab_eq(sp_ctx* c, const FqVec& r) { sp_table* t; SPX(sp_eq_expand(c, U(r), r.size(), &t)); return DevTable(c, t); }
+
+// ------------------------------------------------------------------ generators (commitments.rs:15-33)
+static const uint8_t kBasepointCompressed[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                                 0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+GensStream::GensStream(sp_ctx* c_, const char* label, size_t npoints) : c(c_) {
+  Shake256 shake;  // commitments.rs:16-19
+  shake.absorb(label, strlen(label));
+  shake.absorb(kBasepointCompressed, 32);
+  std::vector<uint8_t> uniform(64 * npoints);
+  shake.squeeze(uniform.data(), uniform.size());
+  compressed.resize(32 * npoints);
+  SPX(sp_gens_from_uniform(c, uniform.data(), npoints, compressed.data(), &g));  // from_uniform_bytes on the device (:21-30)
+}
+MultiCommitGens GensStream::multi_commit_gens(size_t n) const {
+  REQUIRE(n + 1 <= sp_gens_len(g));
+  MultiCommitGens m;
+  m.g = g;
+  m.G.resize(n);
+  for (size_t i = 0; i < n; i++) m.G[i] = (uint32_t)i;
+  m.h = (uint32_t)n;
+  return m;
+}
+DotProductProofGens GensStream::dot_product_gens(size_t n) const {  // nizk/mod.rs:415-418: new(n+1).split_at(n)
+  MultiCommitGens all = multi_commit_gens(n + 1);
+  DotProductProofGens d;
+  d.n = n;
+  d.gens_n.g = d.gens_1.g = g;
+  d.gens_n.G.assign(all.G.begin(), all.G.begin() + n);
+  d.gens_1.G.assign(all.G.begin() + n, all.G.end());
+  d.gens_n.h = d.gens_1.h = all.h;
+  return d;
+}
+PolyCommitmentGens GensStream::poly_commitment_gens(size_t num_vars) const {  // dense_mlpoly.rs:31-35
+  size_t right = num_vars - num_vars / 2;
+  return PolyCommitmentGens{dot_product_gens(pow2(right))};
+}
+static size_t pad_vars(size_t num_vars, size_t num_inputs) {  // lib.rs:288-294
+  size_t v = num_vars > num_inputs + 1 ? num_vars : num_inputs + 1;
+  return next_pow2(v);
+}
+static R1CSGens make_r1cs_gens(const GensStream& s, size_t num_vars_padded) {  // r1csproof.rs:48-73
+  R1CSGens g;
+  g.gens_pc = s.poly_commitment_gens(log_2(num_vars_padded));
+  g.gens_sc.gens_1 = g.gens_pc.gens.gens_1;
+  g.gens_sc.gens_3 = s.multi_commit_gens(3);
+  g.gens_sc.gens_4 = s.multi_commit_gens(4);
+  return g;
+}
+static size_t sat_stream_points(size_t nvp) {
+  size_t lv = log_2(nvp);
+  size_t n = pow2(lv - lv / 2) + 2;
+  return n < 5 ? 5 : n;
+}
+NIZKGens::NIZKGens(Ctx& ctx, size_t, size_t num_vars, size_t num_inputs)
+    : stream_sat(ctx.h, "gens_r1cs_sat", sat_stream_points(pad_vars(num_vars, num_inputs))),
+      gens_r1cs_sat(make_r1cs_gens(stream_sat, pad_vars(num_vars, num_inputs))) {}
+SNARKGens::SNARKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, size_t nnz)
+    : stream_sat(ctx.h, "gens_r1cs_sat", sat_stream_points(pad_vars(num_vars, num_inputs))) {
+  size_t nvp = pad_vars(num_vars, num_inputs);
+  gens_r1cs_sat = make_r1cs_gens(stream_sat, nvp);
+  // r1cs.rs:33-48 -> sparse_mlpoly.rs:313-337, batch_size = 3
+  size_t nvx = log_2(num_cons), nvy = log_2(2 * nvp);
+  size_t num_vars_ops = log_2(next_pow2(nnz)) + log_2(next_pow2(3 * 5));
+  size_t num_vars_mem = (nvx > nvy ? nvx : nvy) + 1;
+  size_t num_vars_derefs = log_2(next_pow2(nnz)) + log_2(next_pow2(3 * 2));
+  size_t mx = 0;
+  for (size_t v : {num_vars_ops, num_vars_mem, num_vars_derefs}) mx = std::max(mx, pow2(v - v / 2));
+  stream_eval = GensStream(ctx.h, "gens_r1cs_eval", mx + 2);
+  gens_r1cs_eval.gens_ops = stream_eval.poly_commitment_gens(num_vars_ops);
+  gens_r1cs_eval.gens_mem = stream_eval.poly_commitment_gens(num_vars_mem);
+  gens_r1cs_eval.gens_derefs = stream_eval.poly_commitment_gens(num_vars_derefs);
+}
+
+// ------------------------------------------------------------------ instance (lib.rs:121-228)
+Instance::Instance(Ctx& ctx, size_t nc, size_t nv, size_t ni, const std::vector<SparseEntry>& A_, const std::vector<SparseEntry>& B_,
+                   const std::vector<SparseEntry>& C_)
+    : c(ctx.h) {
+  // padding rules: lib.rs:129-156
+  size_t nvp = next_pow2(std::max(nv, ni + 1));
+  size_t ncp = nc;
+  if (nc == 0 || nc == 1) ncp = 2;
+  if (next_pow2(nc) != nc) ncp = next_pow2(nc);
+  size_t shift = nvp - nv;
+  auto conv = [&](const std::vector<SparseEntry>& in, std::vector<SparseEntry>& out) {
+    for (auto& e : in) {
+      if (e.row >= nc || e.col >= nv + 1 + ni) throw Error("InvalidIndex");  // lib.rs:164-172
+      SparseEntry o = e;
+      if (e.col >= nv) o.col = e.col + shift;  // lib.rs:178-182: references to 1 / inputs move with the padding
+      out.push_back(o);
+    }
+    // lib.rs:188-194: explicit zero constraints only when the original count was 0 or 1
+    if (nc == 0 || nc == 1)
+      for (size_t i = in.size(); i < ncp; i++) out.push_back(SparseEntry{i, nv, fq_zero()});
+  };
+  conv(A_, A); conv(B_, B); conv(C_, C);
+  num_cons = ncp; num_vars = nvp; num_inputs = ni;
+  auto up = [&](const std::vector<SparseEntry>& m, sp_sparse** d) {
+    std::vector<uint64_t> r(m.size()), cc(m.size());
+    FqVec v(m.size());
+    for (size_t i = 0; i < m.size(); i++) { r[i] = m[i].row; cc[i] = m[i].col; v[i] = m[i].val; }
+    SPX(sp_sparse_upload(c, r.data(), cc.data(), U(v), m.size(), num_cons, 2 * num_vars, d));
+  };
+  up(A, &dA); up(B, &dB); up(C, &dC);
+}
+Instance::~Instance() { sp_sparse_free(dA); sp_sparse_free(dB); sp_sparse_free(dC); }
+
+Fq seed_scalar(const char* domain, uint64_t seed) {
+  Shake256 sh;
+  sh.absorb(domain, strlen(domain));
+  uint8_t sb[8];
+  for (int i = 0; i < 8; i++) sb[i] = (uint8_t)(seed >> (8 * i));
+  sh.absorb(sb, 8);
+  uint8_t buf[64];
+  sh.squeeze(buf, 64);
+  uint64_t w[8];
+  memcpy(w, buf, 64);
+  return fq_from_u512(w);
+}
+std::unique_ptr<Instance> Instance::produce_synthetic_r1cs(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, uint64_t seed,
+                                                           FqVec* vars, FqVec* inputs) {
+  REQUIRE(pow2(log_2(num_cons)) == num_cons && pow2(log_2(num_vars)) == num_vars && num_inputs < num_vars);  // r1cs.rs:165-167
+  size_t size_z = num_vars + num_inputs + 1;
+  Shake256 sh;
+  const char* dom = "spartan-synthetic-r1cs";
+  sh.absorb(dom, strlen(dom));
+  uint8_t sb[8];
+  for (int i = 0; i < 8; i++) sb[i] = (uint8_t)(seed >> (8 * i));
+  sh.absorb(sb, 8);
+  FqVec Z(size_z);  // Scalar::random = from_u512 of 64 random bytes (ristretto255.rs:374-380)
+  for (size_t i = 0; i < size_z; i++) {
+    uint8_t buf[64];
+    sh.squeeze(buf, 64);
+    uint64_t w[8];
+    memcpy(w, buf, 64);
+    Z[i] = fq_from_u512(w);
+  }
+  Z[num_vars] = fq_one();  // r1cs.rs:187
+  // C_val = Z_A * Z_B / Z_C (r1cs.rs:205-213): one batch inversion instead of num_cons inversions (same values)
+  FqVec cinv(num_cons), pref(num_cons);
+  Fq acc = fq_one();
+  for (size_t i = 0; i < num_cons; i++) {
+    Fq cz = Z[(i + 3) % size_z];
+    cinv[i] = fq_is_zero(cz) ? fq_one() : cz;
+    pref[i] = acc;
+    acc = acc * cinv[i];
+  }
+  acc = fq_invert(acc);
+  for (size_t i = num_cons; i-- > 0;) {
+    Fq tmp = acc * cinv[i];
+    cinv[i] = acc * pref[i];
+    acc = tmp;
+  }
+  std::vector<SparseEntry> A, B, C;
+  for (size_t i = 0; i < num_cons; i++) {
+    size_t A_idx = i % size_z, B_idx = (i + 2) % size_z, C_idx = (i + 3) % size_z;
+    A.push_back({i, A_idx, fq_one()});
+    B.push_back({i, B_idx, fq_one()});
+    Fq AB = Z[A_idx] * Z[B_idx];
+    if (fq_is_zero(Z[C_idx])) C.push_back({i, num_vars, AB});
+    else C.push_back({i, C_idx, AB * cinv[i]});
+  }
+  vars->assign(Z.begin(), Z.begin() + num_vars);
+  inputs->assign(Z.begin() + num_vars + 1, Z.end());
+  return std::unique_ptr<Instance>(new Instance(ctx, num_cons, num_vars, num_inputs, A, B, C));
+}
+
+// ------------------------------------------------------------------ commitments (commitments.rs:73-92)
+static CP to_cp(const uint8_t* p) { CP c; memcpy(c.data(), p, 32); return c; }
+// rows of scalars over an explicit generator index list
+static std::vector<CP> msm_rows(sp_ctx* c, const sp_gens* g, const std::vector<uint32_t>& idx, const FqVec& scalars, size_t rows) {
+  REQUIRE(scalars.size() == rows * idx.size());
+  std::vector<uint8_t> out(32 * rows);
+  SPX(sp_msm_indexed(c, g, idx.data(), idx.size(), U(scalars), rows, out.data()));
+  std::vector<CP> r(rows);
+  for (size_t i = 0; i < rows; i++) r[i] = to_cp(&out[32 * i]);
+  return r;
+}
+static CP commit_scalar(sp_ctx* c, const Fq& x, const Fq& blind, const MultiCommitGens& g1) {  // Scalar::commit :73-78
+  REQUIRE(g1.n() == 1);
+  return msm_rows(c, g1.g, {g1.G[0], g1.h}, {x, blind}, 1)[0];
+}
+static CP commit_vec(sp_ctx* c, const FqVec& v, const Fq& blind, const MultiCommitGens& gn) {  // [Scalar]::commit :80-92
+  REQUIRE(gn.n() == v.size());
+  bool contiguous = true;
+  for (size_t i = 0; i < gn.G.size(); i++) contiguous = contiguous && gn.G[i] == gn.G[0] + i;
+  if (contiguous && v.size() >= 64) {
+    uint8_t out[32];
+    SPX(sp_commit_rows(c, gn.g, gn.G[0], gn.h, U(v), 1, v.size(), U(blind), out));
+    return to_cp(out);
+  }
+  std::vector<uint32_t> idx = gn.G;
+  idx.push_back(gn.h);
+  FqVec s = v;
+  s.push_back(blind);
+  return msm_rows(c, gn.g, idx, s, 1)[0];
+}
+// DensePolynomial::commit (dense_mlpoly.rs:179-204): L row commitments of the R-wide rows of a device table
+static PolyCommitment poly_commit(sp_ctx* c, const DevTable& Z, size_t num_vars, const PolyCommitmentGens& gens, const FqVec* blinds) {
+  size_t Ls = pow2(num_vars / 2), Rs = pow2(num_vars - num_vars / 2);
+  const MultiCommitGens& g = gens.gens.gens_n;
+  REQUIRE(g.n() == Rs && Z.len() == Ls * Rs);
+  REQUIRE(!blinds || blinds->size() == Ls);
+  std::vector<uint8_t> out(32 * Ls);
+  SPX(sp_commit_rows_dev(c, g.g, g.G[0], g.h, Z.h, 0, Ls, Rs, blinds ? U(*blinds) : nullptr, out.data()));
+  PolyCommitment pc;
+  pc.C.resize(Ls);
+  for (size_t i = 0; i < Ls; i++) pc.C[i] = to_cp(&out[32 * i]);
+  return pc;
+}
+static void append_poly_commitment(Transcript& t, const char* label, const PolyCommitment& c) {  // dense_mlpoly.rs:292-300
+  t.append_message(label, "poly_commitment_begin");
+  for (auto& pt : c.C) t.append_point("poly_commitment_share", pt.data());
+  t.append_message(label, "poly_commitment_end");
+}
+
+// ------------------------------------------------------------------ small host-side algebra (O(log n) / O(sqrt n) sized)
+static FqVec eq_evals_host(const FqVec& r) {  // EqPolynomial::evals (dense_mlpoly.rs:68-84); used only for the sqrt(N)-sized L/R vectors
+  size_t ell = r.size();
+  FqVec evals(pow2(ell), fq_one());
+  size_t size = 1;
+  for (size_t j = 0; j < ell; j++) {
+    size *= 2;
+    for (size_t i = size - 1;; i -= 2) {
+      Fq scalar = evals[i / 2];
+      evals[i] = scalar * r[j];
+      evals[i - 1] = scalar - evals[i];
+      if (i == 1) break;
+    }
+  }
+  return evals;
+}
+struct UniPoly {  // unipoly.rs
+  FqVec coeffs;
+  static UniPoly from_evals(const FqVec& e) {  // :23-55
+    static const Fq two_inv = fq_invert(fq_from_u64(2)), six_inv = fq_invert(fq_from_u64(6));
+    UniPoly u;
+    if (e.size() == 3) {
+      Fq c = e[0];
+      Fq a = two_inv * (e[2] - e[1] - e[1] + c);
+      Fq b = e[1] - c - a;
+      u.coeffs = {c, b, a};
+    } else {
+      REQUIRE(e.size() == 4);
+      Fq d = e[0];
+      Fq a = six_inv * (e[3] - e[2] - e[2] - e[2] + e[1] + e[1] + e[1] - e[0]);
+      Fq b = two_inv * (e[0] + e[0] - e[1] - e[1] - e[1] - e[1] - e[1] + e[2] + e[2] + e[2] + e[2] - e[3]);
+      Fq c = e[1] - d - a - b;
+      u.coeffs = {d, c, b, a};
+    }
+    return u;
+  }
+  size_t degree() const { return coeffs.size() - 1; }
+  Fq evaluate(const Fq& r) const {  // :72-80
+    Fq eval = coeffs[0], power = r;
+    for (size_t i = 1; i < coeffs.size(); i++) { eval += power * coeffs[i]; power *= r; }
+    return eval;
+  }
+  FqVec compress() const {  // :82-88
+    FqVec c;
+    c.push_back(coeffs[0]);
+    c.insert(c.end(), coeffs.begin() + 2, coeffs.end());
+    return c;
+  }
+  void append_to_transcript(Transcript& t, const char* label) const {  // :112-120
+    t.append_message(label, "UniPoly_begin");
+    for (auto& c : coeffs) t.append_scalar("coeff", c);
+    t.append_message(label, "UniPoly_end");
+  }
+};
+static Fq dot_host(const FqVec& a, const FqVec& b) {
+  Fq s = fq_zero();
+  for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i];
+  return s;
+}
+
+// ------------------------------------------------------------------ nizk/mod.rs Sigma protocols
+static KnowledgeProof knowledge_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& x, const Fq& r, CP* C_out) {
+  t.append_protocol_name("knowledge proof");  // :27-52
+  Fq t1 = tape.random_scalar("t1"), t2 = tape.random_scalar("t2");
+  std::vector<CP> cm = msm_rows(c, g.g, {g.G[0], g.h}, {x, r, t1, t2}, 2);
+  t.append_point("C", cm[0].data());
+  t.append_point("alpha", cm[1].data());
+  Fq ch = t.challenge_scalar("c");
+  *C_out = cm[0];
+  return KnowledgeProof{cm[1], x * ch + t1, r * ch + t2};
+}
+static EqualityProof equality_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& v1, const Fq& s1, const Fq& v2,
+                                    const Fq& s2) {
+  t.append_protocol_name("equality proof");  // :88-116
+  Fq r = tape.random_scalar("r");
+  std::vector<CP> cm = msm_rows(c, g.g, {g.G[0], g.h}, {v1, s1, v2, s2, fq_zero(), r}, 3);  // C1, C2, alpha = r*h
+  t.append_point("C1", cm[0].data());
+  t.append_point("C2", cm[1].data());
+  t.append_point("alpha", cm[2].data());
+  Fq ch = t.challenge_scalar("c");
+  return EqualityProof{cm[2], ch * (s1 - s2) + r};
+}
+static ProductProof product_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& x, const Fq& rX, const Fq& y,
+                                  const Fq& rY, const Fq& z, const Fq& rZ, CP* Xo, CP* Yo, CP* Zo) {
+  t.append_protocol_name("product proof");  // :159-227
+  Fq b1 = tape.random_scalar("b1"), b2 = tape.random_scalar("b2"), b3 = tape.random_scalar("b3");
+  Fq b4 = tape.random_scalar("b4"), b5 = tape.random_scalar("b5");
+  // delta = b3*X + b5*h with X = x*G + rX*h  ==  (b3*x)*G + (b3*rX + b5)*h : same group element, fixed-base form
+  std::vector<CP> cm = msm_rows(c, g.g, {g.G[0], g.h}, {x, rX, y, rY, z, rZ, b1, b2, b3, b4, b3 * x, b3 * rX + b5}, 6);
+  t.append_point("X", cm[0].data());
+  t.append_point("Y", cm[1].data());
+  t.append_point("Z", cm[2].data());
+  t.append_point("alpha", cm[3].data());
+  t.append_point("beta", cm[4].data());
+  t.append_point("delta", cm[5].data());
+  Fq ch = t.challenge_scalar("c");
+  ProductProof p;
+  p.alpha = cm[3]; p.beta = cm[4]; p.delta = cm[5];
+  p.z[0] = b1 + ch * x; p.z[1] = b2 + ch * rX; p.z[2] = b3 + ch * y; p.z[3] = b4 + ch * rY; p.z[4] = b5 + ch * (rZ - rX * y);
+  *Xo = cm[0]; *Yo = cm[1]; *Zo = cm[2];
+  return p;
+}
+
+// ------------------------------------------------------------------ sumcheck.rs: the two ZK provers share everything but `kind`
+// kind 2: prove_cubic_with_additive_term (:588-776), tables (A,B,C,D), comb A*(B*C-D), gens_n = gens_4
+// kind 0: prove_quad (:428-586), tables (A,B), comb A*B, gens_n = gens_3
+static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& claim, const Fq& blind_claim, size_t num_rounds,
+                                                 std::vector<sp_table*> tabs, const MultiCommitGens& g1, const MultiCommitGens& gn, Transcript& t,
+                                                 RandomTape& tape, FqVec* r_out, FqVec* final_claims, Fq* blind_post) {
+  FqVec blinds_poly = tape.random_vector("blinds_poly", num_rounds);
+  FqVec blinds_evals = tape.random_vector("blinds_evals", num_rounds);
+  Fq claim_per_round = claim;
+  CP comm_claim_per_round = commit_scalar(c, claim_per_round, blind_claim, g1);
+  ZKSumcheckInstanceProof out;
+  FqVec r;
+  std::vector<uint32_t> idx_n = gn.G;
+  idx_n.push_back(gn.h);
+  // union index list for the per-round Sigma commitments: (gn.G..., gn.h, g1.G, g1.h)
+  std::vector<uint32_t> idx_u = idx_n;
+  idx_u.push_back(g1.G[0]);
+  idx_u.push_back(g1.h);
+  size_t nn = gn.n(), W = idx_u.size();
+  uint64_t ev[12];
+  SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev));
+  for (size_t j = 0; j < num_rounds; j++) {
+    Fq e0, e2, e3;
+    memcpy(e0.l, ev, 32); memcpy(e2.l, ev + 4, 32); memcpy(e3.l, ev + 8, 32);
+    UniPoly poly = kind == 0 ? UniPoly::from_evals({e0, claim_per_round - e0, e2}) : UniPoly::from_evals({e0, claim_per_round - e0, e2, e3});
+    REQUIRE(poly.coeffs.size() == nn);
+    CP comm_poly = commit_vec(c, poly.coeffs, blinds_poly[j], gn);  // sumcheck.rs:473 / 661
+    t.append_point("comm_poly", comm_poly.data());
+    out.comm_polys.push_back(comm_poly);
+    Fq r_j = t.challenge_scalar("challenge_nextround");
+    // bind every table at r_j (sumcheck.rs:485-486 / 673-676); fused with the next round's evaluation
+    if (sp_table_len(tabs[0]) >= 4) SPX(sp_sumcheck_bind_eval(c, kind, tabs.data(), tabs.size(), U(r_j), ev));
+    else SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
+    // ---- round tail (sumcheck.rs:491-583 / 681-772)
+    Fq eval = poly.evaluate(r_j);
+    // dot product proof randomness (nizk/mod.rs:330-332)
+    FqVec d = tape.random_vector("d_vec", nn);
+    Fq r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_beta");
+    // batch 1: comm_eval = eval*G1 + blinds_evals[j]*h1 ; delta = <d, Gn> + r_delta*hn
+    FqVec rows1(2 * W, fq_zero());
+    rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
+    for (size_t k = 0; k < nn; k++) rows1[W + k] = d[k];
+    rows1[W + nn] = r_delta;
+    std::vector<CP> cm1 = msm_rows(c, gn.g, idx_u, rows1, 2);
+    CP comm_eval = cm1[0], delta = cm1[1];
+    t.append_point("comm_claim_per_round", comm_claim_per_round.data());
+    t.append_point("comm_eval", comm_eval.data());
+    FqVec w = t.challenge_vector("combine_two_claims_to_one", 2);
+    Fq target = w[0] * claim_per_round + w[1] * eval;
+    const Fq& blind_sc = (j == 0) ? blind_claim : blinds_evals[j - 1];
+    Fq blind = w[0] * blind_sc + w[1] * blinds_evals[j];
+    FqVec a(nn);
+    Fq pw = fq_one();
+    for (size_t i = 0; i < nn; i++) {
+      Fq a_sc = (i == 0) ? fq_one() + fq_one() : fq_one();
+      a[i] = w[0] * a_sc + w[1] * pw;
+      pw = pw * r_j;
+    }
+    // DotProductProof::prove (nizk/mod.rs:311-370): x = poly.coeffs, blind_x = blinds_poly[j], y = target, blind_y = blind
+    t.append_protocol_name("dot product proof");
+    // Cx = commit(x, blind_x) is the same group element as comm_poly (same inputs, same generators)
+    t.append_point("Cx", comm_poly.data());
+    Fq dp = dot_host(a, d);
+    // batch 2: Cy = target*G1 + blind*h1 ; beta = dp*G1 + r_beta*h1
+    std::vector<CP> cm2 = msm_rows(c, g1.g, {g1.G[0], g1.h}, {target, blind, dp, r_beta}, 2);
+    t.append_point("Cy", cm2[0].data());
+    t.append_scalars("a", a);
+    t.append_point("delta", delta.data());
+    t.append_point("beta", cm2[1].data());
+    Fq ch = t.challenge_scalar("c");
+    DotProductProof dpp;
+    dpp.delta = delta; dpp.beta = cm2[1];
+    dpp.z.resize(nn);
+    for (size_t i = 0; i < nn; i++) dpp.z[i] = ch * poly.coeffs[i] + d[i];
+    dpp.z_delta = ch * blinds_poly[j] + r_delta;
+    dpp.z_beta = ch * blind + r_beta;
+    claim_per_round = eval;
+    comm_claim_per_round = comm_eval;
+    out.proofs.push_back(dpp);
+    out.comm_evals.push_back(comm_eval);
+    r.push_back(r_j);
+  }
+  final_claims->resize(tabs.size());
+  SPX(sp_table_heads(c, tabs.data(), tabs.size(), U(*final_claims)));
+  *r_out = r;
+  *blind_post = blinds_evals[num_rounds - 1];
+  return out;
+}
+
+// ------------------------------------------------------------------ DotProductProofLog (nizk/mod.rs:440-525) + bullet.rs:32-132
+static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGens& gens, Transcript& t, RandomTape& tape, const FqVec& x,
+                                              const Fq& blind_x, const FqVec& a, const Fq& y, const Fq& blind_y, CP* Cy_out) {
+  t.append_protocol_name("dot product proof (log)");
+  size_t n = x.size();
+  REQUIRE(a.size() == n && gens.n == n);
+  Fq d = tape.random_scalar("d");
+  Fq r_delta = tape.random_scalar("r_delta");
+  Fq r_beta = tape.random_scalar("r_delta");  // sic: the reference draws r_beta under the label "r_delta" (nizk/mod.rs:459)
+  size_t lg_n = log_2(n);
+  FqVec v1 = tape.random_vector("blinds_vec_1", lg_n), v2 = tape.random_vector("blinds_vec_2", lg_n);
+  const MultiCommitGens &gn = gens.gens_n, &g1 = gens.gens_1;
+  CP Cx = commit_vec(c, x, blind_x, gn);
+  t.append_point("Cx", Cx.data());
+  CP Cy = commit_scalar(c, y, blind_y, g1);
+  t.append_point("Cy", Cy.data());
+  t.append_scalars("a", a);
+  Fq r = t.challenge_scalar("r");
+  Fq blind_Gamma = blind_x + r * blind_y;
+  // BulletReductionProof::prove with Q = r*G1 (gens_1.scale(r), nizk/mod.rs:479-480), H = h
+  sp_ipa* ipa = nullptr;
+  SPX(sp_ipa_begin(c, gn.g, gn.G[0], n, g1.G[0], gn.h, U(r), U(x), U(a), &ipa));
+  DotProductProofLog p;
+  Fq blind_hat = blind_Gamma;
+  try {
+    for (size_t k = 0; k < lg_n; k++) {
+      CP L, R;
+      SPX(sp_ipa_round_lr(ipa, U(v1[k]), U(v2[k]), L.data(), R.data()));
+      t.append_point("L", L.data());
+      t.append_point("R", R.data());
+      Fq u = t.challenge_scalar("u");
+      Fq u_inv = fq_invert(u);
+      SPX(sp_ipa_round_fold(ipa, U(u), U(u_inv)));
+      blind_hat = blind_hat + v1[k] * u * u + v2[k] * u_inv * u_inv;
+      p.bullet.L_vec.push_back(L);
+      p.bullet.R_vec.push_back(R);
+    }
+    Fq a_hat, b_hat;
+    SPX(sp_ipa_finish(ipa, a_hat.l, b_hat.l, nullptr));
+    Fq y_hat = a_hat * b_hat;
+    CP delta;
+    SPX(sp_ipa_commit_ghat(ipa, U(d), U(r_delta), delta.data()));  // commit(d, r_delta) under {g_hat, h}
+    t.append_point("delta", delta.data());
+    CP beta = msm_rows(c, g1.g, {g1.G[0], g1.h}, {d * r, r_beta}, 1)[0];  // commit(d, r_beta) under gens_1.scale(r)
+    t.append_point("beta", beta.data());
+    Fq ch = t.challenge_scalar("c");
+    p.delta = delta; p.beta = beta;
+    p.z1 = d + ch * y_hat;
+    p.z2 = b_hat * (ch * blind_hat + r_beta) + r_delta;
+  } catch (...) {
+    sp_ipa_free(ipa);
+    throw;
+  }
+  sp_ipa_free(ipa);
+  if (Cy_out) *Cy_out = Cy;
+  return p;
+}
+
+// PolyEvalProof::prove (dense_mlpoly.rs:312-365)
+static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec* blinds_opt, const FqVec& r, const Fq& Zr, const Fq* blind_Zr_opt,
+                                    const PolyCommitmentGens& gens, Transcript& t, RandomTape& tape, CP* C_Zr) {
+  t.append_protocol_name("polynomial evaluation proof");
+  size_t Ls = pow2(r.size() / 2), Rs = pow2(r.size() - r.size() / 2);
+  REQUIRE(poly.len() == Ls * Rs);
+  FqVec Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
+  FqVec Rv = eq_evals_host(FqVec(r.begin() + r.size() / 2, r.end()));
+  FqVec LZ(Rs);
+  SPX(sp_vecmat(c, U(Lv), Ls, poly.h, U(LZ)));  // DensePolynomial::bound :349
+  Fq LZ_blind = fq_zero();
+  if (blinds_opt) {
+    REQUIRE(blinds_opt->size() == Ls);
+    LZ_blind = dot_host(*blinds_opt, Lv);
+  }
+  Fq blind_Zr = blind_Zr_opt ? *blind_Zr_opt : fq_zero();
+  PolyEvalProof p;
+  p.proof = dotproductlog_prove(c, gens.gens, t, tape, LZ, LZ_blind, Rv, Zr, blind_Zr, C_Zr);
+  return p;
+}
+
+// ------------------------------------------------------------------ R1CSProof::prove (r1csproof.rs:144-349)
+static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const FqVec& vars, const FqVec& input, const R1CSGens& gens, Transcript& t,
+                            RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm) {
+  double t0 = now_s();
+  t.append_protocol_name("R1CS proof");
+  REQUIRE(input.size() < vars.size());
+  REQUIRE(vars.size() == inst.num_vars && input.size() == inst.num_inputs);
+  t.append_scalars("input", input);
+  R1CSProof P;
+  size_t num_vars = vars.size(), lv = log_2(num_vars);
+  // polycommit (:160-171)
+  DevTable poly_vars = tab_upload(c, vars);
+  FqVec blinds_vars = tape.random_vector("poly_blinds", pow2(lv / 2));
+  P.comm_vars = poly_commit(c, poly_vars, lv, gens.gens_pc, &blinds_vars);
+  append_poly_commitment(t, "poly_commitment", P.comm_vars);
+  if (tm) tm->polycommit = now_s() - t0;
+
+  double t1 = now_s();
+  // z = vars | 1 | input | 0...  (:177-185), built on the device
+  DevTable z = tab_alloc(c, 2 * num_vars);
+  SPX(sp_table_copy(c, z.h, 0, poly_vars.h, 0, num_vars));
+  {
+    FqVec tail;
+    tail.push_back(fq_one());
+    tail.insert(tail.end(), input.begin(), input.end());
+    SPX(sp_table_write(c, z.h, num_vars, U(tail), tail.size()));
+  }
+  size_t num_rounds_x = log_2(inst.num_cons), num_rounds_y = log_2(2 * num_vars);
+  FqVec tau = t.challenge_vector("challenge_tau", num_rounds_x);
+  DevTable poly_tau = tab_eq(c, tau);
+  sp_table *tAz, *tBz, *tCz;
+  SPX(sp_sparse_mulvec(c, inst.dA, z.h, &tAz));
+  DevTable poly_Az(c, tAz);
+  SPX(sp_sparse_mulvec(c, inst.dB, z.h, &tBz));
+  DevTable poly_Bz(c, tBz);
+  SPX(sp_sparse_mulvec(c, inst.dC, z.h, &tCz));
+  DevTable poly_Cz(c, tCz);
+  FqVec rx, claims1;
+  Fq blind_claim_postsc1;
+  P.sc_proof_phase1 = zk_sumcheck_prove(c, 2, fq_zero(), fq_zero(), num_rounds_x, {poly_tau.h, poly_Az.h, poly_Bz.h, poly_Cz.h},
+                                        gens.gens_sc.gens_1, gens.gens_sc.gens_4, t, tape, &rx, &claims1, &blind_claim_postsc1);
+  if (tm) tm->sc_phase_one = now_s() - t1;
+  const Fq &tau_claim = claims1[0], &Az_claim = claims1[1], &Bz_claim = claims1[2], &Cz_claim = claims1[3];
+  Fq Az_blind = tape.random_scalar("Az_blind"), Bz_blind = tape.random_scalar("Bz_blind");
+  Fq Cz_blind = tape.random_scalar("Cz_blind"), prod_Az_Bz_blind = tape.random_scalar("prod_Az_Bz_blind");
+  CP comm_Cz, comm_Az, comm_Bz, comm_prod;
+  P.pok_claims_phase2 = knowledge_prove(c, gens.gens_sc.gens_1, t, tape, Cz_claim, Cz_blind, &comm_Cz);
+  Fq prod = Az_claim * Bz_claim;
+  P.proof_prod = product_prove(c, gens.gens_sc.gens_1, t, tape, Az_claim, Az_blind, Bz_claim, Bz_blind, prod, prod_Az_Bz_blind, &comm_Az, &comm_Bz,
+                               &comm_prod);
+  t.append_point("comm_Az_claim", comm_Az.data());
+  t.append_point("comm_Bz_claim", comm_Bz.data());
+  t.append_point("comm_Cz_claim", comm_Cz.data());
+  t.append_point("comm_prod_Az_Bz_claims", comm_prod.data());
+  P.claims_phase2[0] = comm_Az; P.claims_phase2[1] = comm_Bz; P.claims_phase2[2] = comm_Cz; P.claims_phase2[3] = comm_prod;
+  Fq blind_expected_claim_postsc1 = tau_claim * (prod_Az_Bz_blind - Cz_blind);
+  Fq claim_post_phase1 = (Az_claim * Bz_claim - Cz_claim) * tau_claim;
+  P.proof_eq_sc_phase1 = equality_prove(c, gens.gens_sc.gens_1, t, tape, claim_post_phase1, blind_expected_claim_postsc1, claim_post_phase1,
+                                        blind_claim_postsc1);
+
+  double t2 = now_s();
+  Fq r_A = t.challenge_scalar("challenge_Az"), r_B = t.challenge_scalar("challenge_Bz"), r_C = t.challenge_scalar("challenge_Cz");
+  Fq claim_phase2 = r_A * Az_claim + r_B * Bz_claim + r_C * Cz_claim;
+  Fq blind_claim_phase2 = r_A * Az_blind + r_B * Bz_blind + r_C * Cz_blind;
+  DevTable poly_ABC;
+  {
+    DevTable evals_rx = tab_eq(c, rx);  // :274
+    const sp_sparse* ms[3] = {inst.dA, inst.dB, inst.dC};
+    FqVec w = {r_A, r_B, r_C};
+    sp_table* tt;
+    SPX(sp_sparse_eval_table(c, ms, U(w), 3, evals_rx.h, &tt));  // :275-283
+    poly_ABC = DevTable(c, tt);
+  }
+  FqVec ry, claims2;
+  Fq blind_claim_postsc2;
+  P.sc_proof_phase2 = zk_sumcheck_prove(c, 0, claim_phase2, blind_claim_phase2, num_rounds_y, {z.h, poly_ABC.h}, gens.gens_sc.gens_1,
+                                        gens.gens_sc.gens_3, t, tape, &ry, &claims2, &blind_claim_postsc2);
+  if (tm) tm->sc_phase_two = now_s() - t2;
+
+  double t3 = now_s();
+  FqVec ry1(ry.begin() + 1, ry.end());
+  Fq eval_vars_at_ry;
+  SPX(sp_evaluate(c, poly_vars.h, U(ry1), ry1.size(), eval_vars_at_ry.l));  // :299
+  Fq blind_eval = tape.random_scalar("blind_eval");
+  P.proof_eval_vars_at_ry = polyeval_prove(c, poly_vars, &blinds_vars, ry1, eval_vars_at_ry, &blind_eval, gens.gens_pc, t, tape, &P.comm_vars_at_ry);
+  if (tm) tm->polyeval = now_s() - t3;
+
+  Fq blind_eval_Z_at_ry = (fq_one() - ry[0]) * blind_eval;
+  Fq blind_expected_claim_postsc2 = claims2[1] * blind_eval_Z_at_ry;
+  Fq claim_post_phase2 = claims2[0] * claims2[1];
+  P.proof_eq_sc_phase2 = equality_prove(c, gens.gens_pc.gens.gens_1, t, tape, claim_post_phase2, blind_expected_claim_postsc2, claim_post_phase2,
+                                        blind_claim_postsc2);
+  *rx_out = rx;
+  *ry_out = ry;
+  if (tm) tm->r1cs_sat = now_s() - t0;
+  return P;
+}
+
+static FqVec pad_vars_assignment(const Instance& inst, const FqVec& vars) {  // lib.rs:360-368, 519-526
+  FqVec v = vars;
+  if (inst.num_vars > v.size()) v.resize(inst.num_vars, fq_zero());
+  return v;
+}
+
+NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const FqVec& vars, const FqVec& inputs, const NIZKGens& gens, Transcript& t, const Fq& tape_seed,
+                 ProveTimes* tm) {  // lib.rs:501-546
+  double t0 = now_s();
+  RandomTape tape("proof", tape_seed);
+  t.append_protocol_name("Spartan NIZK proof");
+  t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());
+  NIZK P;
+  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, pad_vars_assignment(inst, vars), inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm);
+  if (tm) tm->total = now_s() - t0;
+  return P;
+}
+
+#include "spark.inc"
+
+// ------------------------------------------------------------------ bincode 1.3 (fixed-width LE ints, u64 lengths)
+namespace {
+struct Wr {
+  std::vector<uint8_t> b;
+  void u64(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+  void fq(const Fq& x) { for (int i = 0; i < 4; i++) u64(x.l[i]); }  // Scalar serializes its raw Montgomery limbs (ristretto255.rs:198-199)
+  void cp(const CP& c) { b.insert(b.end(), c.begin(), c.end()); }
+  void fqv(const FqVec& v) { u64(v.size()); for (auto& x : v) fq(x); }
+  void cpv(const std::vector<CP>& v) { u64(v.size()); for (auto& x : v) cp(x); }
+};
+void w_dpp(Wr& w, const DotProductProof& p) { w.cp(p.delta); w.cp(p.beta); w.fqv(p.z); w.fq(p.z_delta); w.fq(p.z_beta); }
+void w_zksc(Wr& w, const ZKSumcheckInstanceProof& p) { w.cpv(p.comm_polys); w.cpv(p.comm_evals); w.u64(p.proofs.size()); for (auto& d : p.proofs) w_dpp(w, d); }
+void w_eq(Wr& w, const EqualityProof& p) { w.cp(p.alpha); w.fq(p.z); }
+void w_pe(Wr& w, const PolyEvalProof& p) {
+  w.cpv(p.proof.bullet.L_vec); w.cpv(p.proof.bullet.R_vec); w.cp(p.proof.delta); w.cp(p.proof.beta); w.fq(p.proof.z1); w.fq(p.proof.z2);
+}
+void w_r1cs(Wr& w, const R1CSProof& p) {
+  w.cpv(p.comm_vars.C);
+  w_zksc(w, p.sc_proof_phase1);
+  for (int i = 0; i < 4; i++) w.cp(p.claims_phase2[i]);
+  w.cp(p.pok_claims_phase2.alpha); w.fq(p.pok_claims_phase2.z1); w.fq(p.pok_claims_phase2.z2);
+  w.cp(p.proof_prod.alpha); w.cp(p.proof_prod.beta); w.cp(p.proof_prod.delta);
+  for (int i = 0; i < 5; i++) w.fq(p.proof_prod.z[i]);
+  w_eq(w, p.proof_eq_sc_phase1);
+  w_zksc(w, p.sc_proof_phase2);
+  w.cp(p.comm_vars_at_ry);
+  w_pe(w, p.proof_eval_vars_at_ry);
+  w_eq(w, p.proof_eq_sc_phase2);
+}
+void w_batched(Wr& w, const ProductCircuitEvalProofBatched& p) {
+  w.u64(p.proof.size());
+  for (auto& l : p.proof) {
+    w.u64(l.proof.compressed_polys.size());
+    for (auto& c : l.proof.compressed_polys) w.fqv(c);
+    w.fqv(l.claims_prod_left); w.fqv(l.claims_prod_right);
+  }
+  for (int i = 0; i < 3; i++) w.fqv(p.claims_dotp[i]);
+}
+void w_evalproof(Wr& w, const SparseMatPolyEvalProof& p) {
+  w.cpv(p.comm_derefs.C);
+  const ProductLayerProof& L = p.proof_prod_layer;
+  w.fq(L.row_init); w.fqv(L.row_read); w.fqv(L.row_write); w.fq(L.row_audit);
+  w.fq(L.col_init); w.fqv(L.col_read); w.fqv(L.col_write); w.fq(L.col_audit);
+  w.fqv(L.eval_val[0]); w.fqv(L.eval_val[1]);
+  w_batched(w, L.proof_mem); w_batched(w, L.proof_ops);
+  const HashLayerProof& h = p.proof_hash_layer;
+  w.fqv(h.row_addr); w.fqv(h.row_read_ts); w.fq(h.row_audit_ts);
+  w.fqv(h.col_addr); w.fqv(h.col_read_ts); w.fq(h.col_audit_ts);
+  w.fqv(h.eval_val); w.fqv(h.eval_derefs[0]); w.fqv(h.eval_derefs[1]);
+  w_pe(w, h.proof_ops); w_pe(w, h.proof_mem); w_pe(w, h.proof_derefs);
+}
+}  // namespace
+std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p) { Wr w; w_r1cs(w, p); return w.b; }
+std::vector<uint8_t> NIZK::serialize() const { Wr w; w_r1cs(w, r1cs_sat_proof); w.fqv(rx); w.fqv(ry); return w.b; }
+std::vector<uint8_t> SNARK::serialize() const {
+  Wr w;
+  w_r1cs(w, r1cs_sat_proof);
+  for (int i = 0; i < 3; i++) w.fq(inst_evals[i]);
+  w_evalproof(w, r1cs_eval_proof);
+  return w.b;
+}
+
+}  // namespace spz

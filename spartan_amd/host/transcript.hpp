@@ -1,0 +1,207 @@
+// spartan_amd host driver: Fiat–Shamir layer.
+// Mirrors src/transcript.rs:13-63 (ProofTranscript, AppendToTranscript) and src/random.rs:10-28 (RandomTape)
+// over Merlin 1.0 (STROBE-128 / Keccak-f[1600]); SHAKE256 for MultiCommitGens::new (src/commitments.rs:16-24).
+// The transcript stays on the host exactly as it stays in Rust in the drop-in design.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../csrc/field.hpp"
+
+namespace spz {
+using sp::Fq;
+
+inline uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+inline void keccak_f1600(uint64_t A[25]) {
+  static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                                  0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                                  0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                                  0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                                  0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                                  0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  static const int RHO[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+  static const int PI[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+  for (int round = 0; round < 24; round++) {
+    uint64_t C[5];
+    for (int x = 0; x < 5; x++) C[x] = A[x] ^ A[x + 5] ^ A[x + 10] ^ A[x + 15] ^ A[x + 20];
+    for (int x = 0; x < 5; x++) {
+      uint64_t D = C[(x + 4) % 5] ^ rotl64(C[(x + 1) % 5], 1);
+      for (int y = 0; y < 25; y += 5) A[y + x] ^= D;
+    }
+    uint64_t cur = A[1];
+    for (int i = 0; i < 24; i++) {
+      int j = PI[i];
+      uint64_t tmp = A[j];
+      A[j] = rotl64(cur, RHO[i]);
+      cur = tmp;
+    }
+    for (int y = 0; y < 25; y += 5) {
+      uint64_t r0 = A[y], r1 = A[y + 1], r2 = A[y + 2], r3 = A[y + 3], r4 = A[y + 4];
+      A[y] = r0 ^ (~r1 & r2);
+      A[y + 1] = r1 ^ (~r2 & r3);
+      A[y + 2] = r2 ^ (~r3 & r4);
+      A[y + 3] = r3 ^ (~r4 & r0);
+      A[y + 4] = r4 ^ (~r0 & r1);
+    }
+    A[0] ^= RC[round];
+  }
+}
+
+class Shake256 {  // FIPS 202, rate 136, suffix 0x1f
+ public:
+  Shake256() : pos_(0), squeezing_(false) { memset(st_, 0, sizeof st_); }
+  void absorb(const void* data, size_t n) {
+    const uint8_t* d = (const uint8_t*)data;
+    uint8_t* s = (uint8_t*)st_;
+    for (size_t i = 0; i < n; i++) {
+      s[pos_++] ^= d[i];
+      if (pos_ == 136) { keccak_f1600(st_); pos_ = 0; }
+    }
+  }
+  void squeeze(uint8_t* out, size_t n) {
+    uint8_t* s = (uint8_t*)st_;
+    if (!squeezing_) {
+      s[pos_] ^= 0x1f;
+      s[135] ^= 0x80;
+      keccak_f1600(st_);
+      pos_ = 0;
+      squeezing_ = true;
+    }
+    for (size_t i = 0; i < n; i++) {
+      if (pos_ == 136) { keccak_f1600(st_); pos_ = 0; }
+      out[i] = s[pos_++];
+    }
+  }
+
+ private:
+  uint64_t st_[25];
+  size_t pos_;
+  bool squeezing_;
+};
+
+class Strobe128 {  // STROBE v1.0.2, the subset Merlin uses (AD, meta-AD, PRF), R = 166
+ public:
+  explicit Strobe128(const char* protocol) : pos_(0), pos_begin_(0), cur_flags_(0) {
+    memset(st_, 0, sizeof st_);
+    uint8_t* s = (uint8_t*)st_;
+    const uint8_t init[6] = {1, 168, 1, 0, 1, 96};
+    memcpy(s, init, 6);
+    memcpy(s + 6, "STROBEv1.0.2", 12);
+    keccak_f1600(st_);
+    meta_ad((const uint8_t*)protocol, strlen(protocol), false);
+  }
+  void meta_ad(const uint8_t* d, size_t n, bool more) { begin_op(FLAG_M | FLAG_A, more); absorb(d, n); }
+  void ad(const uint8_t* d, size_t n, bool more) { begin_op(FLAG_A, more); absorb(d, n); }
+  void prf(uint8_t* out, size_t n, bool more) { begin_op(FLAG_I | FLAG_A | FLAG_C, more); squeeze(out, n); }
+
+ private:
+  static constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, FLAG_K = 32;
+  static constexpr int R = 166;
+  void run_f() {
+    uint8_t* s = (uint8_t*)st_;
+    s[pos_] ^= pos_begin_;
+    s[pos_ + 1] ^= 0x04;
+    s[R + 1] ^= 0x80;
+    keccak_f1600(st_);
+    pos_ = 0;
+    pos_begin_ = 0;
+  }
+  void absorb(const uint8_t* d, size_t n) {
+    uint8_t* s = (uint8_t*)st_;
+    for (size_t i = 0; i < n; i++) {
+      s[pos_++] ^= d[i];
+      if (pos_ == R) run_f();
+    }
+  }
+  void squeeze(uint8_t* out, size_t n) {
+    uint8_t* s = (uint8_t*)st_;
+    for (size_t i = 0; i < n; i++) {
+      out[i] = s[pos_];
+      s[pos_++] = 0;
+      if (pos_ == R) run_f();
+    }
+  }
+  void begin_op(uint8_t flags, bool more) {
+    if (more) return;  // continuation of the current operation (flags must match; Merlin guarantees it)
+    uint8_t old_begin = pos_begin_;
+    pos_begin_ = pos_ + 1;
+    cur_flags_ = flags;
+    uint8_t hdr[2] = {old_begin, flags};
+    absorb(hdr, 2);
+    bool force_f = (flags & (FLAG_C | FLAG_K)) != 0;
+    if (force_f && pos_ != 0) run_f();
+  }
+  uint64_t st_[25];
+  uint8_t pos_, pos_begin_, cur_flags_;
+};
+
+class Transcript {  // merlin::Transcript + libspartan's ProofTranscript trait
+ public:
+  explicit Transcript(const char* label) : s_("Merlin v1.0") { append_message("dom-sep", (const uint8_t*)label, strlen(label)); }
+  void append_message(const char* label, const uint8_t* msg, size_t n) {
+    uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    s_.meta_ad((const uint8_t*)label, strlen(label), false);
+    s_.meta_ad(len, 4, true);
+    s_.ad(msg, n, false);
+  }
+  void append_message(const char* label, const char* msg) { append_message(label, (const uint8_t*)msg, strlen(msg)); }
+  void append_u64(const char* label, uint64_t x) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)(x >> (8 * i));
+    append_message(label, b, 8);
+  }
+  void challenge_bytes(const char* label, uint8_t* out, size_t n) {
+    uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    s_.meta_ad((const uint8_t*)label, strlen(label), false);
+    s_.meta_ad(len, 4, true);
+    s_.prf(out, n, false);
+  }
+  // transcript.rs:14-36
+  void append_protocol_name(const char* name) { append_message("protocol-name", name); }
+  void append_scalar(const char* label, const Fq& x) {
+    Fq c = sp::fq_from_mont(x);  // Scalar::to_bytes: canonical little-endian
+    uint8_t b[32];
+    memcpy(b, c.l, 32);
+    append_message(label, b, 32);
+  }
+  void append_point(const char* label, const uint8_t pt[32]) { append_message(label, pt, 32); }
+  Fq challenge_scalar(const char* label) {
+    uint8_t buf[64];
+    challenge_bytes(label, buf, 64);
+    uint64_t w[8];
+    memcpy(w, buf, 64);
+    return sp::fq_from_u512(w);  // Scalar::from_bytes_wide
+  }
+  std::vector<Fq> challenge_vector(const char* label, size_t len) {
+    std::vector<Fq> v(len);
+    for (size_t i = 0; i < len; i++) v[i] = challenge_scalar(label);
+    return v;
+  }
+  // transcript.rs:49-57
+  void append_scalars(const char* label, const Fq* v, size_t n) {
+    append_message(label, "begin_append_vector");
+    for (size_t i = 0; i < n; i++) append_scalar(label, v[i]);
+    append_message(label, "end_append_vector");
+  }
+  void append_scalars(const char* label, const std::vector<Fq>& v) { append_scalars(label, v.data(), v.size()); }
+
+ private:
+  Strobe128 s_;
+};
+
+// random.rs:10-28. The reference seeds from OsRng (random.rs:13-15); `new_with_seed` is the determinism hook
+// the parity contract needs on both sides.
+class RandomTape {
+ public:
+  RandomTape(const char* name, const Fq& seed) : tape_(name) { tape_.append_scalar("init_randomness", seed); }
+  Fq random_scalar(const char* label) { return tape_.challenge_scalar(label); }
+  std::vector<Fq> random_vector(const char* label, size_t len) { return tape_.challenge_vector(label, len); }
+
+ private:
+  Transcript tape_;
+};
+
+}  // namespace spz

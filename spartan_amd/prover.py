@@ -1,0 +1,164 @@
+"""ctypes binding of the host-side prover driver (spartan_amd/host, libspartan_host.so), which mirrors libspartan's
+SNARK/NIZK API on top of the HIP C ABI. No fallback: raises if either library is missing or no GPU is present."""
+import ctypes, os
+from .capi import SpartanHipError, LIB_PATH, sz, vp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_PATH = os.path.join(_HERE, "lib", "libspartan_host.so")
+if not os.path.exists(HOST_PATH):
+    raise SpartanHipError(f"{HOST_PATH} not built: run __graft_entry__.build()")
+ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+H = ctypes.CDLL(HOST_PATH)
+for f in ("spz_ctx_new", "spz_instance_new", "spz_instance_synthetic", "spz_snark_gens_new", "spz_nizk_gens_new", "spz_snark_encode",
+          "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw"):
+    getattr(H, f).restype = vp
+for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script"):
+    getattr(H, f).restype = sz
+H.spz_last_error.restype = ctypes.c_char_p
+for f in ("spz_ctx_free", "spz_instance_free", "spz_snark_gens_free", "spz_nizk_gens_free", "spz_encode_free", "spz_proof_free"):
+    getattr(H, f).argtypes = [vp]
+u64p = ctypes.POINTER(ctypes.c_uint64)
+TIME_NAMES = ["polycommit", "prove_sc_phase_one", "prove_sc_phase_two", "polyeval", "R1CSProof::prove", "eval_sparse_polys",
+              "commit_nondet_witness", "build_layered_network", "evalproof_layered_network", "total"]
+
+
+def _chk(h, what):
+    if not h:
+        raise SpartanHipError(f"{what} failed: {H.spz_last_error().decode()}")
+    return vp(h)
+
+
+class Ctx:
+    def __init__(self, device=0):
+        self.h = _chk(H.spz_ctx_new(ctypes.c_int(device)), "spz_ctx_new")
+
+    def raw(self):
+        """the underlying sp_ctx* (for profiling calls through spartan_amd.capi.lib)"""
+        return vp(H.spz_ctx_raw(self.h))
+
+    def close(self):
+        if self.h:
+            H.spz_ctx_free(self.h); self.h = None
+
+
+class Instance:
+    def __init__(self, h, num_cons, num_vars, num_inputs, vars_=None, inputs=None):
+        self.h, self.num_cons, self.num_vars, self.num_inputs, self.vars, self.inputs = h, num_cons, num_vars, num_inputs, vars_, inputs
+
+    @staticmethod
+    def new(ctx, num_cons, num_vars, num_inputs, nnz, rows, cols, vals):
+        """Instance::new (lib.rs:121): entries of A, B, C back to back; vals = 32 canonical little-endian bytes each."""
+        h = _chk(H.spz_instance_new(ctx.h, sz(num_cons), sz(num_vars), sz(num_inputs), (sz * 3)(*nnz), rows, cols, vals), "Instance::new")
+        return Instance(h, num_cons, num_vars, num_inputs)
+
+    @staticmethod
+    def produce_synthetic_r1cs(ctx, num_cons, num_vars, num_inputs, seed=0):
+        v = (ctypes.c_uint64 * (4 * num_vars))(); i = (ctypes.c_uint64 * (4 * max(num_inputs, 1)))()
+        h = _chk(H.spz_instance_synthetic(ctx.h, sz(num_cons), sz(num_vars), sz(num_inputs), ctypes.c_uint64(seed), v, i), "produce_synthetic_r1cs")
+        return Instance(h, num_cons, num_vars, num_inputs, v, i)
+
+    def set_digest(self, d):
+        H.spz_instance_set_digest(self.h, d, sz(len(d)))
+
+    def free(self):
+        if self.h:
+            H.spz_instance_free(self.h); self.h = None
+
+
+class SNARKGens:
+    def __init__(self, ctx, num_cons, num_vars, num_inputs, num_nz_entries):
+        self.h = _chk(H.spz_snark_gens_new(ctx.h, sz(num_cons), sz(num_vars), sz(num_inputs), sz(num_nz_entries)), "SNARKGens::new")
+
+    def stream(self, which):
+        n = H.spz_snark_gens_stream(self.h, ctypes.c_int(which), None, sz(0))
+        b = (ctypes.c_uint8 * n)()
+        H.spz_snark_gens_stream(self.h, ctypes.c_int(which), b, sz(n))
+        return bytes(b)
+
+    def free(self):
+        if self.h:
+            H.spz_snark_gens_free(self.h); self.h = None
+
+
+class NIZKGens:
+    def __init__(self, ctx, num_cons, num_vars, num_inputs):
+        self.h = _chk(H.spz_nizk_gens_new(ctx.h, sz(num_cons), sz(num_vars), sz(num_inputs)), "NIZKGens::new")
+
+    def free(self):
+        if self.h:
+            H.spz_nizk_gens_free(self.h); self.h = None
+
+
+def seed_scalar(domain, seed):
+    out = (ctypes.c_uint64 * 4)()
+    H.spz_seed_scalar(domain, ctypes.c_uint64(seed), out)
+    return out
+
+
+def _proof_bytes(p):
+    n = H.spz_proof_bytes(p, None, sz(0))
+    b = (ctypes.c_uint8 * n)()
+    H.spz_proof_bytes(p, b, sz(n))
+    H.spz_proof_free(p)
+    return bytes(b)
+
+
+class SNARK:
+    @staticmethod
+    def encode(ctx, inst, gens):
+        return Encoded(_chk(H.spz_snark_encode(ctx.h, inst.h, gens.h), "SNARK::encode"))
+
+    @staticmethod
+    def prove(ctx, inst, enc, vars_, inputs, gens, transcript_label, tape_seed, times=None):
+        tm = (ctypes.c_double * 10)()
+        p = _chk(H.spz_snark_prove(ctx.h, inst.h, gens.h, enc.h, vars_, sz(len(vars_) // 4), inputs, sz(inst.num_inputs), transcript_label,
+                                   tape_seed, tm), "SNARK::prove")
+        if times is not None:
+            times.update(dict(zip(TIME_NAMES, list(tm))))
+        return _proof_bytes(p)
+
+
+class NIZK:
+    @staticmethod
+    def prove(ctx, inst, vars_, inputs, gens, transcript_label, tape_seed, times=None):
+        tm = (ctypes.c_double * 10)()
+        p = _chk(H.spz_nizk_prove(ctx.h, inst.h, gens.h, vars_, sz(len(vars_) // 4), inputs, sz(inst.num_inputs), transcript_label, tape_seed, tm),
+                 "NIZK::prove")
+        if times is not None:
+            times.update(dict(zip(TIME_NAMES, list(tm))))
+        return _proof_bytes(p)
+
+
+class Encoded:
+    def __init__(self, h):
+        self.h = h
+
+    def comm(self, which):
+        n = H.spz_encode_comm(self.h, ctypes.c_int(which), None, sz(0))
+        b = (ctypes.c_uint8 * (32 * n))()
+        H.spz_encode_comm(self.h, ctypes.c_int(which), b, sz(32 * n))
+        return bytes(b)
+
+    def free(self):
+        if self.h:
+            H.spz_encode_free(self.h); self.h = None
+
+
+def smoke_check(orc):
+    """used by __graft_entry__.smoke(): SNARK::prove at 2^6 constraints on cuda:0, bytes compared with the oracle's."""
+    from tests import helpers as Hh
+    s = 6; N = 1 << s
+    ctx = Ctx(0)
+    inst = Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=3)
+    gens = SNARKGens(ctx, N, N, 10, N)
+    enc = SNARK.encode(ctx, inst, gens)
+    seed = seed_scalar(b"tape", 5)
+    got = SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", seed)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(3)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", seed, None))
+    n = orc.orc_proof_bytes(op, None, sz(0)); b = (ctypes.c_uint8 * n)(); orc.orc_proof_bytes(op, b, sz(n))
+    assert got == bytes(b), "SNARK proof bytes differ from the oracle"
+    assert orc.orc_snark_verify(op, oi, og, oe, b"snark_example") == 1
+    enc.free(); gens.free(); inst.free(); ctx.close()

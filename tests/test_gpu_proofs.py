@@ -1,0 +1,117 @@
+"""Whole-proof byte parity: NIZK::prove / SNARK::prove through the HIP path (host driver over the C ABI) against
+the oracle on the same seeded instance and RandomTape seed; the oracle's restated verifier accepts the bytes' source."""
+import ctypes
+import pytest
+from tests.helpers import *
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    from spartan_amd import prover
+    return prover
+
+
+@pytest.fixture(scope="module")
+def ctx(P):
+    c = P.Ctx(0)
+    yield c
+    c.close()
+
+
+def oracle_bytes(orc, p):
+    n = orc.orc_proof_bytes(p, None, sz(0))
+    b = (ctypes.c_uint8 * n)()
+    orc.orc_proof_bytes(p, b, sz(n))
+    return bytes(b)
+
+
+@pytest.mark.parametrize("s,seed", [(1, 0), (2, 1), (4, 2), (7, 3), (10, 4)])
+def test_nizk_prove_bytes_match_oracle(P, ctx, orc, s, seed):
+    N = 1 << s
+    ni = 10 if N > 16 else 1
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, ni, seed=seed)
+    digest = b"digest-%d" % s
+    inst.set_digest(digest)
+    gens = P.NIZKGens(ctx, N, N, ni)
+    tape = P.seed_scalar(b"tape", seed)
+    got = P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(ni), ctypes.c_uint64(seed)))
+    og = vp(orc.orc_nizk_gens_new(sz(N), sz(N), sz(ni)))
+    op = vp(orc.orc_nizk_prove(oi, og, digest, sz(len(digest)), b"nizk_example", tape, None))
+    assert orc.orc_nizk_verify(op, oi, og, digest, sz(len(digest)), b"nizk_example") == 1
+    want = oracle_bytes(orc, op)
+    assert len(got) == len(want)
+    assert got == want
+    orc.orc_proof_free(op); orc.orc_nizk_gens_free(og); orc.orc_instance_free(oi)
+    gens.free(); inst.free()
+
+
+@pytest.mark.parametrize("s,seed", [(1, 0), (3, 1), (5, 2), (8, 3), (11, 4)])
+def test_snark_encode_and_prove_bytes_match_oracle(P, ctx, orc, s, seed):
+    N = 1 << s
+    ni = 10 if N > 16 else 1
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, ni, seed=seed)
+    gens = P.SNARKGens(ctx, N, N, ni, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(ni), ctypes.c_uint64(seed)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(ni), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    for which in (0, 1):  # ComputationCommitment: comm_comb_ops, comm_comb_mem
+        n = orc.orc_encode_comm(oe, ctypes.c_int(which), None, sz(0))
+        b = (ctypes.c_uint8 * (32 * n))()
+        orc.orc_encode_comm(oe, ctypes.c_int(which), b, sz(32 * n))
+        assert enc.comm(which) == bytes(b)
+    tape = P.seed_scalar(b"tape", 100 + seed)
+    times = {}
+    got = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape, times)
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
+    assert orc.orc_snark_verify(op, oi, og, oe, b"snark_example") == 1
+    want = oracle_bytes(orc, op)
+    assert len(got) == len(want)
+    if got != want:
+        first = next(i for i in range(len(got)) if got[i] != want[i])
+        pytest.fail(f"first differing byte at offset {first} of {len(got)}")
+    assert times["total"] > 0
+    orc.orc_proof_free(op); orc.orc_encode_free(oe); orc.orc_snark_gens_free(og); orc.orc_instance_free(oi)
+    enc.free(); gens.free(); inst.free()
+
+
+def test_generator_streams_match_oracle(P, ctx, orc):
+    gens = P.SNARKGens(ctx, 64, 64, 10, 64)
+    sat = gens.stream(0); ev = gens.stream(1)
+    assert sat == gens_bytes(orc, len(sat) // 32 - 1, b"gens_r1cs_sat")
+    assert ev == gens_bytes(orc, len(ev) // 32 - 1, b"gens_r1cs_eval")
+    gens.free()
+
+
+def test_instance_new_matches_synthetic_and_rejects_bad_input(P, ctx, orc):
+    """Instance::new (lib.rs:121-228) fed with the oracle's exported entries gives the same proof as produce_synthetic_r1cs."""
+    s, seed = 5, 9
+    N = 1 << s
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
+    nnz = [orc.orc_instance_nnz(oi, ctypes.c_int(k)) for k in range(3)]
+    tot = sum(nnz)
+    rows = (ctypes.c_uint64 * tot)(); cols = (ctypes.c_uint64 * tot)(); vals = (ctypes.c_uint64 * (4 * tot))()
+    vars_ = (ctypes.c_uint64 * (4 * N))(); inputs = (ctypes.c_uint64 * 40)()
+    orc.orc_instance_export(oi, rows, cols, vals, vars_, inputs)
+    vb = b"".join(int(v).to_bytes(32, "little") for v in from_mont_array(vals, tot))
+    inst = P.Instance.new(ctx, N, N, 10, nnz, rows, cols, vb)
+    inst.set_digest(b"d")
+    ref = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=seed)
+    ref.set_digest(b"d")
+    assert list(ref.vars) == list(vars_)
+    gens = P.NIZKGens(ctx, N, N, 10)
+    tape = P.seed_scalar(b"tape", 1)
+    a = P.NIZK.prove(ctx, inst, vars_, inputs, gens, b"nizk_example", tape)
+    b = P.NIZK.prove(ctx, ref, ref.vars, ref.inputs, gens, b"nizk_example", tape)
+    assert a == b
+    # error paths of Instance::new (lib.rs tests :627-690): InvalidIndex, InvalidScalar
+    bad_rows = (ctypes.c_uint64 * tot)(*rows); bad_rows[0] = N
+    with pytest.raises(P.SpartanHipError, match="InvalidIndex"):
+        P.Instance.new(ctx, N, N, 10, nnz, bad_rows, cols, vb)
+    larger_than_mod = bytes([3, 0, 0, 0, 255, 255, 255, 255, 254, 91, 254, 255, 2, 164, 189, 83, 5, 216, 161, 9, 8, 216, 57, 51, 72, 125, 157, 41, 83, 167, 237, 115])
+    with pytest.raises(P.SpartanHipError, match="InvalidScalar"):
+        P.Instance.new(ctx, N, N, 10, nnz, rows, cols, larger_than_mod + vb[32:])
+    gens.free(); inst.free(); ref.free(); orc.orc_instance_free(oi)

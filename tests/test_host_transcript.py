@@ -1,0 +1,61 @@
+"""CPU tests of the product's host-side Fiat–Shamir layer (spartan_amd/host/transcript.hpp): SHAKE256 vs hashlib,
+Merlin vs the published test vector and vs the oracle on random scripts, RandomTape draws vs the oracle."""
+import ctypes, hashlib, random
+import pytest
+from tests.helpers import *
+
+
+@pytest.fixture(scope="module")
+def H():
+    from spartan_amd import prover
+    return prover.H
+
+
+def test_shake256(H):
+    rng = random.Random(1)
+    for n in (0, 1, 135, 136, 137, 1000):
+        m = bytes(rng.randrange(256) for _ in range(n))
+        out = (ctypes.c_uint8 * 500)()
+        H.spz_shake256(m, sz(n), out, sz(500))
+        assert bytes(out) == hashlib.shake_256(m).digest(500)
+
+
+def _script(lib, fn, tlabel, ops):
+    n = len(ops)
+    kinds = (ctypes.c_int * n)(*[o[0] for o in ops])
+    labels = (ctypes.c_char_p * n)(*[o[1] for o in ops])
+    bufs = [ctypes.create_string_buffer(o[2], max(len(o[2]), 1)) if o[0] != 1 else None for o in ops]
+    datas = (ctypes.POINTER(ctypes.c_uint8) * n)(*[ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)) if b is not None else None for b in bufs])
+    lens = (sz * n)(*[len(o[2]) if o[0] != 1 else o[2] for o in ops])
+    total = sum(o[2] for o in ops if o[0] == 1)
+    out = (ctypes.c_uint8 * max(total, 1))()
+    got = getattr(lib, fn)(tlabel, sz(n), kinds, labels, datas, lens, out)
+    assert got == total
+    return bytes(out)[:total]
+
+
+def test_merlin_kat_and_random_scripts(H, orc):
+    kat = _script(H, "spz_merlin_script", b"test protocol", [(0, b"some label", b"some data"), (1, b"challenge", 32)])
+    assert kat.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    rng = random.Random(2)
+    for trial in range(20):
+        ops = []
+        for _ in range(rng.randrange(1, 40)):
+            k = rng.randrange(3)
+            label = bytes(rng.randrange(97, 123) for _ in range(rng.randrange(1, 20)))
+            if k == 0:
+                ops.append((0, label, bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 32, 165, 166, 167, 400])))))
+            elif k == 1:
+                ops.append((1, label, rng.choice([1, 32, 64, 200])))
+            else:
+                ops.append((2, label, rng.randrange(2**64).to_bytes(8, "little")))
+        ops.append((1, b"final", 64))
+        assert _script(H, "spz_merlin_script", b"proto", ops) == _script(orc, "orc_merlin_script", b"proto", ops)
+
+
+def test_seed_scalar_matches_oracle(H, orc):
+    a = u64x4(); b = u64x4()
+    for seed in (0, 1, 2**63):
+        H.spz_seed_scalar(b"tape", ctypes.c_uint64(seed), a)
+        orc.orc_seed_scalar(b"tape", ctypes.c_uint64(seed), b)
+        assert list(a) == list(b)
