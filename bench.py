@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — R1CS constraints/sec in SNARK::prove on Instance::produce_synthetic_r1cs (BASELINE.json metric).
+
+A "step" is one SNARK::prove (lib.rs:339-420) over a resident synthetic instance: the instance, the generators
+(with their window tables), the computation commitment/decommitment (SNARK::encode) and the witness are built
+before the timed region; the timed region covers everything SNARK::prove does, including the witness H2D copy,
+all transcript work on the host and the D2H of every commitment.
+
+Multi-GPU (--gpus N, launched with torch.distributed.run, one rank per GPU): each rank proves its own
+independent instance (different seed) — proofs are independent units, so there is no data-path collective;
+"scaling": "weak". Timing is bracketed by barrier + synchronize, and the MAX over ranks is used.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse, ctypes, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def dist_setup(n_gpus):
+    """returns (rank, world, dist or None). Reads RANK/WORLD_SIZE/MASTER_* from the env (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1, None
+    import torch.distributed as dist
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo for the CPU tests
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", str(rank))))
+    dist.init_process_group(backend=backend)
+    return rank, world, dist
+
+
+def dist_barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def dist_max(dist, value, device="cpu"):
+    """MAX over ranks of a python float."""
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dist_sum(dist, value, device="cpu"):
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def cpu_baseline(log2_cons, threads=1):
+    """The oracle (CPU restatement of the reference prover, oracle/) timed on this box's host cores on a bounded
+    sample of the same workload: SNARK::prove at 2^log2_cons constraints. Checker-side only; never the product path."""
+    from tests import helpers as H
+    orc = H.load_oracle()
+    N = 1 << log2_cons
+    orc.orc_set_threads(ctypes.c_int(threads))
+    inst = H.vp(orc.orc_instance_synthetic(H.sz(N), H.sz(N), H.sz(10), ctypes.c_uint64(0)))
+    g = H.vp(orc.orc_snark_gens_new(H.sz(N), H.sz(N), H.sz(10), H.sz(N)))
+    e = H.vp(orc.orc_snark_encode(inst, g))
+    seed = (ctypes.c_uint64 * 4)()
+    orc.orc_seed_scalar(b"tape", ctypes.c_uint64(0), seed)
+    t0 = time.time()
+    p = H.vp(orc.orc_snark_prove(inst, g, e, b"snark_example", seed, None))
+    dt = time.time() - t0
+    orc.orc_proof_free(p); orc.orc_encode_free(e); orc.orc_snark_gens_free(g); orc.orc_instance_free(inst)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": N / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": f"oracle SNARK::prove, produce_synthetic_r1cs 2^{log2_cons}, {dt:.2f} s on {threads} thread(s) of {model} ({os.cpu_count()} logical cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2-cons", type=int, default=20, help="log2 of num_cons = num_vars = num_nz_entries (BASELINE: 20)")
+    ap.add_argument("--cpu-log2-cons", type=int, default=15, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="also print the per-phase span times (timer.rs names) to stderr")
+    args = ap.parse_args()
+
+    rank, world, dist = dist_setup(args.gpus)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the prover has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    from spartan_amd import prover as P, capi
+    s = args.log2_cons
+    N = 1 << s
+    ctx = P.Ctx(local_rank)
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=rank)  # profiler/snark.rs:23-31 shape
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape_seed = P.seed_scalar(b"tape", rank)
+
+    def step(times=None):
+        return P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape_seed, times)
+
+    proof = None
+    for _ in range(args.warmup):
+        proof = step()
+    raw = ctx.raw()
+    capi.lib.sp_prof_reset(raw)
+    capi.lib.sp_prof_enable(raw, ctypes.c_int(1))  # HIP events on the library's own stream, inside the timed region
+    dist_barrier(dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    phase = {}
+    for _ in range(args.steps):
+        p2 = step(phase)
+        if proof is not None and p2 != proof:
+            raise SystemExit("non-deterministic proof bytes")
+        proof = p2
+    torch.cuda.synchronize()
+    dist_barrier(dist)
+    dt = time.perf_counter() - t0
+    dt = dist_max(dist, dt, dev if dist is not None and dist.get_backend() == "nccl" else "cpu")
+    capi.lib.sp_prof_enable(raw, ctypes.c_int(0))
+
+    # per-kernel-family HIP-event totals -> dominant kernel roofline
+    cap = 64
+    names = (ctypes.c_char_p * cap)(); ms = (ctypes.c_double * cap)(); nl = (ctypes.c_uint64 * cap)(); by = (ctypes.c_double * cap)()
+    k = capi.lib.sp_prof_read(raw, names, ms, nl, by, ctypes.c_int(cap))
+    fam = {names[i].decode(): {"ms": ms[i], "launches": int(nl[i]), "alg_bytes": by[i]} for i in range(k) if nl[i]}
+    dom = max(fam, key=lambda n: fam[n]["ms"]) if fam else None
+    roofline = None
+    if dom:
+        f = fam[dom]
+        avg_ms = f["ms"] / f["launches"]
+        ach = (f["alg_bytes"] / f["launches"]) / (avg_ms * 1e-3) / 1e9
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom)
+        except (OSError, ValueError):
+            pass
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+                    "traffic": pmc, "avg_launch_ms": round(avg_ms, 5), "launches_per_step": f["launches"] / args.steps,
+                    "alg_bytes_per_launch": f["alg_bytes"] / f["launches"],
+                    "note": "255-bit EC / 253-bit field integer work: VALU-bound by construction, HBM fraction is reported as the contract asks (DESIGN.md §roofline)"}
+
+    if rank == 0:
+        gpu_ms_total = sum(v["ms"] for v in fam.values()) / args.steps
+        out = {
+            "metric": "R1CS constraints/sec in SNARK::prove (synthetic 2^%d); bit-exact proof" % s,
+            "value": world * N * args.steps / dt,
+            "unit": "constraints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64x4 (F_q Montgomery / F_p 2^255-19 limbs)",
+            "data": "synthetic",
+            "config": {"workload": f"SNARK::prove, Instance::produce_synthetic_r1cs(2^{s}, 2^{s}, 10), nnz 2^{s} per matrix; MSM + sum-checks + IPA + SPARK on GPU",
+                       "proof_bytes": len(proof), "parallelism": "1 proof per GPU, %d independent proofs" % world},
+            "roofline": roofline,
+            "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 4) for n, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            "gpu_busy_ms_per_step": round(gpu_ms_total, 3),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log2_cons)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if args.phases:
+            print("phases (s):", json.dumps({k_: round(v, 5) for k_, v in phase.items()}), file=sys.stderr)
+        print(json.dumps(out))
+    enc.free(); gens.free(); inst.free(); ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
