@@ -14,6 +14,32 @@ int32_t ensure(void** p, size_t* cap, size_t need) {
   *cap = want;
   return SP_OK;
 }
+static size_t pool_class(size_t bytes) {
+  size_t k = 4096;
+  while (k < bytes) k <<= 1;
+  return k;
+}
+int32_t pool_alloc(sp_ctx* c, size_t bytes, void** out) {
+  size_t k = pool_class(bytes);
+  auto it = c->pool.find(k);
+  if (it != c->pool.end() && !it->second.empty()) {
+    *out = it->second.back();
+    it->second.pop_back();
+    return SP_OK;
+  }
+  hipError_t e = hipMalloc(out, k);
+  if (e != hipSuccess) {  // give cached buffers back to the driver and retry once
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool) { for (void* p : kv.second) (void)hipFree(p); kv.second.clear(); }
+    e = hipMalloc(out, k);
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP;
+  }
+  c->pool_bytes += k;
+  return SP_OK;
+}
+void pool_release(sp_ctx* c, void* p, size_t bytes) {
+  if (p) c->pool[pool_class(bytes)].push_back(p);
+}
 int32_t ensure_pinned(sp_ctx* c, size_t need) {
   if (c->pinned_cap >= need) return SP_OK;
   HIPCHK(hipStreamSynchronize(c->stream));  // an async copy may still read the old buffer
@@ -45,6 +71,26 @@ int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes) {
   HIPCHK(hipMemcpyAsync((uint8_t*)c->dstage + off, c->pinned + off, bytes, hipMemcpyHostToDevice, c->stream));
   return SP_OK;
 }
+void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes) {
+  memcpy(c->hmap + off, src, bytes);
+  return c->hmap + off;
+}
+int32_t sync_spin(sp_ctx* c) {
+  HIPCHK(hipEventRecord(c->sync_ev, c->stream));
+  for (;;) {
+    hipError_t e = hipEventQuery(c->sync_ev);
+    if (e == hipSuccess) return SP_OK;
+    if (e != hipErrorNotReady) {
+      fprintf(stderr, "spartan_hip: hipEventQuery failed: %s\n", hipGetErrorString(e));
+      return SP_EHIP;
+    }
+  }
+}
+int32_t fetch_small(sp_ctx* c, void* hdst, size_t bytes) {
+  SPCHK(sync_spin(c));
+  memcpy(hdst, hres(c), bytes);
+  return SP_OK;
+}
 int32_t ensure_dstage(sp_ctx* c, size_t need) {
   if (c->dstage_cap >= need) return SP_OK;
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -54,7 +100,7 @@ int32_t ensure_dstage(sp_ctx* c, size_t need) {
 int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes) {
   SPCHK(ensure_pinned(c, bytes));
   HIPCHK(hipMemcpyAsync(c->pinned, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SPCHK(sync_spin(c));
   memcpy(hdst, c->pinned, bytes);
   return SP_OK;
 }
@@ -123,6 +169,55 @@ __global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size
   if (blinds && s == 0) msm_accumulate(acc, ld_fq(blinds + row), table, h_idx);
   partial[row * nstrips + s] = acc;
 }
+// Latency-bound shapes (Sigma-protocol commits, IPA rounds, single-row commits): one thread per (row, column,
+// window) performs a single table lookup, so the serial chain per thread is one mixed addition instead of 32.
+// partial[row][w*cols + j].  The blind, if any, is column `cols` (generator h_idx).
+__global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols,
+                                                     const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
+                                                     const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial) {
+  size_t ncol = cols + (blinds ? 1 : 0);
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * ncol * MSM_NWIN) return;
+  size_t row = t % rows, rest = t / rows;
+  size_t j = rest % ncol;
+  int w = (int)(rest / ncol);
+  Fq sc = j < cols ? ld_fq(Z + row * z_row_stride + j) : ld_fq(blinds + row);
+  size_t pt = j < cols ? (idx ? (size_t)idx[j] : g_off + j) : h_idx;
+  Pt acc = pt_identity();
+  if (!fq_is_zero(sc)) {
+    Fq s = fq_from_mont(sc);
+    int carry = 0, d = 0;
+    for (int k = 0; k <= w; k++) {  // signed recoding: the carry into window w depends on all lower windows
+      d = (int)((s.l[k >> 3] >> ((k & 7) * 8)) & 0xff) + carry;
+      carry = d > 127;
+      d -= carry << 8;
+    }
+    if (d != 0) acc = pt_madd(acc, table[msm_tidx(pt, w, d < 0 ? -d : d)], d < 0);
+  }
+  partial[row * (ncol * MSM_NWIN) + (size_t)w * ncol + j] = acc;
+}
+// reduction pass: grid (rows, nchunks); block sums `chunk` consecutive partials of its row into one point.
+__global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt* __restrict__ out) {
+  __shared__ Pt sm[256];
+  size_t row = blockIdx.x, ck = blockIdx.y, nchunks = gridDim.y;
+  int t = threadIdx.x;
+  size_t lo = ck * chunk, hi = lo + chunk;
+  if (hi > P) hi = P;
+  Pt acc = pt_identity();
+  bool any = false;
+  for (size_t s = lo + t; s < hi; s += 256) {
+    Pt p = in[row * P + s];
+    acc = any ? pt_add(acc, p) : p;
+    any = true;
+  }
+  sm[t] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) sm[t] = pt_add(sm[t], sm[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) out[row * nchunks + ck] = sm[0];
+}
 // one block per row: sum the row's strip partials, compress.
 __global__ void __launch_bounds__(256) k_msm_reduce(const Pt* __restrict__ partial, size_t nstrips, uint8_t* __restrict__ out) {
   __shared__ Pt sm[256];
@@ -180,11 +275,15 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   c->scratch_cap = c->scratch2_cap = c->dstage_cap = 0;
   c->pinned = nullptr;
   c->pinned_cap = 0;
+  c->hmap = nullptr;
   c->prof_on = 0;
+  c->pool_bytes = 0;
   memset(c->prof_ms, 0, sizeof c->prof_ms);
   memset(c->prof_n, 0, sizeof c->prof_n);
   memset(c->prof_bytes, 0, sizeof c->prof_bytes);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipHostMalloc((void**)&c->hmap, HMAP_SIZE, hipHostMallocDefault));
+  HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
   *out = c;
   return SP_OK;
 }
@@ -193,10 +292,14 @@ void sp_ctx_destroy(sp_ctx* c) {
   (void)hipSetDevice(c->dev);
   prof_drain(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
+  for (auto& kv : c->pool)
+    for (void* p : kv.second) (void)hipFree(p);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->scratch2) (void)hipFree(c->scratch2);
   if (c->dstage) (void)hipFree(c->dstage);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->hmap) (void)hipHostFree(c->hmap);
+  (void)hipEventDestroy(c->sync_ev);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -280,28 +383,52 @@ void sp_gens_free(sp_gens* g) {
 
 // core: Z on device (row stride in elements), optional idx (device), optional blinds (device)
 int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                          const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
   size_t total = rows * cols;
-  size_t strip = total / 131072;
-  if (strip < 1) strip = 1;
-  if (strip > cols) strip = cols;
-  size_t nstrips = (cols + strip - 1) / strip;
-  size_t part_bytes = rows * nstrips * sizeof(Pt);
-  size_t off_out = (part_bytes + 255) & ~(size_t)255;
-  SPCHK(ensure(&c->scratch, &c->scratch_cap, off_out + 32 * rows));
+  size_t ncol = cols + (dblinds ? 1 : 0);
+  bool windowed = rows * ncol * MSM_NWIN <= ((size_t)1 << 19);  // latency-bound shapes: one addition per thread
+  size_t strip = 1, nstrips = 0, P;
+  if (windowed) {
+    P = ncol * MSM_NWIN;
+  } else {
+    strip = total / 131072;
+    if (strip < 1) strip = 1;
+    if (strip > cols) strip = cols;
+    nstrips = (cols + strip - 1) / strip;
+    P = nstrips;
+  }
+  size_t chunk = 1024, nchunks = (P + chunk - 1) / chunk;
+  bool two_pass = P > 2048;
+  size_t part_bytes = (rows * P * sizeof(Pt) + 255) & ~(size_t)255;
+  size_t part2_bytes = two_pass ? ((rows * nchunks * sizeof(Pt) + 255) & ~(size_t)255) : 0;
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, part_bytes + part2_bytes + 32 * rows));
   Pt* partial = (Pt*)c->scratch;
-  uint8_t* dout = (uint8_t*)c->scratch + off_out;
-  size_t nthreads = rows * nstrips;
+  Pt* partial2 = (Pt*)((uint8_t*)c->scratch + part_bytes);
+  bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
+  uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + part_bytes + part2_bytes;
   {
     ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
-    hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols, strip, nstrips,
-                       (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
+    if (windowed) {
+      size_t nthreads = rows * P;
+      hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols,
+                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
+    } else {
+      size_t nthreads = rows * nstrips;
+      hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols, strip, nstrips,
+                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
+    }
   }
   {
-    ProfScope ps(c, PF_MSM_REDUCE, (double)part_bytes);
-    hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)rows), dim3(256), 0, c->stream, (const Pt*)partial, nstrips, dout);
+    ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * P * sizeof(Pt)));
+    if (two_pass) {
+      hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)nchunks), dim3(256), 0, c->stream, (const Pt*)partial, P, chunk, partial2);
+      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)rows), dim3(256), 0, c->stream, (const Pt*)partial2, nchunks, dout);
+    } else {
+      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)rows), dim3(256), 0, c->stream, (const Pt*)partial, P, dout);
+    }
   }
-  SPCHK(fetch_out(c, dout, out_host, 32 * rows));
+  if (small_out) SPCHK(fetch_small(c, out_host, 32 * rows));
+  else SPCHK(fetch_out(c, dout, out_host, 32 * rows));
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
   return SP_OK;
 }
@@ -341,6 +468,11 @@ int32_t sp_msm_indexed(sp_ctx* c, const sp_gens* g, const uint32_t* idx, size_t 
     if (idx[j] >= g->n) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   size_t sb = 32 * rows * cols, ib = (4 * cols + 31) & ~(size_t)31;
+  if (sb + ib <= HMAP_IN) {  // Sigma-protocol sized: the kernel reads scalars and indices straight from the host-mapped page
+    const Fq* ds = (const Fq*)stage_small(c, 0, S, sb);
+    const uint32_t* di = (const uint32_t*)stage_small(c, sb, idx, 4 * cols);
+    return msm_launch(c, g, ds, cols, rows, cols, 0, di, nullptr, 0, out);
+  }
   SPCHK(ensure_dstage(c, sb + ib));
   SPCHK(stage_in(c, 0, S, sb));
   SPCHK(stage_in(c, sb, idx, 4 * cols));
@@ -348,7 +480,7 @@ int32_t sp_msm_indexed(sp_ctx* c, const sp_gens* g, const uint32_t* idx, size_t 
 }
 
 // ---- tables
-int32_t sp_table_alloc(sp_ctx* c, size_t len, sp_table** out) {
+int32_t table_new(sp_ctx* c, size_t len, bool zero, sp_table** out) {
   if (!c || !out || len == 0) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   sp_table* t = new (std::nothrow) sp_table();
@@ -357,13 +489,13 @@ int32_t sp_table_alloc(sp_ctx* c, size_t len, sp_table** out) {
   t->cap = t->len = len;
   t->owner = 1;
   t->d = nullptr;
-  hipError_t e = hipMalloc((void**)&t->d, 32 * len);
-  if (e != hipSuccess) { delete t; return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP; }
-  e = hipMemsetAsync(t->d, 0, 32 * len, c->stream);
-  if (e != hipSuccess) { (void)hipFree(t->d); delete t; return SP_EHIP; }
+  int32_t rc = pool_alloc(c, 32 * len, (void**)&t->d);
+  if (rc != SP_OK) { delete t; return rc; }
+  if (zero && hipMemsetAsync(t->d, 0, 32 * len, c->stream) != hipSuccess) { pool_release(c, t->d, 32 * len); delete t; return SP_EHIP; }
   *out = t;
   return SP_OK;
 }
+int32_t sp_table_alloc(sp_ctx* c, size_t len, sp_table** out) { return table_new(c, len, true, out); }
 int32_t sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* Z, size_t len) {
   if (!c || !t || !Z || off + len > t->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
@@ -373,7 +505,7 @@ int32_t sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* Z, si
 }
 int32_t sp_table_upload(sp_ctx* c, const uint64_t* Z, size_t len, sp_table** out) {
   if (!Z) return SP_EINVAL;
-  SPCHK(sp_table_alloc(c, len, out));
+  SPCHK(table_new(c, len, false, out));
   int32_t rc = sp_table_write(c, *out, 0, Z, len);
   if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; }
   return rc;
@@ -387,7 +519,7 @@ int32_t sp_table_download(sp_ctx* c, const sp_table* t, size_t off, size_t len, 
 }
 int32_t sp_table_clone(sp_ctx* c, const sp_table* t, sp_table** out) {
   if (!t) return SP_EINVAL;
-  SPCHK(sp_table_alloc(c, t->cap, out));
+  SPCHK(table_new(c, t->cap, false, out));
   (*out)->len = t->len;
   HIPCHK(hipMemcpyAsync((*out)->d, t->d, 32 * t->cap, hipMemcpyDeviceToDevice, c->stream));
   return SP_OK;
@@ -402,10 +534,7 @@ size_t sp_table_len(const sp_table* t) { return t ? t->len : 0; }
 void sp_table_free(sp_table* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->dev);
-  if (t->owner) {
-    (void)hipStreamSynchronize(t->ctx->stream);
-    (void)hipFree(t->d);
-  }
+  if (t->owner) pool_release(t->ctx, t->d, 32 * t->cap);
   delete t;
 }
 

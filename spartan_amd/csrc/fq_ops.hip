@@ -176,12 +176,11 @@ __global__ void k_gather_heads(Tabs4 T, int ntabs, Fq* __restrict__ out) {
 
 
 int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out) {
-  Fq* dres = partials + nblk * K;
-  {
+  if (partials != (Fq*)hres(c)) {  // nblk == 1 kernels write their sums into the result area themselves
     ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * K));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, dres);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, (Fq*)hres(c));
   }
-  SPCHK(fetch_out(c, dres, out, 32 * K));
+  SPCHK(fetch_small(c, out, 32 * K));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
@@ -190,17 +189,16 @@ extern "C" {
 int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   if (!c || !r || !out || ell == 0 || ell > 40) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  SPCHK(ensure_dstage(c, 32 * ell));
-  SPCHK(stage_in(c, 0, r, 32 * ell));
+  const Fq* dr = (const Fq*)stage_small(c, 0, r, 32 * ell);
   size_t len = (size_t)1 << ell;
-  SPCHK(sp_table_alloc(c, len, out));
+  SPCHK(table_new(c, len, false, out));
   int lowb = ell < (size_t)EQ_LOWB ? (int)ell : EQ_LOWB;
   size_t nthreads = len >> lowb;
   {
     ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
-    hipLaunchKernelGGL(k_eq_expand, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, (const Fq*)c->dstage, ell, lowb, (*out)->d);
+    hipLaunchKernelGGL(k_eq_expand, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dr, ell, lowb, (*out)->d);
   }
-  HIPCHK(hipStreamSynchronize(c->stream));  // dstage reusable
+  SPCHK(sync_spin(c));  // the host-mapped input page is reusable
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
@@ -222,9 +220,9 @@ int32_t sp_sumcheck_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntab
   size_t len;
   SPCHK(tabs_check(c, tabs, ntabs, kind == 0 ? 2 : (kind == 1 ? 3 : 4), &T, &len));
   HIPCHK(hipSetDevice(c->dev));
-  size_t half = len / 2, nblk = grid_for(half, 1024);
+  size_t half = len / 2, nblk = half <= 256 ? 1 : grid_for(half, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_EVAL, 32.0 * (double)len * (double)ntabs);
     if (kind == 0) hipLaunchKernelGGL(k_sc_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
@@ -270,9 +268,9 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   HIPCHK(hipSetDevice(c->dev));
   Fq rr;
   memcpy(rr.l, r, 32);
-  size_t quarter = len / 4, nblk = grid_for(quarter, 1024);
+  size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
     if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -323,22 +321,21 @@ int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, si
 int32_t sp_evaluate(sp_ctx* c, const sp_table* Z, const uint64_t* r, size_t ell, uint64_t out[4]) {
   if (!c || !Z || !r || !out || ell == 0 || ell > 40 || Z->len != ((size_t)1 << ell)) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  SPCHK(ensure_dstage(c, 32 * ell));
-  SPCHK(stage_in(c, 0, r, 32 * ell));
+  const Fq* dr = (const Fq*)stage_small(c, 0, r, 32 * ell);
   int lowb = ell < (size_t)EQ_LOWB ? (int)ell : EQ_LOWB;
   size_t nthreads = Z->len >> lowb, nblk = grid_for(nthreads, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
   Fq* partials = (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_DOT, 32.0 * (double)Z->len);
-    hipLaunchKernelGGL(k_evaluate, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)Z->d, (const Fq*)c->dstage, ell, lowb, partials);
+    hipLaunchKernelGGL(k_evaluate, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)Z->d, dr, ell, lowb, partials);
   }
   return reduce_and_fetch(c, partials, nblk, 1, out);
 }
 int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t* out) {
   if (!c || !tabs || !out || ntabs == 0) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 4));
+  if (32 * ntabs > HMAP_SIZE - HMAP_IN) return SP_EINVAL;
   for (size_t k0 = 0; k0 < ntabs; k0 += 4) {
     size_t nk = ntabs - k0 < 4 ? ntabs - k0 : 4;
     Tabs4 T = {{nullptr, nullptr, nullptr, nullptr}};
@@ -346,9 +343,9 @@ int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t*
       if (!tabs[k0 + k]) return SP_EINVAL;
       T.p[k] = tabs[k0 + k]->d;
     }
-    hipLaunchKernelGGL(k_gather_heads, dim3(1), dim3(64), 0, c->stream, T, (int)nk, (Fq*)c->scratch);
-    SPCHK(fetch_out(c, c->scratch, out + 4 * k0, 32 * nk));
+    hipLaunchKernelGGL(k_gather_heads, dim3(1), dim3(64), 0, c->stream, T, (int)nk, (Fq*)hres(c) + k0);
   }
+  SPCHK(fetch_small(c, out, 32 * ntabs));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 

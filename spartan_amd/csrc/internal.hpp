@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
 #include <vector>
 
 #include "../../include/spartan_hip.h"
@@ -50,8 +51,14 @@ struct sp_ctx {
   size_t scratch2_cap;
   uint8_t* pinned;  // host pinned staging
   size_t pinned_cap;
-  void* dstage;  // device staging for small host inputs
+  void* dstage;  // device staging for host inputs copied by DMA
   size_t dstage_cap;
+  hipEvent_t sync_ev;  // completion is polled (hipEventQuery spin): lower wake-up latency than a blocking stream sync
+  uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
+
+  // size-class pool of device buffers: per-proof tables are recycled instead of hipMalloc/hipFree'd
+  std::map<size_t, std::vector<void*>> pool;
+  size_t pool_bytes;
   // profiling
   int prof_on;
   std::vector<ProfRec> pending;
@@ -118,11 +125,21 @@ struct ProfScope {
 
 
 int32_t ensure(void** p, size_t* cap, size_t need);
+// stream-ordered pool: a buffer released here may be handed out again to a later call on the same stream
+int32_t pool_alloc(sp_ctx* c, size_t bytes, void** out);
+void pool_release(sp_ctx* c, void* p, size_t bytes);
+extern "C" int32_t table_new(sp_ctx* c, size_t len, bool zero, sp_table** out);
 int32_t ensure_pinned(sp_ctx* c, size_t need);
 void prof_drain(sp_ctx* c);
 int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes);   // host -> c->dstage (+off), async
 int32_t ensure_dstage(sp_ctx* c, size_t need);
 int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes);  // device -> host, synchronous
+// host-mapped page layout: [0, HMAP_IN) kernel inputs, [HMAP_IN, HMAP_SIZE) kernel results
+constexpr size_t HMAP_IN = 32768, HMAP_SIZE = 65536;
+void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes);  // returns the device-visible address; bytes+off <= HMAP_IN
+static inline uint8_t* hres(sp_ctx* c) { return c->hmap + HMAP_IN; }
+int32_t fetch_small(sp_ctx* c, void* hdst, size_t bytes);
+int32_t sync_spin(sp_ctx* c);  // wait for everything queued on the context stream                 // stream sync + copy out of the result area
 int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out);
 // fixed-base MSM core: Z on device (row stride in elements), optional idx / blinds (device); out on host, synchronous
 extern "C" int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,

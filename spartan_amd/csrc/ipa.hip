@@ -10,6 +10,7 @@ struct sp_ipa {
   Fq q_scale;
   Fq *a, *b, *s, *s2, *rows;  // device: a[n0], b[n0], s[n0], s2[n0], rows[2][n0+2]
   uint32_t* idx;              // device: n0+2 generator indices
+  size_t bytes;
 };
 
 // single block. rows[0] = scalars of L, rows[1] = scalars of R over (G[0..n0), Qbase, H).
@@ -74,9 +75,7 @@ extern "C" {
 
 void sp_ipa_free(sp_ipa* ipa) {
   if (!ipa) return;
-  (void)hipSetDevice(ipa->ctx->dev);
-  (void)hipStreamSynchronize(ipa->ctx->stream);
-  if (ipa->a) (void)hipFree(ipa->a);  // one allocation backs a, b, s, s2, rows, idx
+  pool_release(ipa->ctx, ipa->a, ipa->bytes);  // one allocation backs a, b, s, s2, rows, idx
   delete ipa;
 }
 int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
@@ -89,8 +88,10 @@ int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t
   ipa->q_scale = limbs(q_scale);
   size_t fq_count = 4 * n + 2 * (n + 2);
   uint8_t* base = nullptr;
-  hipError_t e = hipMalloc((void**)&base, 32 * fq_count + 4 * (n + 2));
-  if (e != hipSuccess) { delete ipa; return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP; }
+  ipa->bytes = 32 * fq_count + 4 * (n + 2);
+  ipa->a = nullptr;
+  int32_t prc = pool_alloc(c, ipa->bytes, (void**)&base);
+  if (prc != SP_OK) { delete ipa; return prc; }
   ipa->a = (Fq*)base; ipa->b = ipa->a + n; ipa->s = ipa->b + n; ipa->s2 = ipa->s + n; ipa->rows = ipa->s2 + n;
   ipa->idx = (uint32_t*)(ipa->rows + 2 * (n + 2));
   std::vector<uint32_t> idx(n + 2);
@@ -98,9 +99,11 @@ int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t
   idx[n] = (uint32_t)q_idx;
   idx[n + 1] = (uint32_t)h_idx;
   Fq one = fq_one();
-  if (hipMemcpy(ipa->a, a, 32 * n, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(ipa->b, b, 32 * n, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(ipa->s, &one, 32, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemcpyAsync(ipa->a, a, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(ipa->b, b, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(ipa->s, &one, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
     sp_ipa_free(ipa);
     return SP_EHIP;
   }

@@ -200,18 +200,16 @@ static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, 
     T[k] = Triple{A[k]->d, B[k]->d, C[k]->d};
   }
   if (len < 2 || !is_pow2(len)) return SP_EINVAL;
-  SPCHK(ensure_dstage(c, sizeof(Triple) * ninst));
-  SPCHK(stage_in(c, 0, T.data(), sizeof(Triple) * ninst));
+  stage_small(c, 0, T.data(), sizeof(Triple) * ninst);
   *len_out = len;
   return SP_OK;
 }
 static int32_t batched_finish(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out) {
-  Fq* dres = partials + ninst * nblk * 3;
-  {
+  if (partials != (Fq*)hres(c)) {
     ProfScope ps(c, PF_REDUCE, 96.0 * (double)(nblk * ninst));
-    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, dres);
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c));
   }
-  SPCHK(fetch_out(c, dres, out, 96 * ninst));
+  SPCHK(fetch_small(c, out, 96 * ninst));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out) {
@@ -219,12 +217,12 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   size_t len;
   HIPCHK(hipSetDevice(c ? c->dev : 0));
   SPCHK(batched_setup(c, A, B, C, ninst, &len));
-  size_t half = len / 2, nblk = grid_for(half, 256);
+  size_t half = len / 2, nblk = half <= 256 ? 1 : grid_for(half, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst);
-    hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->dstage, half, partials);
+    hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
   }
   return batched_finish(c, partials, nblk, ninst, out);
 }
@@ -235,12 +233,12 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   HIPCHK(hipSetDevice(c ? c->dev : 0));
   SPCHK(batched_setup(c, A, B, C, ninst, &len));
   if (len < 4) return SP_EINVAL;
-  size_t quarter = len / 4, nblk = grid_for(quarter, 256);
+  size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst);
-    hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->dstage, quarter,
+    hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
                        limbs(r), partials);
   }
   // A_k and B_k are now bound (distinct tables assumed for A and B)
@@ -256,21 +254,19 @@ int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_
     ptrs[k] = tabs[k]->d;
   }
   HIPCHK(hipSetDevice(c->dev));
-  SPCHK(ensure_dstage(c, 8 * nt));
-  SPCHK(stage_in(c, 0, ptrs.data(), 8 * nt));
+  stage_small(c, 0, ptrs.data(), 8 * nt);
   size_t nblk = grid_for(n, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1) * nt));
   Fq* partials = (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_DOT, 32.0 * (double)n * (double)(nt + 1));
-    hipLaunchKernelGGL(k_dot_many, dim3((unsigned)nblk, (unsigned)nt), dim3(256), 0, c->stream, (const Fq*)chi->d, (Fq* const*)c->dstage, n, partials);
+    hipLaunchKernelGGL(k_dot_many, dim3((unsigned)nblk, (unsigned)nt), dim3(256), 0, c->stream, (const Fq*)chi->d, (Fq* const*)c->hmap, n, partials);
   }
-  Fq* dres = partials + nt * nblk;
   {
     ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * nt));
-    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, dres);
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, (Fq*)hres(c));
   }
-  SPCHK(fetch_out(c, dres, out, 32 * nt));
+  SPCHK(fetch_small(c, out, 32 * nt));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_dot3(sp_ctx* c, const sp_table* l, const sp_table* r, const sp_table* w, size_t off, size_t n, uint64_t out[4]) {

@@ -111,7 +111,7 @@ void sp_sparse_free(sp_sparse* m) {
 int32_t sp_sparse_mulvec(sp_ctx* c, const sp_sparse* m, const sp_table* z, sp_table** out) {
   if (!c || !m || !z || !out || z->len < m->num_cols) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  SPCHK(sp_table_alloc(c, m->num_rows, out));
+  SPCHK(table_new(c, m->num_rows, false, out));
   {
     ProfScope ps(c, PF_SPARSE, (double)m->nnz * (4 + 32 + 32) + 32.0 * (double)m->num_rows);
     hipLaunchKernelGGL(k_spmv, dim3((unsigned)((m->num_rows + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)m->row_ptr,
@@ -133,7 +133,7 @@ int32_t sp_sparse_eval_table(sp_ctx* c, const sp_sparse* const* ms, const uint64
   }
   HIPCHK(hipSetDevice(c->dev));
   size_t nc = ms[0]->num_cols;
-  SPCHK(sp_table_alloc(c, nc, out));
+  SPCHK(table_new(c, nc, false, out));
   {
     ProfScope ps(c, PF_SPARSE, bytes + 32.0 * (double)nc);
     hipLaunchKernelGGL(k_eval_table, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, M, (const Fq*)rx->d, nc, (*out)->d);

@@ -382,36 +382,50 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
   FqVec blinds_poly = tape.random_vector("blinds_poly", num_rounds);
   FqVec blinds_evals = tape.random_vector("blinds_evals", num_rounds);
   Fq claim_per_round = claim;
-  CP comm_claim_per_round = commit_scalar(c, claim_per_round, blind_claim, g1);
   ZKSumcheckInstanceProof out;
   FqVec r;
-  std::vector<uint32_t> idx_n = gn.G;
-  idx_n.push_back(gn.h);
-  // union index list for the per-round Sigma commitments: (gn.G..., gn.h, g1.G, g1.h)
-  std::vector<uint32_t> idx_u = idx_n;
+  // One generator index list serves every commitment of a round: (gn.G..., gn.h, g1.G, g1.h). Commitments that
+  // do not depend on each other are computed as rows of one launch; each round needs two launches.
+  std::vector<uint32_t> idx_u = gn.G;
+  idx_u.push_back(gn.h);
   idx_u.push_back(g1.G[0]);
   idx_u.push_back(g1.h);
   size_t nn = gn.n(), W = idx_u.size();
-  uint64_t ev[12];
-  SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev));
-  for (size_t j = 0; j < num_rounds; j++) {
+  auto make_poly = [&](const uint64_t* ev, const Fq& cl) {
     Fq e0, e2, e3;
     memcpy(e0.l, ev, 32); memcpy(e2.l, ev + 4, 32); memcpy(e3.l, ev + 8, 32);
-    UniPoly poly = kind == 0 ? UniPoly::from_evals({e0, claim_per_round - e0, e2}) : UniPoly::from_evals({e0, claim_per_round - e0, e2, e3});
-    REQUIRE(poly.coeffs.size() == nn);
-    CP comm_poly = commit_vec(c, poly.coeffs, blinds_poly[j], gn);  // sumcheck.rs:473 / 661
+    return kind == 0 ? UniPoly::from_evals({e0, cl - e0, e2}) : UniPoly::from_evals({e0, cl - e0, e2, e3});
+  };
+  auto poly_row = [&](FqVec& rows, size_t row, const UniPoly& poly, const Fq& blind) {
+    for (size_t k = 0; k < nn; k++) rows[row * W + k] = poly.coeffs[k];
+    rows[row * W + nn] = blind;
+  };
+  uint64_t ev[12];
+  SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev));
+  UniPoly poly = make_poly(ev, claim_per_round);
+  REQUIRE(poly.coeffs.size() == nn);
+  CP comm_claim_per_round, comm_poly;
+  {  // comm_claim_per_round (sumcheck.rs:448 / 611) and the first comm_poly (:473 / 661)
+    FqVec rows0(2 * W, fq_zero());
+    rows0[nn + 1] = claim_per_round; rows0[nn + 2] = blind_claim;
+    poly_row(rows0, 1, poly, blinds_poly[0]);
+    std::vector<CP> cm = msm_rows(c, gn.g, idx_u, rows0, 2);
+    comm_claim_per_round = cm[0];
+    comm_poly = cm[1];
+  }
+  for (size_t j = 0; j < num_rounds; j++) {
     t.append_point("comm_poly", comm_poly.data());
     out.comm_polys.push_back(comm_poly);
     Fq r_j = t.challenge_scalar("challenge_nextround");
     // bind every table at r_j (sumcheck.rs:485-486 / 673-676); fused with the next round's evaluation
+    bool more = j + 1 < num_rounds;
     if (sp_table_len(tabs[0]) >= 4) SPX(sp_sumcheck_bind_eval(c, kind, tabs.data(), tabs.size(), U(r_j), ev));
     else SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
     // ---- round tail (sumcheck.rs:491-583 / 681-772)
     Fq eval = poly.evaluate(r_j);
-    // dot product proof randomness (nizk/mod.rs:330-332)
-    FqVec d = tape.random_vector("d_vec", nn);
+    FqVec d = tape.random_vector("d_vec", nn);  // DotProductProof randomness (nizk/mod.rs:330-332)
     Fq r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_beta");
-    // batch 1: comm_eval = eval*G1 + blinds_evals[j]*h1 ; delta = <d, Gn> + r_delta*hn
+    // launch 1: comm_eval = eval*G1 + blinds_evals[j]*h ; delta = <d, Gn> + r_delta*hn
     FqVec rows1(2 * W, fq_zero());
     rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
     for (size_t k = 0; k < nn; k++) rows1[W + k] = d[k];
@@ -433,11 +447,20 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     }
     // DotProductProof::prove (nizk/mod.rs:311-370): x = poly.coeffs, blind_x = blinds_poly[j], y = target, blind_y = blind
     t.append_protocol_name("dot product proof");
-    // Cx = commit(x, blind_x) is the same group element as comm_poly (same inputs, same generators)
-    t.append_point("Cx", comm_poly.data());
+    t.append_point("Cx", comm_poly.data());  // Cx = commit(x, blind_x): same inputs and generators as comm_poly
     Fq dp = dot_host(a, d);
-    // batch 2: Cy = target*G1 + blind*h1 ; beta = dp*G1 + r_beta*h1
-    std::vector<CP> cm2 = msm_rows(c, g1.g, {g1.G[0], g1.h}, {target, blind, dp, r_beta}, 2);
+    // launch 2: Cy = target*G1 + blind*h ; beta = dp*G1 + r_beta*h ; and the next round's comm_poly (its inputs,
+    // the next evaluations and claim = eval, are already known)
+    UniPoly next_poly;
+    size_t nrows2 = more ? 3 : 2;
+    FqVec rows2(nrows2 * W, fq_zero());
+    rows2[nn + 1] = target; rows2[nn + 2] = blind;
+    rows2[W + nn + 1] = dp; rows2[W + nn + 2] = r_beta;
+    if (more) {
+      next_poly = make_poly(ev, eval);
+      poly_row(rows2, 2, next_poly, blinds_poly[j + 1]);
+    }
+    std::vector<CP> cm2 = msm_rows(c, gn.g, idx_u, rows2, nrows2);
     t.append_point("Cy", cm2[0].data());
     t.append_scalars("a", a);
     t.append_point("delta", delta.data());
@@ -454,6 +477,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     out.proofs.push_back(dpp);
     out.comm_evals.push_back(comm_eval);
     r.push_back(r_j);
+    if (more) { poly = next_poly; comm_poly = cm2[2]; }
   }
   final_claims->resize(tabs.size());
   SPX(sp_table_heads(c, tabs.data(), tabs.size(), U(*final_claims)));

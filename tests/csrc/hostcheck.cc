@@ -28,6 +28,7 @@ void hc_fp_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) { fp_to_bytes(fp_
 void hc_fp_invert(const uint8_t* a, uint8_t* o) { fp_to_bytes(fp_invert(fp_from_bytes(a)), o); }
 // raw 256-bit limbs (exercises weakly-reduced inputs >= p, >= 2^255)
 void hc_fp_mul_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_mul(x, y), o); }
+void hc_fp_sqr_raw(const uint64_t* a, uint8_t* o) { Fp x; memcpy(x.v, a, 32); fp_to_bytes(fp_sqr(x), o); }
 void hc_fp_add_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_add(x, y), o); }
 void hc_fp_sub_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_sub(x, y), o); }
 
