@@ -123,7 +123,8 @@ def main():
         proof = step()
     raw = ctx.raw()
     capi.lib.sp_prof_reset(raw)
-    capi.lib.sp_prof_enable(raw, ctypes.c_int(1))  # HIP events on the library's own stream, inside the timed region
+    if not os.environ.get("BENCH_NO_PROF"):
+        capi.lib.sp_prof_enable(raw, ctypes.c_int(1))  # HIP events on the library's own stream, inside the timed region
     dist_barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -207,13 +207,13 @@ __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ i
   bool any = false;
   for (size_t s = lo + t; s < hi; s += 256) {
     Pt p = in[row * P + s];
-    acc = any ? pt_add(acc, p) : p;
+    acc = any ? pt_add_lat(acc, p) : p;
     any = true;
   }
   sm[t] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (t < s) sm[t] = pt_add(sm[t], sm[t + s]);
+    if (t < s) sm[t] = pt_add_lat(sm[t], sm[t + s]);
     __syncthreads();
   }
   if (t == 0) out[row * nchunks + ck] = sm[0];
@@ -227,13 +227,13 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const Pt* __restrict__ parti
   bool any = false;
   for (size_t s = t; s < nstrips; s += 256) {
     Pt p = partial[row * nstrips + s];
-    acc = any ? pt_add(acc, p) : p;
+    acc = any ? pt_add_lat(acc, p) : p;
     any = true;
   }
   sm[t] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (t < s && (size_t)(t + s) < nstrips) sm[t] = pt_add(sm[t], sm[t + s]);
+    if (t < s && (size_t)(t + s) < nstrips) sm[t] = pt_add_lat(sm[t], sm[t + s]);
     __syncthreads();
   }
   if (t == 0) {

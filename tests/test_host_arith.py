@@ -46,6 +46,8 @@ def test_fp_matches_python(hc):
             a, b = vals[i], vals[j]
             hc.hc_fp_mul_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == a * b % P
             hc.hc_fp_sqr_raw(raw(a), out); assert int.from_bytes(bytes(out), "little") == a * a % P
+            hc.hc_fp_mul_lat_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == a * b % P
+            hc.hc_fp_sqr_lat_raw(raw(a), out); assert int.from_bytes(bytes(out), "little") == a * a % P
             hc.hc_fp_add_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == (a + b) % P
             hc.hc_fp_sub_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == (a - b) % P
     for a in vals[1:40]:
@@ -86,3 +88,19 @@ def test_fixed_base_table_msm_matches_oracle(hc, orc, kind):
     assert hc.hc_msm_fixed(g, sz(n), mont_array(sc), o1) == 1
     assert orc.orc_pt_msm(mont_array(sc), g, sz(n), o2) == 1
     assert bytes(o1) == bytes(o2)
+
+
+def test_fe10_serial_chain_matches_python(hc):
+    """radix-2^25.5 arithmetic used by the lone-wave exponentiation ladder (spartan_amd/csrc/fe10.hpp)."""
+    rng = random.Random(16)
+    out = u8x32()
+    def raw(x): return u64x4(*[(x >> (64 * i)) & (2**64 - 1) for i in range(4)])
+    edge = [0, 1, 2, 19, P - 1, P - 2, P, P + 5, 2**255 - 1, 2**255, 2**256 - 1, 2**26 - 1, 2**26, (2**255 - 19) // 2]
+    vals = edge + [rng.randrange(2**256) for _ in range(200)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 1) % len(vals)]
+        hc.hc_fe10_mul_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == a * b % P
+        for k in (1, 2, 5, 50):
+            hc.hc_fe10_sqr_chain_raw(raw(a), ctypes.c_int(k), out); assert int.from_bytes(bytes(out), "little") == pow(a, 2**k, P)
+        hc.hc_fp_pow_p58_serial(raw(a), out); assert int.from_bytes(bytes(out), "little") == pow(a, (P - 5) // 8, P)
+        hc.hc_fp_invert_serial(raw(a), out); assert int.from_bytes(bytes(out), "little") == pow(a, P - 2, P)
