@@ -45,6 +45,9 @@ void sp_ctx_destroy(sp_ctx* ctx);
 /* HIP-event timing of every kernel family on the context's stream (bench.py's roofline numbers). */
 int32_t sp_prof_enable(sp_ctx* ctx, int on);
 int32_t sp_prof_reset(sp_ctx* ctx);
+/* Restrict event recording to one kernel family by name (NULL = all): each recorded launch costs two
+ * hipEventRecord calls, so bench.py times with only the dominant family instrumented. */
+int32_t sp_prof_select(sp_ctx* ctx, const char* family);
 /* Fills up to cap entries; returns number of kernel families. name[i] is a static string. */
 int32_t sp_prof_read(sp_ctx* ctx, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap);
 

@@ -277,6 +277,7 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   c->pinned_cap = 0;
   c->hmap = nullptr;
   c->prof_on = 0;
+  c->prof_mask = ~0ULL;
   c->pool_bytes = 0;
   memset(c->prof_ms, 0, sizeof c->prof_ms);
   memset(c->prof_n, 0, sizeof c->prof_n);
@@ -308,6 +309,14 @@ int32_t sp_prof_enable(sp_ctx* c, int on) {
   prof_drain(c);
   c->prof_on = on;
   return SP_OK;
+}
+int32_t sp_prof_select(sp_ctx* c, const char* family) {
+  if (!c) return SP_EINVAL;
+  prof_drain(c);
+  if (!family) { c->prof_mask = ~0ULL; return SP_OK; }
+  for (int i = 0; i < PF_COUNT; i++)
+    if (strcmp(kProfNames[i], family) == 0) { c->prof_mask = 1ULL << i; return SP_OK; }
+  return SP_EINVAL;
 }
 int32_t sp_prof_reset(sp_ctx* c) {
   if (!c) return SP_EINVAL;

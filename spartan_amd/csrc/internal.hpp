@@ -61,6 +61,7 @@ struct sp_ctx {
   size_t pool_bytes;
   // profiling
   int prof_on;
+  uint64_t prof_mask;  // bit i set = record HIP events for kernel family i
   std::vector<ProfRec> pending;
   std::vector<hipEvent_t> free_events;
   double prof_ms[PF_COUNT];
@@ -99,7 +100,7 @@ struct ProfScope {
   int fam;
   hipEvent_t e0, e1;
   bool on;
-  ProfScope(sp_ctx* c_, int fam_, double bytes) : c(c_), fam(fam_), on(c_->prof_on != 0) {
+  ProfScope(sp_ctx* c_, int fam_, double bytes) : c(c_), fam(fam_), on(c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;

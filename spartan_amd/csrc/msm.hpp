@@ -20,20 +20,42 @@ constexpr size_t MSM_PT_ENTRIES = (size_t)MSM_NWIN * MSM_TENT;
 // index of entry (point pt, window w, magnitude m in 1..128)
 SP_HD size_t msm_tidx(size_t pt, int w, int m) { return (pt * MSM_NWIN + (size_t)w) * MSM_TENT + (size_t)(m - 1); }
 
-// acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar.
-SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) {
-  if (fq_is_zero(s_mont)) return;
-  Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
+// signed 8-bit recoding of a canonical scalar (< 2^253): digits d_w in [-128, 127], sum d_w 2^(8w) = s.
+// mag[w] = |d_w| (0..128) packed 4 per word, neg bit w = (d_w < 0).
+SP_HD void msm_recode(const Fq& s, uint32_t mag[8], uint32_t* neg) {
   int carry = 0;
-#pragma unroll 1
+  uint32_t ng = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) mag[k] = 0;
+#pragma unroll
   for (int w = 0; w < MSM_NWIN; w++) {
     int d = (int)((s.l[w >> 3] >> ((w & 7) * 8)) & 0xff) + carry;
     carry = d > 127;
-    d -= carry << 8;  // d in [-128, 127]
-    if (d != 0) {
-      int m = d < 0 ? -d : d;
-      acc = pt_madd(acc, table[msm_tidx(pt, w, m)], d < 0);
-    }
+    d -= carry << 8;
+    uint32_t m = (uint32_t)(d < 0 ? -d : d);
+    mag[w >> 2] |= m << ((w & 3) * 8);
+    ng |= (uint32_t)(d < 0) << w;
+  }
+  *neg = ng;
+}
+
+// acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar. The table entry of the
+// next window is requested before the current mixed addition so the gather latency overlaps the 7 multiplications.
+SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) {
+  if (fq_is_zero(s_mont)) return;
+  Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
+  uint32_t mag[8], neg;
+  msm_recode(s, mag, &neg);
+  const Niels* base = table + pt * MSM_PT_ENTRIES;
+  uint32_t m = mag[0] & 0xff;
+  Niels cur = base[m ? m - 1 : 0];
+#pragma unroll 1
+  for (int w = 0; w < MSM_NWIN; w++) {
+    uint32_t mn = (w + 1 < MSM_NWIN) ? (mag[(w + 1) >> 2] >> (((w + 1) & 3) * 8)) & 0xff : 0;
+    Niels nxt = base[(size_t)((w + 1 < MSM_NWIN) ? w + 1 : w) * MSM_TENT + (mn ? mn - 1 : 0)];
+    if (m != 0) acc = pt_madd(acc, cur, (neg >> w) & 1);
+    cur = nxt;
+    m = mn;
   }
 }
 
