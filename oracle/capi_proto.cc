@@ -172,3 +172,90 @@ void orc_sumcheck_eval(int kind, const uint64_t* A, const uint64_t* B, const uin
   memcpy(out, e0.l, 32); memcpy(out + 4, e2.l, 32); if (kind != 0) memcpy(out + 8, e3.l, 32);
 }
 }
+
+// ---- verification of EXTERNAL proof bytes (the GPU path's output) by the oracle's restated verifier ----
+namespace {
+struct Rd {
+  const uint8_t* p; size_t n, o; bool ok;
+  Rd(const uint8_t* p_, size_t n_) : p(p_), n(n_), o(0), ok(true) {}
+  uint64_t u64() { if (o + 8 > n) { ok = false; return 0; } uint64_t x; memcpy(&x, p + o, 8); o += 8; return x; }
+  Fq fq() { Fq x = fq_zero(); if (o + 32 > n) { ok = false; return x; } memcpy(x.l, p + o, 32); o += 32;
+            // a serialized Scalar must be a fully reduced Montgomery residue
+            Fq t = fq_sub(x, FQ_MODULUS); (void)t; uint64_t b = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)x.l[i] - FQ_MODULUS.l[i] - b; b = (uint64_t)(d >> 64) & 1; } if (!b) ok = false;
+            return x; }
+  CP cp() { CP c{}; if (o + 32 > n) { ok = false; return c; } memcpy(c.data(), p + o, 32); o += 32; return c; }
+  FqVec fqv() { uint64_t k = u64(); FqVec v; if (k > (1u << 24)) { ok = false; return v; } for (uint64_t i = 0; i < k && ok; i++) v.push_back(fq()); return v; }
+  std::vector<CP> cpv() { uint64_t k = u64(); std::vector<CP> v; if (k > (1u << 24)) { ok = false; return v; } for (uint64_t i = 0; i < k && ok; i++) v.push_back(cp()); return v; }
+};
+void r_dpp(Rd& r, DotProductProof& p) { p.delta = r.cp(); p.beta = r.cp(); p.z = r.fqv(); p.z_delta = r.fq(); p.z_beta = r.fq(); }
+void r_zksc(Rd& r, ZKSumcheckProof& p) { p.comm_polys = r.cpv(); p.comm_evals = r.cpv(); uint64_t k = r.u64(); if (k > 64) { r.ok = false; return; } p.proofs.resize(k); for (auto& d : p.proofs) r_dpp(r, d); }
+void r_eq(Rd& r, EqualityProof& p) { p.alpha = r.cp(); p.z = r.fq(); }
+void r_pe(Rd& r, PolyEvalProof& p) { p.proof.bullet.L_vec = r.cpv(); p.proof.bullet.R_vec = r.cpv(); p.proof.delta = r.cp(); p.proof.beta = r.cp(); p.proof.z1 = r.fq(); p.proof.z2 = r.fq(); }
+void r_r1cs(Rd& r, R1CSProof& p) {
+  p.comm_vars.C = r.cpv(); r_zksc(r, p.sc_proof_phase1);
+  for (int i = 0; i < 4; i++) p.claims_phase2[i] = r.cp();
+  p.pok_Cz.alpha = r.cp(); p.pok_Cz.z1 = r.fq(); p.pok_Cz.z2 = r.fq();
+  p.proof_prod.alpha = r.cp(); p.proof_prod.beta = r.cp(); p.proof_prod.delta = r.cp();
+  for (int i = 0; i < 5; i++) p.proof_prod.z[i] = r.fq();
+  r_eq(r, p.proof_eq_sc_phase1); r_zksc(r, p.sc_proof_phase2);
+  p.comm_vars_at_ry = r.cp(); r_pe(r, p.proof_eval_vars_at_ry); r_eq(r, p.proof_eq_sc_phase2);
+}
+void r_batched(Rd& r, ProductCircuitEvalProofBatched& p) {
+  uint64_t k = r.u64(); if (k > 64) { r.ok = false; return; }
+  p.proof.resize(k);
+  for (auto& l : p.proof) {
+    uint64_t m = r.u64(); if (m > 64) { r.ok = false; return; }
+    l.proof.compressed_polys.resize(m);
+    for (auto& c : l.proof.compressed_polys) c = r.fqv();
+    l.claims_prod_left = r.fqv(); l.claims_prod_right = r.fqv();
+  }
+  for (int i = 0; i < 3; i++) p.claims_dotp[i] = r.fqv();
+}
+void r_evalproof(Rd& r, SparseMatPolyEvalProof& p) {
+  p.comm_derefs.C = r.cpv();
+  ProductLayerProof& L = p.proof_prod_layer;
+  L.row_init = r.fq(); L.row_read = r.fqv(); L.row_write = r.fqv(); L.row_audit = r.fq();
+  L.col_init = r.fq(); L.col_read = r.fqv(); L.col_write = r.fqv(); L.col_audit = r.fq();
+  L.eval_val[0] = r.fqv(); L.eval_val[1] = r.fqv();
+  r_batched(r, L.proof_mem); r_batched(r, L.proof_ops);
+  HashLayerProof& h = p.proof_hash_layer;
+  h.row_addr = r.fqv(); h.row_read_ts = r.fqv(); h.row_audit_ts = r.fq();
+  h.col_addr = r.fqv(); h.col_read_ts = r.fqv(); h.col_audit_ts = r.fq();
+  h.eval_val = r.fqv(); h.eval_derefs[0] = r.fqv(); h.eval_derefs[1] = r.fqv();
+  r_pe(r, h.proof_ops); r_pe(r, h.proof_mem); r_pe(r, h.proof_derefs);
+}
+}  // namespace
+
+extern "C" {
+// SNARK::verify (lib.rs:423-466) on bincode bytes produced elsewhere, against a computation commitment given as bytes
+// (comm_comb_ops / comm_comb_mem: n x 32). Returns 1 accept, 0 reject, -1 malformed.
+int orc_snark_verify_bytes(const uint8_t* proof, size_t proof_len, void* gens, size_t num_cons, size_t num_vars, size_t num_inputs,
+                           size_t num_ops, size_t num_mem_cells, const uint8_t* comm_ops, size_t n_ops, const uint8_t* comm_mem, size_t n_mem,
+                           const uint64_t* inputs, const char* transcript_label) {
+  Rd r(proof, proof_len);
+  SNARKProof P;
+  r_r1cs(r, P.r1cs_sat_proof);
+  for (int i = 0; i < 3; i++) P.inst_evals[i] = r.fq();
+  r_evalproof(r, P.r1cs_eval_proof);
+  if (!r.ok || r.o != proof_len) return -1;
+  R1CSCommitment comm;
+  comm.num_cons = num_cons; comm.num_vars = num_vars; comm.num_inputs = num_inputs;
+  comm.comm.batch_size = 3; comm.comm.num_ops = num_ops; comm.comm.num_mem_cells = num_mem_cells;
+  for (size_t i = 0; i < n_ops; i++) { CP c; memcpy(c.data(), comm_ops + 32 * i, 32); comm.comm.comm_comb_ops.C.push_back(c); }
+  for (size_t i = 0; i < n_mem; i++) { CP c; memcpy(c.data(), comm_mem + 32 * i, 32); comm.comm.comm_comb_mem.C.push_back(c); }
+  Transcript t(transcript_label);
+  return snark_verify(P, comm, limbs_vec(inputs, num_inputs), t, ((SnarkGensH*)gens)->g) ? 1 : 0;
+}
+// NIZK::verify (lib.rs:549-587) on external bytes
+int orc_nizk_verify_bytes(const uint8_t* proof, size_t proof_len, void* inst, void* gens, const uint8_t* digest, size_t digest_len,
+                          const char* transcript_label) {
+  Rd r(proof, proof_len);
+  NIZKProof P;
+  r_r1cs(r, P.r1cs_sat_proof);
+  P.rx = r.fqv(); P.ry = r.fqv();
+  if (!r.ok || r.o != proof_len) return -1;
+  Transcript t(transcript_label);
+  std::vector<uint8_t> d(digest, digest + digest_len);
+  return nizk_verify(P, ((InstH*)inst)->inst, d, ((InstH*)inst)->inputs, t, ((NizkGensH*)gens)->g) ? 1 : 0;
+}
+}

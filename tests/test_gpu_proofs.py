@@ -115,3 +115,29 @@ def test_instance_new_matches_synthetic_and_rejects_bad_input(P, ctx, orc):
     with pytest.raises(P.SpartanHipError, match="InvalidScalar"):
         P.Instance.new(ctx, N, N, 10, nnz, rows, cols, larger_than_mod + vb[32:])
     gens.free(); inst.free(); ref.free(); orc.orc_instance_free(oi)
+
+
+@pytest.mark.parametrize("s", [16, 20])
+def test_snark_full_size_properties(P, ctx, orc, s):
+    """BASELINE sizes (configs[1] 2^16, configs[2] 2^20), where the oracle prover is too slow to run in a test:
+    size-independent properties — README proof lengths, determinism, and the oracle's restated VERIFIER accepts the
+    GPU proof bytes against the GPU computation commitment (and rejects a corrupted proof)."""
+    N = 1 << s
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", s)
+    proof = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == proof
+    from tests.test_oracle_pins import sat_proof_len
+    if s == 20:
+        assert sat_proof_len(20) == 47024 and len(proof) == 47024 + 96 + 133720  # README.md:362,374 + 3 inst_evals
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    ops, mem = enc.comm(0), enc.comm(1)
+    def verify(b):
+        return orc.orc_snark_verify_bytes(b, sz(len(b)), og, sz(N), sz(N), sz(10), sz(N), sz(2 * N), ops, sz(len(ops) // 32), mem,
+                                          sz(len(mem) // 32), inst.inputs, b"snark_example")
+    assert verify(proof) == 1
+    bad = bytearray(proof); bad[8 + 32 * 3 + 5] ^= 0x10   # corrupt one witness-commitment share
+    assert verify(bytes(bad)) in (0, -1)
+    orc.orc_snark_gens_free(og); enc.free(); gens.free(); inst.free()

@@ -274,3 +274,33 @@ def test_oracle_snark_roundtrip(orc, s):
         orc.orc_proof_free(p)
         p = vp(orc.orc_snark_prove(inst, g, e, b"snark_example", seed, None))
     orc.orc_proof_free(p); orc.orc_encode_free(e); orc.orc_snark_gens_free(g); orc.orc_instance_free(inst)
+
+
+def test_oracle_verifies_its_own_serialized_bytes(orc):
+    """bincode round trip: ser_snark -> orc_snark_verify_bytes (the entry point used to check GPU proofs at sizes
+    where the oracle prover is too slow)."""
+    s = 6; N = 1 << s
+    inst = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(5)))
+    g = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    e = vp(orc.orc_snark_encode(inst, g))
+    seed = u64x4(); orc.orc_seed_scalar(b"tape", ctypes.c_uint64(1), seed)
+    p = vp(orc.orc_snark_prove(inst, g, e, b"snark_example", seed, None))
+    n = orc.orc_proof_bytes(p, None, sz(0)); pb = (ctypes.c_uint8 * n)(); orc.orc_proof_bytes(p, pb, sz(n))
+    comms = []
+    for which in (0, 1):
+        k = orc.orc_encode_comm(e, ctypes.c_int(which), None, sz(0)); b = (ctypes.c_uint8 * (32 * k))()
+        orc.orc_encode_comm(e, ctypes.c_int(which), b, sz(32 * k)); comms.append((bytes(b), k))
+    tot = sum(orc.orc_instance_nnz(inst, ctypes.c_int(k)) for k in range(3))
+    rows = (ctypes.c_uint64 * tot)(); cols = (ctypes.c_uint64 * tot)(); vals = (ctypes.c_uint64 * (4 * tot))()
+    vars_ = (ctypes.c_uint64 * (4 * N))(); inputs = (ctypes.c_uint64 * 40)()
+    orc.orc_instance_export(inst, rows, cols, vals, vars_, inputs)
+    def verify(b):
+        return orc.orc_snark_verify_bytes(bytes(b), sz(len(b)), g, sz(N), sz(N), sz(10), sz(N), sz(2 * N), comms[0][0], sz(comms[0][1]),
+                                          comms[1][0], sz(comms[1][1]), inputs, b"snark_example")
+    good = bytes(pb)
+    assert verify(good) == 1
+    assert verify(good[:-1]) == -1                      # truncated
+    bad = bytearray(good); bad[len(bad) // 2] ^= 1
+    assert verify(bytes(bad)) in (0, -1)                # a flipped bit is rejected (or is no longer a canonical scalar)
+    bad = bytearray(good); bad[40] ^= 1                 # inside comm_vars
+    assert verify(bytes(bad)) in (0, -1)
