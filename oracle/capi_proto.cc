@@ -259,3 +259,37 @@ int orc_nizk_verify_bytes(const uint8_t* proof, size_t proof_len, void* inst, vo
   return nizk_verify(P, ((InstH*)inst)->inst, d, ((InstH*)inst)->inputs, t, ((NizkGensH*)gens)->g) ? 1 : 0;
 }
 }
+
+extern "C" {
+// Instance::new (lib.rs:121-228): padding of num_vars / num_cons, column shift for the constant/input columns, explicit
+// zero rows when num_cons is 0 or 1, canonical-byte values. Returns NULL and sets *err (1 InvalidIndex, 2 InvalidScalar).
+void* orc_instance_new_padded(size_t num_cons, size_t num_vars, size_t num_inputs, const size_t nnz[3], const uint64_t* rows,
+                              const uint64_t* cols, const uint8_t* vals, const uint64_t* vars, size_t n_assigned_vars, const uint64_t* inputs,
+                              int* err) {
+  *err = 0;
+  size_t nvp = num_vars > num_inputs + 1 ? num_vars : num_inputs + 1;   // :132-139
+  nvp = next_pow2(nvp);
+  size_t ncp = num_cons;                                                 // :143-156
+  if (num_cons == 0 || num_cons == 1) ncp = 2;
+  if (next_pow2(num_cons) != num_cons) ncp = next_pow2(num_cons);
+  InstH* h = new InstH;
+  h->inst.num_cons = ncp; h->inst.num_vars = nvp; h->inst.num_inputs = num_inputs;
+  SparseMatPoly* m[3] = {&h->inst.A, &h->inst.B, &h->inst.C};
+  size_t off = 0;
+  for (int k = 0; k < 3; k++) {
+    m[k]->num_vars_x = log_2(ncp); m[k]->num_vars_y = log_2(2 * nvp);
+    for (size_t i = 0; i < nnz[k]; i++, off++) {
+      if (rows[off] >= num_cons || cols[off] >= num_vars + 1 + num_inputs) { *err = 1; delete h; return nullptr; }   // :164-172
+      Fq v;
+      if (!fq_from_bytes(vals + 32 * off, &v)) { *err = 2; delete h; return nullptr; }                               // :174-186
+      size_t col = cols[off] >= num_vars ? cols[off] + nvp - num_vars : cols[off];                                   // :178-182
+      m[k]->M.push_back({(size_t)rows[off], col, v});
+    }
+    if (num_cons == 0 || num_cons == 1)                                                                                // :188-194
+      for (size_t i = nnz[k]; i < ncp; i++) m[k]->M.push_back({i, num_vars, fq_zero()});
+  }
+  h->vars = limbs_vec(vars, n_assigned_vars);
+  h->inputs = limbs_vec(inputs, num_inputs);
+  return h;
+}
+}

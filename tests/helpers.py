@@ -21,7 +21,7 @@ def load_oracle():
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     _build_if_missing(so, "make -C oracle")
     L = ctypes.CDLL(so)
-    for f in ("orc_instance_synthetic", "orc_instance_new", "orc_snark_gens_new", "orc_nizk_gens_new", "orc_snark_encode",
+    for f in ("orc_instance_synthetic", "orc_instance_new", "orc_instance_new_padded", "orc_snark_gens_new", "orc_nizk_gens_new", "orc_snark_encode",
               "orc_snark_prove", "orc_nizk_prove"):
         getattr(L, f).restype = vp
     for f in ("orc_proof_bytes", "orc_instance_nnz", "orc_instance_shape_bincode", "orc_encode_comm", "orc_merlin_script"):

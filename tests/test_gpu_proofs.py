@@ -141,3 +141,50 @@ def test_snark_full_size_properties(P, ctx, orc, s):
     bad = bytearray(proof); bad[8 + 32 * 3 + 5] ^= 0x10   # corrupt one witness-commitment share
     assert verify(bytes(bad)) in (0, -1)
     orc.orc_snark_gens_free(og); enc.free(); gens.free(); inst.free()
+
+
+def test_padded_constraints_like_reference(P, ctx, orc):
+    """lib.rs:672-753 test_padded_constraints: num_cons = 1, num_vars = 0, num_inputs = 3 (a^2 + b + 13 = z). Exercises the
+    padding rules of Instance::new (zero-variable / one-constraint), SNARK and NIZK; bytes equal the oracle's and verify."""
+    num_cons, num_vars, num_inputs, nnz_param = 1, 0, 3, 3
+    le = lambda x: (x % Q).to_bytes(32, "little")
+    A = [(0, num_vars + 2, le(1))]
+    B = [(0, num_vars + 2, le(1))]
+    C = [(0, num_vars + 1, le(1)), (0, num_vars, le(-13)), (0, num_vars + 3, le(-1))]
+    nnz = [len(A), len(B), len(C)]
+    ent = A + B + C
+    rows = (ctypes.c_uint64 * len(ent))(*[e[0] for e in ent]); cols = (ctypes.c_uint64 * len(ent))(*[e[1] for e in ent])
+    vals = b"".join(e[2] for e in ent)
+    vars_ = (ctypes.c_uint64 * 4)()           # no variables assigned (the prover pads to num_vars_padded = 4)
+    inputs = mont_array([16, 1, 2])
+    inst = P.Instance.new(ctx, num_cons, num_vars, num_inputs, nnz, rows, cols, vals)
+    inst.num_inputs = num_inputs
+    err = ctypes.c_int(0)
+    oi = vp(orc.orc_instance_new_padded(sz(num_cons), sz(num_vars), sz(num_inputs), (sz * 3)(*nnz), rows, cols, vals, vars_, sz(0), inputs,
+                                        ctypes.byref(err)))
+    assert err.value == 0 and oi
+    tape = P.seed_scalar(b"tape", 77)
+    empty = (ctypes.c_uint64 * 0)()
+    # SNARK
+    gens = P.SNARKGens(ctx, num_cons, num_vars, num_inputs, nnz_param)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    got = P.SNARK.prove(ctx, inst, enc, empty, inputs, gens, b"snark_example", tape)
+    og = vp(orc.orc_snark_gens_new(sz(num_cons), sz(num_vars), sz(num_inputs), sz(nnz_param)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
+    assert orc.orc_snark_verify(op, oi, og, oe, b"snark_example") == 1
+    assert got == oracle_bytes(orc, op)
+    # NIZK
+    inst.set_digest(b"padded")
+    ngens = P.NIZKGens(ctx, num_cons, num_vars, num_inputs)
+    got = P.NIZK.prove(ctx, inst, empty, inputs, ngens, b"nizk_example", tape)
+    ong = vp(orc.orc_nizk_gens_new(sz(num_cons), sz(num_vars), sz(num_inputs)))
+    onp = vp(orc.orc_nizk_prove(oi, ong, b"padded", sz(6), b"nizk_example", tape, None))
+    assert orc.orc_nizk_verify(onp, oi, ong, b"padded", sz(6), b"nizk_example") == 1
+    assert got == oracle_bytes(orc, onp)
+    # error paths of the oracle restatement agree with the product's (InvalidIndex / InvalidScalar)
+    bad_rows = (ctypes.c_uint64 * len(ent))(*[1] + [e[0] for e in ent[1:]])
+    assert not orc.orc_instance_new_padded(sz(num_cons), sz(num_vars), sz(num_inputs), (sz * 3)(*nnz), bad_rows, cols, vals, vars_, sz(0), inputs, ctypes.byref(err)) and err.value == 1
+    with pytest.raises(P.SpartanHipError, match="InvalidIndex"):
+        P.Instance.new(ctx, num_cons, num_vars, num_inputs, nnz, bad_rows, cols, vals)
+    ngens.free(); enc.free(); gens.free(); inst.free()
