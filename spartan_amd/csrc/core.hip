@@ -197,48 +197,54 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
   partial[row * (ncol * MSM_NWIN) + (size_t)w * ncol + j] = acc;
 }
 // reduction pass: grid (rows, nchunks); block sums `chunk` consecutive partials of its row into one point.
-__global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt* __restrict__ out) {
-  __shared__ Pt sm[256];
+// Reductions run on the radix-2^25.5 serial-chain arithmetic (fe10.hpp): few waves, latency-bound.
+__global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt10* __restrict__ out) {
+  __shared__ Pt10 sm[256];
   size_t row = blockIdx.x, ck = blockIdx.y, nchunks = gridDim.y;
   int t = threadIdx.x;
   size_t lo = ck * chunk, hi = lo + chunk;
   if (hi > P) hi = P;
-  Pt acc = pt_identity();
+  Pt10 acc = pt10_identity();
   bool any = false;
   for (size_t s = lo + t; s < hi; s += 256) {
-    Pt p = in[row * P + s];
-    acc = any ? pt_add_lat(acc, p) : p;
+    Pt10 p = pt10_load(in[row * P + s]);
+    acc = any ? pt10_add(acc, p) : p;
     any = true;
   }
   sm[t] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (t < s) sm[t] = pt_add_lat(sm[t], sm[t + s]);
+    if (t < s) sm[t] = pt10_add(sm[t], sm[t + s]);
     __syncthreads();
   }
   if (t == 0) out[row * nchunks + ck] = sm[0];
 }
-// one block per row: sum the row's strip partials, compress.
-__global__ void __launch_bounds__(256) k_msm_reduce(const Pt* __restrict__ partial, size_t nstrips, uint8_t* __restrict__ out) {
-  __shared__ Pt sm[256];
+// one block per row: sum the row's partials, RFC 9496 encode. IN10: partials already in Pt10 form (second pass).
+template <bool IN10>
+__global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ partial_, size_t nstrips, uint8_t* __restrict__ out) {
+  __shared__ Pt10 sm[256];
   size_t row = blockIdx.x;
   int t = threadIdx.x;
-  Pt acc = pt_identity();
+  Pt10 acc = pt10_identity();
   bool any = false;
   for (size_t s = t; s < nstrips; s += 256) {
-    Pt p = partial[row * nstrips + s];
-    acc = any ? pt_add_lat(acc, p) : p;
+    Pt10 p = IN10 ? ((const Pt10*)partial_)[row * nstrips + s] : pt10_load(((const Pt*)partial_)[row * nstrips + s]);
+    acc = any ? pt10_add(acc, p) : p;
     any = true;
   }
   sm[t] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (t < s && (size_t)(t + s) < nstrips) sm[t] = pt_add_lat(sm[t], sm[t + s]);
+  int top = 128;
+  while (top > 1 && (size_t)top >= nstrips) top >>= 1;  // no levels that would only add identities
+  for (int s = top; s > 0; s >>= 1) {
+    if (t < s && (size_t)(t + s) < nstrips) sm[t] = pt10_add(sm[t], sm[t + s]);
     __syncthreads();
   }
   if (t == 0) {
     uint8_t c[32];
-    pt_compress(sm[0], c);
+    Pt10 r = sm[0];
+    fe10_pin(r.X); fe10_pin(r.Y); fe10_pin(r.Z); fe10_pin(r.T);
+    pt10_compress(r, c);
     for (int k = 0; k < 32; k++) out[32 * row + k] = c[k];
   }
 }
@@ -409,10 +415,10 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
   size_t chunk = 1024, nchunks = (P + chunk - 1) / chunk;
   bool two_pass = P > 2048;
   size_t part_bytes = (rows * P * sizeof(Pt) + 255) & ~(size_t)255;
-  size_t part2_bytes = two_pass ? ((rows * nchunks * sizeof(Pt) + 255) & ~(size_t)255) : 0;
+  size_t part2_bytes = two_pass ? ((rows * nchunks * sizeof(Pt10) + 255) & ~(size_t)255) : 0;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, part_bytes + part2_bytes + 32 * rows));
   Pt* partial = (Pt*)c->scratch;
-  Pt* partial2 = (Pt*)((uint8_t*)c->scratch + part_bytes);
+  Pt10* partial2 = (Pt10*)((uint8_t*)c->scratch + part_bytes);
   bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
   uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + part_bytes + part2_bytes;
   {
@@ -431,9 +437,9 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
     ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * P * sizeof(Pt)));
     if (two_pass) {
       hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)nchunks), dim3(256), 0, c->stream, (const Pt*)partial, P, chunk, partial2);
-      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)rows), dim3(256), 0, c->stream, (const Pt*)partial2, nchunks, dout);
+      hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial2, nchunks, dout);
     } else {
-      hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)rows), dim3(256), 0, c->stream, (const Pt*)partial, P, dout);
+      hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial, P, dout);
     }
   }
   if (small_out) SPCHK(fetch_small(c, out_host, 32 * rows));
@@ -519,11 +525,19 @@ int32_t sp_table_upload(sp_ctx* c, const uint64_t* Z, size_t len, sp_table** out
   if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; }
   return rc;
 }
+__global__ void k_copy_small(const Fq* __restrict__ src, size_t n, Fq* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st_fq(dst + i, ld_fq(src + i));
+}
 int32_t sp_table_download(sp_ctx* c, const sp_table* t, size_t off, size_t len, uint64_t* out) {
   if (!c || !t || !out || off + len > t->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
+  if (32 * len <= 4096) {  // a few elements (product-circuit roots, final claims): kernel write into the mapped page + poll
+    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)((len + 63) / 64)), dim3(64), 0, c->stream, (const Fq*)(t->d + off), len, (Fq*)hres(c));
+    return fetch_small(c, out, 32 * len);
+  }
   HIPCHK(hipMemcpyAsync(out, t->d + off, 32 * len, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SPCHK(sync_spin(c));
   return SP_OK;
 }
 int32_t sp_table_clone(sp_ctx* c, const sp_table* t, sp_table** out) {

@@ -161,4 +161,49 @@ SP_HD Pt pt_from_uniform_bytes(const uint8_t b[64]) {
   return pt_add(pt_elligator(t1), pt_elligator(t2));
 }
 
+// ---------------------------------------------------------------- serial-chain forms (fe10.hpp): LDS tree additions
+// and the ristretto encode executed by a handful of waves on the commit critical path. Same group elements, same bytes.
+struct Pt10 {
+  Fe10 X, Y, Z, T;
+};
+SP_HD Pt10 pt10_identity() { return Pt10{Fe10{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, fe10_one(), fe10_one(), Fe10{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}}; }
+SP_HD Pt10 pt10_load(const Pt& p) { return Pt10{fe10_load(p.X), fe10_load(p.Y), fe10_load(p.Z), fe10_load(p.T)}; }
+SP_HD Pt10 pt10_add(const Pt10& p, const Pt10& q) {
+  Fe10 A = fe10_mul(fe10_sub(p.Y, p.X), fe10_sub(q.Y, q.X));
+  Fe10 B = fe10_mul(fe10_add(p.Y, p.X), fe10_add(q.Y, q.X));
+  Fe10 C = fe10_mul(fe10_mul(p.T, fe10_load(fp_D2())), q.T);
+  Fe10 Dd = fe10_mul(fe10_add(p.Z, p.Z), q.Z);
+  Fe10 E = fe10_sub(B, A), F = fe10_sub(Dd, C), G = fe10_add(Dd, C), H = fe10_add(B, A);
+  return Pt10{fe10_mul(E, F), fe10_mul(G, H), fe10_mul(F, G), fe10_mul(E, H)};
+}
+SP_HD bool fe10_is_negative(const Fe10& a) { return fe10_to_fp(a).v[0] & 1; }
+SP_HD Fe10 fe10_abs(const Fe10& a) { return fe10_select(a, fe10_neg(a), fe10_is_negative(a)); }
+// RFC 9496 §4.3.2 Encode on radix-2^25.5 limbs
+SP_HD void pt10_compress(const Pt10& p, uint8_t out[32]) {
+  Fe10 sqrt_m1 = fe10_load(fp_SQRT_M1());
+  Fe10 u1 = fe10_mul(fe10_add(p.Z, p.Y), fe10_sub(p.Z, p.Y));
+  Fe10 u2 = fe10_mul(p.X, p.Y);
+  // SQRT_RATIO_M1(1, v) with v = u1 * u2^2
+  Fe10 v = fe10_mul(u1, fe10_sqr(u2));
+  Fe10 v3 = fe10_mul(fe10_sqr(v), v);
+  Fe10 v7 = fe10_mul(fe10_sqr(v3), v);
+  Fe10 r = fe10_mul(v3, fe10_pow_p58(v7));
+  Fp check = fe10_to_fp(fe10_mul(v, fe10_sqr(r)));
+  bool flipped = fp_eq(check, fp_neg(fp_one()));
+  bool flipped_i = fp_eq(check, fp_neg(fp_SQRT_M1()));
+  r = fe10_select(r, fe10_mul(r, sqrt_m1), flipped || flipped_i);
+  Fe10 invsqrt = fe10_abs(r);
+  Fe10 den1 = fe10_mul(invsqrt, u1), den2 = fe10_mul(invsqrt, u2);
+  Fe10 z_inv = fe10_mul(fe10_mul(den1, den2), p.T);
+  Fe10 ix0 = fe10_mul(p.X, sqrt_m1), iy0 = fe10_mul(p.Y, sqrt_m1);
+  Fe10 ench = fe10_mul(den1, fe10_load(fp_INVSQRT_A_MINUS_D()));
+  bool rotate = fe10_is_negative(fe10_mul(p.T, z_inv));
+  Fe10 x = fe10_select(p.X, iy0, rotate);
+  Fe10 y = fe10_select(p.Y, ix0, rotate);
+  Fe10 den_inv = fe10_select(den2, ench, rotate);
+  y = fe10_select(y, fe10_neg(y), fe10_is_negative(fe10_mul(x, z_inv)));
+  Fe10 s = fe10_abs(fe10_mul(den_inv, fe10_sub(p.Z, y)));
+  fp_to_bytes(fe10_to_fp(s), out);
+}
+
 }  // namespace sp

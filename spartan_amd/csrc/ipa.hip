@@ -13,19 +13,15 @@ struct sp_ipa {
   size_t bytes;
 };
 
-// single block. rows[0] = scalars of L, rows[1] = scalars of R over (G[0..n0), Qbase, H).
+// rows[0] = scalars of L, rows[1] = scalars of R over (G[0..n0), Qbase, H). Blocks 0..nb-1 fill the generator
+// columns; the extra last block computes c_L, c_R (LDS reduce) and the two trailing columns.
 __global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
                                                      size_t n0, Fq q_scale, Fq blind_L, Fq blind_R, Fq* __restrict__ rows) {
   __shared__ Fq sm[256];
-  size_t h = n_cur / 2;
-  Fq c[2] = {fq_zero(), fq_zero()};
-  for (size_t i = threadIdx.x; i < h; i += 256) {
-    c[0] = fq_add(c[0], fq_mul(ld_fq(a + i), ld_fq(b + h + i)));  // c_L = <a_L, b_R>  (bullet.rs:80)
-    c[1] = fq_add(c[1], fq_mul(ld_fq(a + h + i), ld_fq(b + i)));  // c_R = <a_R, b_L>  (bullet.rs:81)
-  }
-  block_sum_fq<2>(c, sm);
-  size_t stride = n0 + 2;
-  for (size_t j = threadIdx.x; j < n0; j += 256) {
+  size_t h = n_cur / 2, stride = n0 + 2;
+  if (blockIdx.x + 1 < gridDim.x) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n0) return;
     size_t p = j / n_cur, i = j % n_cur;
     Fq sp_ = ld_fq(s + p);
     Fq l = fq_zero(), r = fq_zero();
@@ -33,7 +29,14 @@ __global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, c
     else r = fq_mul(ld_fq(a + h + i), sp_);           // a_R[i] * G_L[i]
     st_fq(rows + j, l);
     st_fq(rows + stride + j, r);
+    return;
   }
+  Fq c[2] = {fq_zero(), fq_zero()};
+  for (size_t i = threadIdx.x; i < h; i += 256) {
+    c[0] = fq_add(c[0], fq_mul(ld_fq(a + i), ld_fq(b + h + i)));  // c_L = <a_L, b_R>  (bullet.rs:80)
+    c[1] = fq_add(c[1], fq_mul(ld_fq(a + h + i), ld_fq(b + i)));  // c_R = <a_R, b_L>  (bullet.rs:81)
+  }
+  block_sum_fq<2>(c, sm);
   if (threadIdx.x == 0) {
     st_fq(rows + n0, fq_mul(c[0], q_scale));
     st_fq(rows + n0 + 1, blind_L);
@@ -116,7 +119,7 @@ int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t b
   HIPCHK(hipSetDevice(c->dev));
   {
     ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);
-    hipLaunchKernelGGL(k_ipa_prepare, dim3(1), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
+    hipLaunchKernelGGL(k_ipa_prepare, dim3((unsigned)((ipa->n0 + 255) / 256 + 1)), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
                        ipa->n0, ipa->q_scale, limbs(blind_L), limbs(blind_R), ipa->rows);
   }
   uint8_t lr[64];

@@ -3,16 +3,42 @@
 // Every group operation and every O(N) field pass is an sp_* call (HIP); see libspartan.hpp.
 #include "libspartan.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <map>
 
 namespace spz {
 using namespace sp;
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// optional per-entry-point wall-clock accounting (SPARTAN_CALLSTATS=1): where the latency of a proof accumulates
+struct CallStats {
+  struct E { double t = 0; size_t n = 0; };
+  std::map<std::string, E> m;
+  bool on = getenv("SPARTAN_CALLSTATS") != nullptr;
+  ~CallStats() { dump(); }
+  void dump() {
+    if (!on || m.empty()) return;
+    std::vector<std::pair<std::string, E>> v(m.begin(), m.end());
+    std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.second.t > b.second.t; });
+    fprintf(stderr, "[callstats] %-34s %8s %12s %10s\n", "entry point", "calls", "total ms", "avg us");
+    for (auto& kv : v) fprintf(stderr, "[callstats] %-34s %8zu %12.3f %10.1f\n", kv.first.c_str(), kv.second.n, kv.second.t * 1e3, kv.second.t / kv.second.n * 1e6);
+    m.clear();
+  }
+};
+static CallStats g_calls;
 #define SPX(call)                                                                                        \
   do {                                                                                                   \
+    double t0_ = g_calls.on ? now_s() : 0;                                                               \
     int32_t rc_ = (call);                                                                                \
+    if (g_calls.on) {                                                                                    \
+      std::string k_(#call);                                                                             \
+      auto& e_ = g_calls.m[k_.substr(0, k_.find('('))];                                                  \
+      e_.t += now_s() - t0_;                                                                             \
+      e_.n++;                                                                                            \
+    }                                                                                                    \
     if (rc_ != SP_OK) throw Error(std::string(#call) + " failed: " + sp_strerror(rc_) + " (" + std::to_string(rc_) + ")"); \
   } while (0)
 #define REQUIRE(cond)                                                    \

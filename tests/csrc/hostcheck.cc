@@ -42,6 +42,9 @@ void hc_fp_sub_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; 
 int hc_pt_recompress(const uint8_t* in, uint8_t* out) { Pt p; if (!pt_decompress(in, &p)) return 0; pt_compress(p, out); return 1; }
 void hc_pt_from_uniform(const uint8_t* in64, uint8_t* out) { pt_compress(pt_from_uniform_bytes(in64), out); }
 int hc_pt_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { Pt p, q; if (!pt_decompress(a, &p) || !pt_decompress(b, &q)) return 0; pt_compress(pt_add(p, q), out); return 1; }
+// serial-chain (Fe10) forms: add two points and encode through Pt10
+int hc_pt10_add_compress(const uint8_t* a, const uint8_t* b, uint8_t* out) { Pt p, q; if (!pt_decompress(a, &p) || !pt_decompress(b, &q)) return 0; pt10_compress(pt10_add(pt10_load(p), pt10_load(q)), out); return 1; }
+int hc_pt10_sum_compress(const uint8_t* pts, size_t n, uint8_t* out) { Pt10 acc = pt10_identity(); for (size_t i = 0; i < n; i++) { Pt p; if (!pt_decompress(pts + 32 * i, &p)) return 0; acc = pt10_add(acc, pt10_load(p)); } pt10_compress(acc, out); return 1; }
 int hc_pt_dbl(const uint8_t* a, uint8_t* out) { Pt p; if (!pt_decompress(a, &p)) return 0; pt_compress(pt_dbl(p), out); return 1; }
 
 // fixed-base table MSM exactly as the device does it: build tables like k_table_build, accumulate like k_msm_rows

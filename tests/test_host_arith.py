@@ -104,3 +104,22 @@ def test_fe10_serial_chain_matches_python(hc):
             hc.hc_fe10_sqr_chain_raw(raw(a), ctypes.c_int(k), out); assert int.from_bytes(bytes(out), "little") == pow(a, 2**k, P)
         hc.hc_fp_pow_p58_serial(raw(a), out); assert int.from_bytes(bytes(out), "little") == pow(a, (P - 5) // 8, P)
         hc.hc_fp_invert_serial(raw(a), out); assert int.from_bytes(bytes(out), "little") == pow(a, P - 2, P)
+
+
+def test_pt10_add_and_encode_match_oracle(hc, orc):
+    rng = random.Random(17)
+    o1 = u8x32(); o2 = u8x32()
+    pts = []
+    for _ in range(30):
+        u = bytes(rng.randrange(256) for _ in range(64))
+        orc.orc_pt_from_uniform_bytes(u, o2); pts.append(bytes(o2))
+    pts.append(bytes(32))  # identity
+    for i in range(len(pts)):
+        a, b = pts[i], pts[(i * 3 + 1) % len(pts)]
+        assert hc.hc_pt10_add_compress(a, b, o1) == 1 and orc.orc_pt_add(a, b, o2) == 1 and bytes(o1) == bytes(o2)
+        assert hc.hc_pt10_add_compress(a, a, o1) == 1 and orc.orc_pt_dbl(a, o2) == 1 and bytes(o1) == bytes(o2)
+    # long accumulation chain (limb bounds must hold across many dependent additions)
+    acc = bytes(32)
+    for p_ in pts:
+        orc.orc_pt_add(acc, p_, o2); acc = bytes(o2)
+    assert hc.hc_pt10_sum_compress(b"".join(pts), sz(len(pts)), o1) == 1 and bytes(o1) == acc
