@@ -116,8 +116,8 @@ void* spz_snark_prove(void* ctx, void* inst, void* gens, void* enc, const uint64
     memcpy(seed.l, tape_seed, 32);
     ProveTimes tm;
     EncH* e = (EncH*)enc;
-    SNARK p = SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, limbs_vec(vars, nvars), limbs_vec(inputs, ninputs), *(SNARKGens*)gens, t,
-                           seed, &tm);
+    SNARK p = SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(SNARKGens*)gens,
+                           t, seed, &tm);
     fill_times(tm, times10);
     ProofH* h = new ProofH;
     h->bytes = p.serialize();
@@ -131,7 +131,7 @@ void* spz_nizk_prove(void* ctx, void* inst, void* gens, const uint64_t* vars, si
     Fq seed;
     memcpy(seed.l, tape_seed, 32);
     ProveTimes tm;
-    NIZK p = NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, limbs_vec(vars, nvars), limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t, seed, &tm);
+    NIZK p = NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t, seed, &tm);
     fill_times(tm, times10);
     ProofH* h = new ProofH;
     h->bytes = p.serialize();

@@ -205,14 +205,24 @@ struct SNARK {  // lib.rs:311-467
   // SNARK::prove (lib.rs:339-420). `tape_seed` replaces the OsRng draw of RandomTape::new (random.rs:13-15).
   static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
                      const FqVec& vars, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript, const Fq& tape_seed,
-                     ProveTimes* times = nullptr);
+                     ProveTimes* times = nullptr) {
+    return prove(ctx, inst, comm, decomm, vars.data(), vars.size(), inputs, gens, transcript, tape_seed, times);
+  }
+  // same, reading the assignment in place (a Rust `&[Scalar]` / a caller-owned buffer): no host-side copy
+  static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
+                     const Fq* vars, size_t num_vars_given, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript,
+                     const Fq& tape_seed, ProveTimes* times = nullptr);
   std::vector<uint8_t> serialize() const;  // bincode 1.3 default encoding
 };
 struct NIZK {  // lib.rs:488-587
   R1CSProof r1cs_sat_proof;
   FqVec rx, ry;
   static NIZK prove(Ctx& ctx, const Instance& inst, const FqVec& vars, const FqVec& inputs, const NIZKGens& gens, Transcript& transcript,
-                    const Fq& tape_seed, ProveTimes* times = nullptr);
+                    const Fq& tape_seed, ProveTimes* times = nullptr) {
+    return prove(ctx, inst, vars.data(), vars.size(), inputs, gens, transcript, tape_seed, times);
+  }
+  static NIZK prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t num_vars_given, const FqVec& inputs, const NIZKGens& gens,
+                    Transcript& transcript, const Fq& tape_seed, ProveTimes* times = nullptr);
   std::vector<uint8_t> serialize() const;
 };
 

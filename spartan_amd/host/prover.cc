@@ -592,17 +592,18 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
 }
 
 // ------------------------------------------------------------------ R1CSProof::prove (r1csproof.rs:144-349)
-static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const FqVec& vars, const FqVec& input, const R1CSGens& gens, Transcript& t,
-                            RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm) {
+static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& input, const R1CSGens& gens,
+                            Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm) {
   double t0 = now_s();
   t.append_protocol_name("R1CS proof");
-  REQUIRE(input.size() < vars.size());
-  REQUIRE(vars.size() == inst.num_vars && input.size() == inst.num_inputs);
+  // lib.rs:360-368 / 519-526: the assignment is zero-padded to the instance's (padded) num_vars — done in the device table
+  REQUIRE(nvars_given <= inst.num_vars && input.size() < inst.num_vars && input.size() == inst.num_inputs);
   t.append_scalars("input", input);
   R1CSProof P;
-  size_t num_vars = vars.size(), lv = log_2(num_vars);
+  size_t num_vars = inst.num_vars, lv = log_2(num_vars);
   // polycommit (:160-171)
-  DevTable poly_vars = tab_upload(c, vars);
+  DevTable poly_vars = tab_alloc(c, num_vars);  // zero-filled: implicit padding
+  if (nvars_given) SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
   FqVec blinds_vars = tape.random_vector("poly_blinds", pow2(lv / 2));
   P.comm_vars = poly_commit(c, poly_vars, lv, gens.gens_pc, &blinds_vars);
   append_poly_commitment(t, "poly_commitment", P.comm_vars);
@@ -689,20 +690,14 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const FqVec& vars, 
   return P;
 }
 
-static FqVec pad_vars_assignment(const Instance& inst, const FqVec& vars) {  // lib.rs:360-368, 519-526
-  FqVec v = vars;
-  if (inst.num_vars > v.size()) v.resize(inst.num_vars, fq_zero());
-  return v;
-}
-
-NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const FqVec& vars, const FqVec& inputs, const NIZKGens& gens, Transcript& t, const Fq& tape_seed,
-                 ProveTimes* tm) {  // lib.rs:501-546
+NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& inputs, const NIZKGens& gens, Transcript& t,
+                 const Fq& tape_seed, ProveTimes* tm) {  // lib.rs:501-546
   double t0 = now_s();
   RandomTape tape("proof", tape_seed);
   t.append_protocol_name("Spartan NIZK proof");
   t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());
   NIZK P;
-  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, pad_vars_assignment(inst, vars), inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm);
+  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, vars, nvars_given, inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm);
   if (tm) tm->total = now_s() - t0;
   return P;
 }
