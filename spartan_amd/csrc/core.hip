@@ -406,7 +406,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
   if (windowed) {
     P = ncol * MSM_NWIN;
   } else {
-    strip = total / 131072;
+    strip = total / 524288;  // enough threads for >= 4 waves per SIMD on 256 CUs
     if (strip < 1) strip = 1;
     if (strip > cols) strip = cols;
     nstrips = (cols + strip - 1) / strip;
