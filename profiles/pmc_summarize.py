@@ -5,7 +5,7 @@ requests at 64 B, i.e. reports half the bytes of a wide (16 B/lane) coalesced st
 16 B per lane (ulonglong2). WRITE_SIZE is uncalibrated on gfx950 (reported as is).
 usage: python profiles/pmc_summarize.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv"""
 import csv, json, sys, collections
-FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_windows": "msm_rows_fixed", "k_msm_reduce": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_compress",
+FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_reduce": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
           "k_cubic_bind_eval_batched": "sumcheck_bind_eval", "k_sc_bind_eval": "sumcheck_bind_eval", "k_sc_eval": "sumcheck_eval",
           "k_cubic_eval_batched": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand"}
 def load(path, counter):
@@ -23,8 +23,7 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
     print("%-32s %8d %16.0f %16.0f %16.0f" % (k[:32], nf[k], fb, wb, fb + wb))
     if k in FAMILY:
         fam_bytes[FAMILY[k]] += 2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024
-        if k in ("k_msm_rows", "k_msm_windows", "k_msm_reduce", "k_cubic_bind_eval_batched", "k_sc_bind_eval", "k_sc_eval", "k_cubic_eval_batched", "k_bind_top", "k_eq_expand"):
-            fam_n[FAMILY[k]] += nf[k]
+        fam_n[FAMILY[k]] += nf[k]
 out = {fam: fam_bytes[fam] / max(fam_n[fam], 1) for fam in fam_bytes}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print("\nper-family HBM bytes per launch (profiles/pmc_traffic.json):", json.dumps(out))

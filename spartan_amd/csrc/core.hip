@@ -1,7 +1,7 @@
 // spartan_amd: context, generators (window tables), fixed-base MSM, device tables.
 #include "internal.hpp"
 
-const char* kProfNames[PF_COUNT] = {"gens_table_build", "msm_rows_fixed", "msm_reduce_compress", "eq_expand", "sumcheck_eval",
+const char* kProfNames[PF_COUNT] = {"gens_table_build", "msm_rows_fixed", "msm_windows_fixed", "msm_reduce_pass", "msm_reduce_compress", "eq_expand", "sumcheck_eval",
                                     "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "misc"};
 
 int32_t ensure(void** p, size_t* cap, size_t need) {
@@ -154,10 +154,21 @@ __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __res
 __global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
                                                   size_t nstrips, const Niels* __restrict__ table, size_t g_off,
                                                   const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx,
-                                                  Pt* __restrict__ partial) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * nstrips) return;
-  size_t row = t % rows, s = t / rows;
+                                                  Pt* __restrict__ partial, int xcd_map) {
+  size_t row, s;
+  if (xcd_map) {
+    // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): all row-blocks of a column strip are
+    // given to the SAME XCD, back to back, so the strip's window tables are fetched into one L2 instead of eight.
+    size_t rb_count = rows / 256, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
+    s = xcd + 8 * (k / rb_count);
+    if (s >= nstrips) return;
+    row = (k % rb_count) * 256 + threadIdx.x;
+  } else {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * nstrips) return;
+    row = t % rows;
+    s = t / rows;
+  }
   Pt acc = pt_identity();
   size_t j0 = s * strip, j1 = j0 + strip;
   if (j1 > cols) j1 = cols;
@@ -421,26 +432,29 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
   Pt10* partial2 = (Pt10*)((uint8_t*)c->scratch + part_bytes);
   bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
   uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + part_bytes + part2_bytes;
-  {
+  if (windowed) {
+    ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * P));
+    size_t nthreads = rows * P;
+    hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols,
+                       (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
+  } else {
+    // K1: 32 B read per committed scalar + 32 B written per row
     ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
-    if (windowed) {
-      size_t nthreads = rows * P;
-      hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols,
-                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
-    } else {
-      size_t nthreads = rows * nstrips;
-      hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols, strip, nstrips,
-                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
-    }
+    int xcd_map = rows % 256 == 0;
+    size_t nblocks = xcd_map ? ((nstrips + 7) / 8) * 8 * (rows / 256) : (rows * nstrips + 255) / 256;
+    hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, c->stream, dZ, z_stride, rows, cols, strip, nstrips,
+                       (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map);
   }
-  {
-    ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * P * sizeof(Pt)));
-    if (two_pass) {
+  if (two_pass) {
+    {
+      ProfScope ps(c, PF_MSM_REDUCE_PASS, (double)(rows * P * sizeof(Pt)) + (double)(rows * nchunks * sizeof(Pt10)));
       hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)nchunks), dim3(256), 0, c->stream, (const Pt*)partial, P, chunk, partial2);
-      hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial2, nchunks, dout);
-    } else {
-      hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial, P, dout);
     }
+    ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * nchunks * sizeof(Pt10)) + 32.0 * (double)rows);
+    hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial2, nchunks, dout);
+  } else {
+    ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * P * sizeof(Pt)) + 32.0 * (double)rows);
+    hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial, P, dout);
   }
   if (small_out) SPCHK(fetch_small(c, out_host, 32 * rows));
   else SPCHK(fetch_out(c, dout, out_host, 32 * rows));

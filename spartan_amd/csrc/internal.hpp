@@ -20,6 +20,8 @@ using namespace sp;
 enum ProfFamily {
   PF_GENS_TABLE = 0,
   PF_MSM_ROWS,
+  PF_MSM_WINDOWS,
+  PF_MSM_REDUCE_PASS,
   PF_MSM_REDUCE,
   PF_EQ_EXPAND,
   PF_SC_EVAL,
