@@ -72,6 +72,14 @@ int32_t sp_commit_rows(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx
 /* Same with Z taken from a device table: elements [z_off, z_off + rows*cols). */
 int32_t sp_commit_rows_dev(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows,
                            size_t cols, const uint64_t* blinds, uint8_t* out);
+/* Background variant (no blinds): the commit is queued on a lower-priority HIP stream behind everything issued so far and
+ * runs concurrently with later calls on the context; sp_job_wait blocks, copies the 32*rows bytes out and frees the job.
+ * Used to overlap the row half of the SPARK `derefs` commitment (sparse_mlpoly.rs:1473-1478), which only depends on rx,
+ * with the latency-bound second sum-check of R1CSProof::prove. */
+typedef struct sp_job sp_job;
+int32_t sp_commit_rows_dev_begin(sp_ctx* ctx, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
+                                 sp_job** out);
+int32_t sp_job_wait(sp_job* job, uint8_t* out /*32*rows*/);
 /* Small/irregular commits (Scalar::commit, UniPoly::commit, the Sigma-protocol commitments of
  * src/nizk/mod.rs, the per-round L/R of src/nizk/bullet.rs:83-97 re-expressed over the ORIGINAL generators):
  * out[i] = compress( sum_j S[i*cols+j] * P[idx[j]] ). */

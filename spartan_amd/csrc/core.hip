@@ -300,6 +300,20 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   memset(c->prof_n, 0, sizeof c->prof_n);
   memset(c->prof_bytes, 0, sizeof c->prof_bytes);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    // Background stream confined to 7/8 of the CUs: a long-running MSM cannot be preempted, so without a reserve the
+    // latency-critical kernels of the main stream would queue behind its workgroups for milliseconds.
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0);
+    for (int i = 0; i < ncu; i++)
+      if (i % 8 != 7) mask[i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&c->stream_bg, (uint32_t)words, mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(hipStreamCreateWithFlags(&c->stream_bg, hipStreamNonBlocking));
+    }
+  }
   HIPCHK(hipHostMalloc((void**)&c->hmap, HMAP_SIZE, hipHostMallocDefault));
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
   *out = c;
@@ -318,6 +332,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->hmap) (void)hipHostFree(c->hmap);
   (void)hipEventDestroy(c->sync_ev);
+  (void)hipStreamDestroy(c->stream_bg);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -407,59 +422,136 @@ void sp_gens_free(sp_gens* g) {
   delete g;
 }
 
-// core: Z on device (row stride in elements), optional idx (device), optional blinds (device)
-int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
-  size_t total = rows * cols;
-  size_t ncol = cols + (dblinds ? 1 : 0);
-  bool windowed = rows * ncol * MSM_NWIN <= ((size_t)1 << 19);  // latency-bound shapes: one addition per thread
-  size_t strip = 1, nstrips = 0, P;
-  if (windowed) {
-    P = ncol * MSM_NWIN;
+// MSM launch plan: kernel shapes and scratch sizes for a (rows x cols) fixed-base commit
+struct MsmPlan {
+  bool windowed, two_pass;
+  size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
+};
+static MsmPlan msm_plan(size_t rows, size_t cols, bool has_blinds) {
+  MsmPlan m;
+  size_t total = rows * cols, ncol = cols + (has_blinds ? 1 : 0);
+  m.windowed = rows * ncol * MSM_NWIN <= ((size_t)1 << 19);  // latency-bound shapes: one addition per thread
+  m.strip = 1; m.nstrips = 0;
+  if (m.windowed) {
+    m.P = ncol * MSM_NWIN;
   } else {
-    strip = total / 524288;  // enough threads for >= 4 waves per SIMD on 256 CUs
-    if (strip < 1) strip = 1;
-    if (strip > cols) strip = cols;
-    nstrips = (cols + strip - 1) / strip;
-    P = nstrips;
+    m.strip = total / 524288;  // enough threads for >= 4 waves per SIMD on 256 CUs
+    if (m.strip < 1) m.strip = 1;
+    if (m.strip > cols) m.strip = cols;
+    m.nstrips = (cols + m.strip - 1) / m.strip;
+    m.P = m.nstrips;
   }
-  size_t chunk = 1024, nchunks = (P + chunk - 1) / chunk;
-  bool two_pass = P > 2048;
-  size_t part_bytes = (rows * P * sizeof(Pt) + 255) & ~(size_t)255;
-  size_t part2_bytes = two_pass ? ((rows * nchunks * sizeof(Pt10) + 255) & ~(size_t)255) : 0;
-  SPCHK(ensure(&c->scratch, &c->scratch_cap, part_bytes + part2_bytes + 32 * rows));
-  Pt* partial = (Pt*)c->scratch;
-  Pt10* partial2 = (Pt10*)((uint8_t*)c->scratch + part_bytes);
-  bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
-  uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + part_bytes + part2_bytes;
-  if (windowed) {
-    ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * P));
-    size_t nthreads = rows * P;
-    hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dZ, z_stride, rows, cols,
-                       (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial);
+  m.chunk = 1024; m.nchunks = (m.P + m.chunk - 1) / m.chunk;
+  m.two_pass = m.P > 2048;
+  m.part_bytes = (rows * m.P * sizeof(Pt) + 255) & ~(size_t)255;
+  m.part2_bytes = m.two_pass ? ((rows * m.nchunks * sizeof(Pt10) + 255) & ~(size_t)255) : 0;
+  return m;
+}
+// enqueue the kernels of one commit on `st`; scratch holds part_bytes + part2_bytes; dout receives 32*rows bytes
+static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows,
+                        size_t cols, size_t g_off, const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* scratch, uint8_t* dout) {
+  size_t total = rows * cols;
+  Pt* partial = (Pt*)scratch;
+  Pt10* partial2 = (Pt10*)(scratch + m.part_bytes);
+  sp_ctx* pc = prof ? c : nullptr;  // HIP-event timing only for work on the main stream
+  auto scope = [&](int fam, double bytes) { return ProfScope(pc ? pc : c, pc ? fam : -1, bytes); };
+  if (m.windowed) {
+    ProfScope ps = scope(PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * m.P));
+    size_t nthreads = rows * m.P;
+    hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, dZ, z_stride, rows, cols, (const Niels*)g->table,
+                       g_off, didx, dblinds, h_idx, partial);
   } else {
     // K1: 32 B read per committed scalar + 32 B written per row
-    ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
+    ProfScope ps = scope(PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
     int xcd_map = rows % 256 == 0;
-    size_t nblocks = xcd_map ? ((nstrips + 7) / 8) * 8 * (rows / 256) : (rows * nstrips + 255) / 256;
-    hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, c->stream, dZ, z_stride, rows, cols, strip, nstrips,
-                       (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map);
+    size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
+    hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips, (const Niels*)g->table,
+                       g_off, didx, dblinds, h_idx, partial, xcd_map);
   }
-  if (two_pass) {
+  if (m.two_pass) {
     {
-      ProfScope ps(c, PF_MSM_REDUCE_PASS, (double)(rows * P * sizeof(Pt)) + (double)(rows * nchunks * sizeof(Pt10)));
-      hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)nchunks), dim3(256), 0, c->stream, (const Pt*)partial, P, chunk, partial2);
+      ProfScope ps = scope(PF_MSM_REDUCE_PASS, (double)(rows * m.P * sizeof(Pt)) + (double)(rows * m.nchunks * sizeof(Pt10)));
+      hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)m.nchunks), dim3(256), 0, st, (const Pt*)partial, m.P, m.chunk, partial2);
     }
-    ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * nchunks * sizeof(Pt10)) + 32.0 * (double)rows);
-    hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial2, nchunks, dout);
+    ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.nchunks * sizeof(Pt10)) + 32.0 * (double)rows);
+    hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
   } else {
-    ProfScope ps(c, PF_MSM_REDUCE, (double)(rows * P * sizeof(Pt)) + 32.0 * (double)rows);
-    hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)partial, P, dout);
+    ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.P * sizeof(Pt)) + 32.0 * (double)rows);
+    hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
   }
+}
+// core: Z on device (row stride in elements), optional idx (device), optional blinds (device); synchronous
+int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
+  MsmPlan m = msm_plan(rows, cols, dblinds != nullptr);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + 32 * rows));
+  bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
+  uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + m.part_bytes + m.part2_bytes;
+  msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, dout);
   if (small_out) SPCHK(fetch_small(c, out_host, 32 * rows));
   else SPCHK(fetch_out(c, dout, out_host, 32 * rows));
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
   return SP_OK;
+}
+
+// ---- background commit (overlaps a throughput-bound MSM with the latency-bound rounds that follow on the main stream)
+struct sp_job {
+  sp_ctx* ctx;
+  uint8_t* scratch;
+  size_t scratch_bytes, rows;
+  hipEvent_t done;
+};
+int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
+                                 sp_job** out) {
+  if (!c || !g || !Z || !out || rows == 0 || cols == 0 || g_off + cols > g->n || z_off + rows * cols > Z->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  MsmPlan m = msm_plan(rows, cols, false);
+  sp_job* j = new (std::nothrow) sp_job();
+  if (!j) return SP_ENOMEM;
+  j->ctx = c; j->rows = rows; j->scratch = nullptr;
+  j->scratch_bytes = m.part_bytes + m.part2_bytes + ((32 * rows + 255) & ~(size_t)255);
+  int32_t rc = pool_alloc(c, j->scratch_bytes, (void**)&j->scratch);
+  if (rc != SP_OK) { delete j; return rc; }
+  hipEvent_t ready;
+  if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&j->done, hipEventDisableTiming) != hipSuccess) {
+    pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP;
+  }
+  // the job reads Z as produced by everything queued so far on the main stream
+  (void)hipEventRecord(ready, c->stream);
+  (void)hipStreamWaitEvent(c->stream_bg, ready, 0);
+  msm_enqueue(c, c->stream_bg, false, m, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, nullptr, 0, j->scratch,
+              j->scratch + m.part_bytes + m.part2_bytes);
+  (void)hipEventRecord(j->done, c->stream_bg);
+  (void)hipEventDestroy(ready);
+  if (hipGetLastError() != hipSuccess) { (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  *out = j;
+  return SP_OK;
+}
+int32_t sp_job_wait(sp_job* j, uint8_t* out) {
+  if (!j || !out) return SP_EINVAL;
+  sp_ctx* c = j->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  int32_t rc = SP_OK;
+  for (;;) {
+    hipError_t e = hipEventQuery(j->done);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) { rc = SP_EHIP; break; }
+  }
+  if (rc == SP_OK) {
+    MsmPlan m = msm_plan(j->rows, 1, false);  // only the sizes that depend on rows are needed below
+    (void)m;
+    // result sits at the tail of the job scratch
+    size_t off = j->scratch_bytes - ((32 * j->rows + 255) & ~(size_t)255);
+    if (hipMemcpyAsync(out, j->scratch + off, 32 * j->rows, hipMemcpyDeviceToHost, c->stream_bg) != hipSuccess ||
+        hipStreamSynchronize(c->stream_bg) != hipSuccess)
+      rc = SP_EHIP;
+  }
+  // the scratch goes back to the pool, which hands it to main-stream work: make that work wait for the job
+  (void)hipStreamWaitEvent(c->stream, j->done, 0);
+  (void)hipEventDestroy(j->done);
+  pool_release(c, j->scratch, j->scratch_bytes);
+  delete j;
+  return rc;
 }
 
 int32_t sp_commit_rows_dev(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows, size_t cols,

@@ -46,6 +46,7 @@ struct ProfRec {
 struct sp_ctx {
   int dev;
   hipStream_t stream;
+  hipStream_t stream_bg;  // lower-priority background stream: throughput MSMs overlapped with latency-bound rounds
   // scratch
   void* scratch;
   size_t scratch_cap;
@@ -102,7 +103,7 @@ struct ProfScope {
   int fam;
   hipEvent_t e0, e1;
   bool on;
-  ProfScope(sp_ctx* c_, int fam_, double bytes) : c(c_), fam(fam_), on(c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)) {
+  ProfScope(sp_ctx* c_, int fam_, double bytes) : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;

@@ -158,3 +158,28 @@ def test_vecmat_dot_evaluate_match_oracle(ctx, orc, v):
     orc.orc_dot(mont_array(Z), chi, sz(n), w)
     assert list(e) == list(w)
     t.free(); tb.free()
+
+
+def test_background_commit_overlaps_and_matches(ctx, orc, gens40):
+    """sp_commit_rows_dev_begin / sp_job_wait: the commit runs on the background stream while main-stream calls proceed;
+    both results are bit-exact (the job must observe Z as written before begin, and its scratch must not alias)."""
+    from spartan_amd import capi
+    rng = random.Random(77)
+    rows, cols = 512, 32   # large enough to take the strip kernel path (not the windowed one)
+    Z = rand_scalars(rng, rows * cols)
+    t = capi.Table.upload(ctx, mont_array(Z), rows * cols)
+    job = gens40.commit_rows_begin(t, rows, cols, g_off=2)
+    # main-stream work issued while the job is in flight
+    a = rand_scalars(rng, 1 << 12); b = rand_scalars(rng, 1 << 12)
+    ta = capi.Table.upload(ctx, mont_array(a), 1 << 12); tb = capi.Table.upload(ctx, mont_array(b), 1 << 12)
+    for _ in range(5):
+        d = capi.dot(ctx, ta, tb, 1 << 12)
+        assert from_mont_limbs(d) == sum(x * y for x, y in zip(a, b)) % Q
+    sync = gens40.commit_rows(t, rows, cols, None, g_off=2, h_idx=39)
+    got = gens40.commit_rows_wait(job)
+    assert got == sync
+    g = gens40.compressed
+    want = (ctypes.c_uint8 * (32 * 4))()
+    assert orc.orc_commit_rows(g[32 * 2:32 * (2 + cols)], sz(cols), g[32 * 39:], mont_array(Z[:4 * cols]), sz(4), sz(cols), None, want) == 0
+    assert got[:128] == bytes(want)
+    t.free(); ta.free(); tb.free()
