@@ -171,9 +171,9 @@ int32_t sp_product_tree(sp_ctx* ctx, sp_table* store, size_t n);
 /* prove_cubic_batched evaluations (sumcheck.rs:287-357): for each instance k, the sums of A_k*B_k*C_k at
  * t = 0, 2, 3 over the current length -> out[4*(3k + {0,1,2})]. Tables may repeat across instances. */
 int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out);
-/* Fused round: bind every A_k and B_k at r (in place, halving them), evaluate the next round on the bound
- * values; C tables are read and bound on the fly but NOT written — bind the distinct C tables afterwards
- * with sp_table_bind_top. Requires current length >= 4. */
+/* Fused round: bind every A_k, B_k and C_k at r (halving them) and evaluate the next round on the bound values in the
+ * same pass. A and B tables must be distinct; a C table may be shared by several instances (poly_C_par) and is bound
+ * once, out of place. Requires current length >= 4. */
 int32_t sp_sumcheck_bind_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst,
                                       const uint64_t r[4], uint64_t* out);
 /* out[k] = <chi, T_k> for k < nt (the ~23 DensePolynomial::evaluate calls of HashLayerProof::prove share chi). */

@@ -610,6 +610,9 @@ int32_t table_new(sp_ctx* c, size_t len, bool zero, sp_table** out) {
   t->cap = t->len = len;
   t->owner = 1;
   t->d = nullptr;
+  t->d_bytes = 32 * len;
+  t->alt = nullptr;
+  t->alt_bytes = 0;
   int32_t rc = pool_alloc(c, 32 * len, (void**)&t->d);
   if (rc != SP_OK) { delete t; return rc; }
   if (zero && hipMemsetAsync(t->d, 0, 32 * len, c->stream) != hipSuccess) { pool_release(c, t->d, 32 * len); delete t; return SP_EHIP; }
@@ -660,10 +663,31 @@ int32_t sp_table_copy(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* 
   return SP_OK;
 }
 size_t sp_table_len(const sp_table* t) { return t ? t->len : 0; }
+}  // extern "C"
+int32_t table_ensure_alt(sp_table* t, size_t elems) {
+  if (t->alt && t->alt_bytes >= 32 * elems) return SP_OK;
+  if (t->alt) pool_release(t->ctx, t->alt, t->alt_bytes);
+  t->alt = nullptr;
+  t->alt_bytes = 0;
+  SPCHK(pool_alloc(t->ctx, 32 * elems, (void**)&t->alt));
+  t->alt_bytes = 32 * elems;
+  return SP_OK;
+}
+void table_swap_to_alt(sp_table* t, size_t new_len) {
+  Fq* old = t->d;
+  int old_owned = t->owner;
+  size_t old_bytes = t->d_bytes;
+  t->d = t->alt; t->owner = 1; t->d_bytes = t->alt_bytes;
+  t->cap = t->alt_bytes / 32; t->len = new_len;
+  if (old_owned) { t->alt = old; t->alt_bytes = old_bytes; }
+  else { t->alt = nullptr; t->alt_bytes = 0; }  // a view's original storage belongs to its parent
+}
+extern "C" {
 void sp_table_free(sp_table* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->dev);
-  if (t->owner) pool_release(t->ctx, t->d, 32 * t->cap);
+  if (t->owner) pool_release(t->ctx, t->d, t->d_bytes);
+  if (t->alt) pool_release(t->ctx, t->alt, t->alt_bytes);
   delete t;
 }
 

@@ -78,10 +78,15 @@ struct sp_gens {
 };
 struct sp_table {
   sp_ctx* ctx;
-  Fq* d;
-  size_t cap, len;
-  int owner;  // 0 for views (sp_table_view)
+  Fq* d;           // current contents
+  size_t cap, len; // elements addressable through d / current (bound) length
+  int owner;       // d came from the pool (0 for views into another table)
+  size_t d_bytes;  // pool size of d when owned
+  Fq* alt;         // second pool buffer for out-of-place binds of tables shared between kernel instances
+  size_t alt_bytes;
 };
+int32_t table_ensure_alt(sp_table* t, size_t elems);
+void table_swap_to_alt(sp_table* t, size_t new_len);
 
 #define HIPCHK(x)                                                                                   \
   do {                                                                                              \

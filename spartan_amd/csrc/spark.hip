@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, s
 
 struct Triple {
   Fq *a, *b, *c;
+  Fq* c_out;  // where this instance writes the bound C (non-null for exactly one instance per distinct C table)
 };
 __device__ __forceinline__ void cubic_point(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c0, const Fq& c1, Fq (&e)[3]) {
   Fq a2 = fq_sub(fq_dbl(a1), a0), b2 = fq_sub(fq_dbl(b1), b0), c2 = fq_sub(fq_dbl(c1), c0);
@@ -65,9 +66,12 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* _
       Fq x0 = ld_fq(ptr[k] + i), x1 = ld_fq(ptr[k] + quarter + i), x2 = ld_fq(ptr[k] + 2 * quarter + i), x3 = ld_fq(ptr[k] + 3 * quarter + i);
       lo[k] = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
       hi[k] = fq_add(x1, fq_mul(r, fq_sub(x3, x1)));
-      if (k < 2) {  // C is shared between instances: bound separately afterwards
+      if (k < 2) {
         st_fq(ptr[k] + i, lo[k]);
         st_fq(ptr[k] + quarter + i, hi[k]);
+      } else if (t.c_out) {  // C may be shared between instances: bound out of place, once
+        st_fq(t.c_out + i, lo[k]);
+        st_fq(t.c_out + quarter + i, hi[k]);
       }
     }
     cubic_point(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], e);
@@ -77,6 +81,52 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* _
     Fq* p = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
     st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]);
   }
+}
+// Latency form of the fused round for short tables (quarter <= a few hundred): the ~12 dependent field
+// multiplications of one index are spread over 8 lanes (six do one bind each, then three do one evaluation point
+// each), so a round costs ~3 multiplications of latency instead of 12. Block = 32 indices x 8 roles; grid (nblk, ninst).
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+  __shared__ Fq bound[32][6];  // [index][table*2 + half]
+  __shared__ Fq red[3][32];
+  Triple t = T[blockIdx.y];
+  int li = threadIdx.x >> 3, role = threadIdx.x & 7;
+  size_t i = (size_t)blockIdx.x * 32 + li;
+  bool live = i < quarter;
+  if (role < 6 && live) {
+    int k = role >> 1, half = role & 1;
+    Fq* ptr = k == 0 ? t.a : (k == 1 ? t.b : t.c);
+    Fq x0 = ld_fq(ptr + (size_t)half * quarter + i), x2 = ld_fq(ptr + (size_t)(2 + half) * quarter + i);
+    Fq v = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
+    bound[li][role] = v;
+    if (k < 2) st_fq(ptr + (size_t)half * quarter + i, v);
+    else if (t.c_out) st_fq(t.c_out + (size_t)half * quarter + i, v);  // C may be shared between instances: bound out of place, once
+  }
+  __syncthreads();
+  if (role < 3) {
+    Fq e = fq_zero();
+    if (live) {
+      // the three evaluation points run the SAME instruction stream (no divergence inside the wave): the value of a
+      // table's line at t = 0, 2, 3 is selected per lane, then one product of three
+      Fq a0 = bound[li][0], a1 = bound[li][1], b0 = bound[li][2], b1 = bound[li][3], c0 = bound[li][4], c1 = bound[li][5];
+      Fq a2 = fq_sub(fq_dbl(a1), a0), b2 = fq_sub(fq_dbl(b1), b0), c2 = fq_sub(fq_dbl(c1), c0);
+      Fq a3 = fq_sub(fq_add(a2, a1), a0), b3 = fq_sub(fq_add(b2, b1), b0), c3 = fq_sub(fq_add(c2, c1), c0);
+      Fq av, bv, cv;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        av.l[k] = role == 0 ? a0.l[k] : (role == 1 ? a2.l[k] : a3.l[k]);
+        bv.l[k] = role == 0 ? b0.l[k] : (role == 1 ? b2.l[k] : b3.l[k]);
+        cv.l[k] = role == 0 ? c0.l[k] : (role == 1 ? c2.l[k] : c3.l[k]);
+      }
+      e = fq_mul(fq_mul(av, bv), cv);
+    }
+    red[role][li] = e;
+  }
+  __syncthreads();
+  for (int s = 16; s > 0; s >>= 1) {
+    if (role < 3 && li < s) red[role][li] = fq_add(red[role][li], red[role][li + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) st_fq(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x, red[threadIdx.x][0]);
 }
 // partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
 __global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
@@ -152,7 +202,7 @@ int32_t sp_table_view(sp_ctx* c, const sp_table* parent, size_t off, size_t len,
   if (!c || !parent || !out || len == 0 || off + len > parent->cap) return SP_EINVAL;
   sp_table* t = new (std::nothrow) sp_table();
   if (!t) return SP_ENOMEM;
-  t->ctx = c; t->d = parent->d + off; t->cap = t->len = len; t->owner = 0;
+  t->ctx = c; t->d = parent->d + off; t->cap = t->len = len; t->owner = 0; t->d_bytes = 0; t->alt = nullptr; t->alt_bytes = 0;
   *out = t;
   return SP_OK;
 }
@@ -191,15 +241,25 @@ int32_t sp_product_tree(sp_ctx* c, sp_table* store, size_t n) {
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
-static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t* len_out) {
+static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t* len_out, bool bind_c) {
   if (!c || !A || !B || !C || ninst == 0 || ninst > 64) return SP_EINVAL;
   size_t len = A[0] ? A[0]->len : 0;
   std::vector<Triple> T(ninst);
   for (size_t k = 0; k < ninst; k++) {
     if (!A[k] || !B[k] || !C[k] || A[k]->len != len || B[k]->len != len || C[k]->len != len) return SP_EINVAL;
-    T[k] = Triple{A[k]->d, B[k]->d, C[k]->d};
+    T[k] = Triple{A[k]->d, B[k]->d, C[k]->d, nullptr};
   }
   if (len < 2 || !is_pow2(len)) return SP_EINVAL;
+  if (bind_c) {
+    for (size_t k = 0; k < ninst; k++) {
+      bool first = true;
+      for (size_t m = 0; m < k; m++) first = first && C[m] != C[k];
+      if (first) {
+        SPCHK(table_ensure_alt(C[k], len / 2));
+        T[k].c_out = C[k]->alt;
+      }
+    }
+  }
   stage_small(c, 0, T.data(), sizeof(Triple) * ninst);
   *len_out = len;
   return SP_OK;
@@ -216,7 +276,7 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   if (!out) return SP_EINVAL;
   size_t len;
   HIPCHK(hipSetDevice(c ? c->dev : 0));
-  SPCHK(batched_setup(c, A, B, C, ninst, &len));
+  SPCHK(batched_setup(c, A, B, C, ninst, &len, false));
   size_t half = len / 2, nblk = half <= 256 ? 1 : grid_for(half, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
   Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
@@ -231,18 +291,30 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   if (!out || !r) return SP_EINVAL;
   size_t len;
   HIPCHK(hipSetDevice(c ? c->dev : 0));
-  SPCHK(batched_setup(c, A, B, C, ninst, &len));
+  if (!c) return SP_EINVAL;
+  for (size_t k = 0; k < ninst && C; k++)
+    if (C[k] && C[k]->len < 4) return SP_EINVAL;
+  SPCHK(batched_setup(c, A, B, C, ninst, &len, true));
   if (len < 4) return SP_EINVAL;
-  size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 256);
+  size_t quarter = len / 4;
+  bool tiny = quarter <= 512;  // latency-bound rounds: one index per 8 lanes
+  size_t nblk = tiny ? (quarter + 31) / 32 : grid_for(quarter, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
   Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst);
-    hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
-                       limbs(r), partials);
+    if (tiny)
+      hipLaunchKernelGGL(k_cubic_bind_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
+                         limbs(r), partials);
+    else
+      hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
+                         limbs(r), partials);
   }
-  // A_k and B_k are now bound (distinct tables assumed for A and B)
+  // A_k and B_k are now bound in place (distinct tables assumed for A and B); each distinct C was bound into its
+  // alternate buffer by the first instance that uses it: make that buffer current
   for (size_t k = 0; k < ninst; k++) { A[k]->len = len / 2; B[k]->len = len / 2; }
+  for (size_t k = 0; k < ninst; k++)
+    if (C[k]->len == len) table_swap_to_alt(C[k], len / 2);
   return batched_finish(c, partials, nblk, ninst, out);
 }
 int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out) {
