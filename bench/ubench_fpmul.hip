@@ -9,6 +9,7 @@
 #include <vector>
 typedef unsigned __int128 u128;
 #define HD __host__ __device__ __forceinline__
+#include "../spartan_amd/csrc/curve.hpp"  // the product library's own field code (fp_mul, fp_mul_lat, fe10_mul, pt_madd)
 
 // ---------- A: 8x32 saturated, operand scanning, fold 2^256 = 38 ----------
 struct FA { uint32_t v[8]; };
@@ -292,7 +293,7 @@ template <int V> __global__ void k_chain(uint32_t* out, const uint32_t* in, int 
     for (int it = 0; it < iters; it++) { x = mulC(x, y); x2 = mulC(x2, y2); y.v[0] ^= x2.v[1] & 0xffff; y2.v[0] ^= x.v[1] & 0xffff; }
     uint32_t s = 0; for (int i = 0; i < 10; i++) s ^= x.v[i] ^ x2.v[i]; out[tid] = s;
   } else if (V == 3) {
-    FD x, y; for (int i = 0; i < 4; i++) { x.v[i] = in[i] + tid; y.v[i] = in[8 + i] ^ tid; }
+    FD x, y; for (int i = 0; i < 4; i++) { x.v[i] = (((uint64_t)in[(2 * i + 1) & 7] << 32) | in[(2 * i) & 7]) + tid; y.v[i] = (((uint64_t)in[8 + ((2 * i + 1) & 7)] << 32) | in[8 + ((2 * i) & 7)]) ^ tid; }
     FD x2 = y, y2 = x;
     for (int it = 0; it < iters; it++) { x = mulD(x, y); x2 = mulD(x2, y2); y.v[0] ^= x2.v[1]; y2.v[0] ^= x.v[1]; }
     uint64_t s = 0; for (int i = 0; i < 4; i++) s ^= x.v[i] ^ x2.v[i]; out[tid] = (uint32_t)s;
@@ -301,6 +302,30 @@ template <int V> __global__ void k_chain(uint32_t* out, const uint32_t* in, int 
     FE x2 = y, y2 = x;
     for (int it = 0; it < iters; it++) { x = mulE(x, y); x2 = mulE(x2, y2); y.v[0] ^= x2.v[1] & 0xffff; y2.v[0] ^= x.v[1] & 0xffff; }
     uint64_t s = 0; for (int i = 0; i < 5; i++) s ^= x.v[i] ^ x2.v[i]; out[tid] = (uint32_t)s;
+  }
+}
+// the product library's multipliers in the same 2-chain harness, and its mixed addition
+template <int V> __global__ void k_lib(uint32_t* out, const uint32_t* in, int iters) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  sp::Fp x, y;
+  for (int i = 0; i < 4; i++) { x.v[i] = ((uint64_t)in[2 * i + 1] << 32 | in[2 * i]) + tid; y.v[i] = ((uint64_t)in[8 + ((2 * i + 1) & 7)] << 32 | in[8 + ((2 * i) & 7)]) ^ tid; }
+  if (V == 0 || V == 1) {
+    sp::Fp x2 = y, y2 = x;
+    for (int it = 0; it < iters; it++) {
+      if (V == 0) { x = sp::fp_mul(x, y); x2 = sp::fp_mul(x2, y2); }
+      else { x = sp::fp_mul_lat(x, y); x2 = sp::fp_mul_lat(x2, y2); }
+      y.v[0] ^= x2.v[1]; y2.v[0] ^= x.v[1];
+    }
+    uint64_t s = 0; for (int i = 0; i < 4; i++) s ^= x.v[i] ^ x2.v[i]; out[tid] = (uint32_t)s;
+  } else if (V == 2) {
+    sp::Fe10 a = sp::fe10_load(x), b = sp::fe10_load(y), a2 = b, b2 = a;
+    for (int it = 0; it < iters; it++) { a = sp::fe10_mul(a, b); a2 = sp::fe10_mul(a2, b2); b.v[0] ^= a2.v[1] & 0xff; b2.v[0] ^= a.v[1] & 0xff; }
+    uint32_t s = 0; for (int i = 0; i < 10; i++) s ^= (uint32_t)(a.v[i] ^ a2.v[i]); out[tid] = s;
+  } else {
+    sp::Pt acc = sp::pt_identity();
+    sp::Niels n{x, y, sp::fp_add(x, y)};
+    for (int it = 0; it < iters; it++) { acc = sp::pt_madd(acc, n, it & 1); n.yp.v[0] ^= acc.X.v[1]; }
+    uint64_t s = 0; for (int i = 0; i < 4; i++) s ^= acc.X.v[i] ^ acc.Y.v[i] ^ acc.Z.v[i] ^ acc.T.v[i]; out[tid] = (uint32_t)s;
   }
 }
 // raw instruction-rate probes
@@ -393,6 +418,10 @@ int main(int argc, char** argv) {
   ms = timeit([&] { k_chain<3><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[3], ms, nmul / ms / 1e6);
   ms = timeit([&] { k_chain<4><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[4], ms, nmul / ms / 1e6);
   ms = timeit([&] { k_chain<5><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[5], ms, nmul / ms / 1e6);
+  ms = timeit([&] { k_lib<0><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fp_mul (4x64 op-scan)", ms, nmul / ms / 1e6);
+  ms = timeit([&] { k_lib<1><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fp_mul_lat (ILP form)", ms, nmul / ms / 1e6);
+  ms = timeit([&] { k_lib<2><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fe10_mul (10x25.5 s)", ms, nmul / ms / 1e6);
+  ms = timeit([&] { k_lib<3><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gadd/s (x7 = %.1f Gmul/s)\n", "lib pt_madd", ms, 0.5 * nmul / ms / 1e6, 3.5 * nmul / ms / 1e6);
   double nop = 64.0 * blocks * threads * 1024;
   ms = timeit([&] { k_mad64<<<blocks, threads>>>(out, 1024); }, 5); printf("v_mad_u64_u32          %8.3f ms  %8.2f Gop/s (lane-ops)\n", ms, nop / ms / 1e6);
   ms = timeit([&] { k_mullo<<<blocks, threads>>>(out, 1024); }, 5); printf("v_mul_lo_u32(+add)     %8.3f ms  %8.2f Gop/s\n", ms, nop / ms / 1e6);

@@ -5,8 +5,9 @@
 //       residue x*2^256 mod q, always fully reduced to [0,q) (reference: src/scalar/ristretto255.rs:199,
 //       248-328, 642-760), so device buffers are bit-compatible with a Rust `&[Scalar]`.
 //   Fp  base field of edwards25519, p = 2^255 - 19. 4x64 saturated limbs, weakly reduced (any value in
-//       [0,2^256) congruent to the element); 2^256 = 38 (mod p) folds carries. Chosen from
-//       bench/ubench_fpmul.hip on MI355X: 4x64 via __int128 = 190 Gmul/s vs 151 (8x32) / 154 (10x25.5).
+//       [0,2^256) congruent to the element); 2^256 = 38 (mod p) folds carries. bench/ubench_fpmul.hip on
+//       MI355X, full-width operands: 4x64 via __int128 = 156 Gmul/s, 8x32 = 153, 10x25.5 = 154 — all within 5 %
+//       (the 32x32 multiplier rate is what binds), so the layout that is also the natural host form was kept.
 //
 // Everything is SP_HD (host+device) so the very same source is unit-tested on the CPU against the oracle
 // (tests/csrc/hostcheck.cc) and then runs on gfx950.
@@ -235,31 +236,41 @@ SP_HD Fp fp_sub(const Fp& a, const Fp& b) {
 SP_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 
 SP_HD Fp fp_reduce512(const uint64_t t[8]) {
-  // lo + 38*hi
+  // lo + 38*hi ; written with a 64-bit running carry (this exact shape measured fastest in bench/ubench_fpmul.hip)
   Fp r;
-  u128 c = 0;
+  uint64_t c = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    c += (u128)t[i + 4] * 38 + t[i];
-    r.v[i] = (uint64_t)c;
-    c >>= 64;
+    u128 x = (u128)t[i + 4] * 38u + t[i] + c;
+    r.v[i] = (uint64_t)x;
+    c = (uint64_t)(x >> 64);
   }
-  uint64_t c2 = fp_add_small(r, 38 * (uint64_t)c);  // c < 39
-  r.v[0] += 38 * c2;
+  u128 x = (u128)c * 38u + r.v[0];  // c < 39
+  r.v[0] = (uint64_t)x;
+  uint64_t cc = (uint64_t)(x >> 64);
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    u128 s = (u128)r.v[i] + cc;
+    r.v[i] = (uint64_t)s;
+    cc = (uint64_t)(s >> 64);
+  }
+  r.v[0] += cc * 38u;  // a second wrap leaves r < 2^64: cannot carry
   return r;
 }
 SP_HD Fp fp_mul(const Fp& a, const Fp& b) {
-  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    u128 c = 0;
+    uint64_t c = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      c += (u128)a.v[i] * b.v[j] + t[i + j];
-      t[i + j] = (uint64_t)c;
-      c >>= 64;
+      u128 x = (u128)a.v[i] * b.v[j] + t[i + j] + c;
+      t[i + j] = (uint64_t)x;
+      c = (uint64_t)(x >> 64);
     }
-    t[i + 4] = (uint64_t)c;
+    t[i + 4] = c;
   }
   return fp_reduce512(t);
 }
