@@ -188,3 +188,37 @@ def test_padded_constraints_like_reference(P, ctx, orc):
     with pytest.raises(P.SpartanHipError, match="InvalidIndex"):
         P.Instance.new(ctx, num_cons, num_vars, num_inputs, nnz, bad_rows, cols, vals)
     ngens.free(); enc.free(); gens.free(); inst.free()
+
+
+def test_concurrent_contexts_produce_identical_proofs(P, orc):
+    """Three contexts on the same GPU proving from three host threads at once (bench.py's throughput mode): every proof
+    equals its single-stream bytes, which equal the oracle's."""
+    import threading
+    s_ = 9; N = 1 << s_
+    work = []
+    for k in range(3):
+        c = P.Ctx(0)
+        inst = P.Instance.produce_synthetic_r1cs(c, N, N, 10, seed=50 + k)
+        gens = P.SNARKGens(c, N, N, 10, N)
+        enc = P.SNARK.encode(c, inst, gens)
+        tape = P.seed_scalar(b"tape", 50 + k)
+        single = P.SNARK.prove(c, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+        work.append([c, inst, gens, enc, tape, single, []])
+
+    def run(w):
+        for _ in range(4):
+            w[6].append(P.SNARK.prove(w[0], w[1], w[3], w[1].vars, w[1].inputs, w[2], b"snark_example", w[4]))
+    ths = [threading.Thread(target=run, args=(w,)) for w in work]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    for k, w in enumerate(work):
+        assert len(w[6]) == 4 and all(p == w[5] for p in w[6])
+    # one of them against the oracle
+    k = 1
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(50 + k)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", work[k][4], None))
+    assert oracle_bytes(orc, op) == work[k][5]
+    for w in work:
+        w[3].free(); w[2].free(); w[1].free(); w[0].close()
