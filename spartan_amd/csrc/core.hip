@@ -131,19 +131,29 @@ __global__ void k_points_load(const uint8_t* __restrict__ in, int mode, size_t n
   }
   pts[i] = p;
 }
-// stage 2: one thread per (point, window): entries k * 2^(8w) * P, k = 1..128, affine Niels.
+// stage 2: one thread per (point, window, chunk of TB_CHUNK magnitudes): entries k * 2^(c w) * P in affine Niels form.
+constexpr int TB_CHUNK = MSM_TENT < 128 ? MSM_TENT : 128;
+constexpr int TB_NCHUNK = MSM_TENT / TB_CHUNK;
 __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __restrict__ table) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * MSM_NWIN) return;
-  size_t pt = t / MSM_NWIN;
-  int w = (int)(t % MSM_NWIN);
+  if (t >= n * MSM_NWIN * TB_NCHUNK) return;
+  int ck = (int)(t % TB_NCHUNK);
+  size_t pw = t / TB_NCHUNK;
+  size_t pt = pw / MSM_NWIN;
+  int w = (int)(pw % MSM_NWIN);
   Pt base = pts[pt];
   for (int k = 0; k < MSM_WBITS * w; k++) base = pt_dbl(base);
-  Pt acc = base;
-  for (int m = 1; m <= MSM_TENT; m++) {
+  // first multiple of this chunk: (ck * TB_CHUNK + 1) * base by double-and-add
+  int m0 = ck * TB_CHUNK + 1;
+  Pt acc = pt_identity();
+  for (int b = 15; b >= 0; b--) {
+    acc = pt_dbl(acc);
+    if ((m0 >> b) & 1) acc = pt_add(acc, base);
+  }
+  for (int m = m0; m < m0 + TB_CHUNK; m++) {
     Fp zinv = fp_invert(acc.Z);
     table[msm_tidx(pt, w, m)] = pt_to_niels(acc, zinv);
-    if (m < MSM_TENT) acc = pt_add(acc, base);
+    if (m + 1 < m0 + TB_CHUNK) acc = pt_add(acc, base);
   }
 }
 
@@ -197,12 +207,7 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
   Pt acc = pt_identity();
   if (!fq_is_zero(sc)) {
     Fq s = fq_from_mont(sc);
-    int carry = 0, d = 0;
-    for (int k = 0; k <= w; k++) {  // signed recoding: the carry into window w depends on all lower windows
-      d = (int)((s.l[k >> 3] >> ((k & 7) * 8)) & 0xff) + carry;
-      carry = d > 127;
-      d -= carry << 8;
-    }
+    int d = msm_digit(s, w);
     if (d != 0) acc = pt_madd(acc, table[msm_tidx(pt, w, d < 0 ? -d : d)], d < 0);
   }
   partial[row * (ncol * MSM_NWIN) + (size_t)w * ncol + j] = acc;
@@ -390,7 +395,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     ProfScope ps(c, PF_GENS_TABLE, (double)n * MSM_PT_ENTRIES * sizeof(Niels));
     hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
                        (mode == 1 && comp_out) ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
-    size_t nt = n * MSM_NWIN;
+    size_t nt = n * MSM_NWIN * TB_NCHUNK;
     hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table);
   }
   int bad = 0;

@@ -5,38 +5,57 @@
 // DensePolynomial::commit_inner (src/dense_mlpoly.rs:164-177), the 2..5-point Sigma-protocol commitments
 // (src/nizk/mod.rs) and — after re-expressing the folded generators of BulletReductionProof::prove
 // (src/nizk/bullet.rs:83-109) over the original ones — the inner-product argument too. So the device keeps,
-// per generator P and per signed 8-bit window w, the 128 multiples k*2^(8w)*P (k=1..128) in affine Niels
-// form; a 253-bit scalar costs at most 32 mixed additions and no doublings.
+// per generator P and per signed c-bit window w, the 2^(c-1) multiples k*2^(cw)*P in affine Niels form; a
+// 253-bit scalar costs at most ceil(254/c) mixed additions and no doublings (c = SP_MSM_WBITS).
 #pragma once
 #include "curve.hpp"
 
 namespace sp {
 
-constexpr int MSM_WBITS = 8;
-constexpr int MSM_NWIN = 32;                      // 32 * 8 = 256 bits >= 253 + carry
-constexpr int MSM_TENT = 1 << (MSM_WBITS - 1);    // 128 entries per (point, window)
+#ifndef SP_MSM_WBITS
+#define SP_MSM_WBITS 12  // measured on MI355X at 2^20: c = 8 / 10 / 12 / 13 -> row commit 2.29 / 2.25 / 1.93 / 1.79 ms, proof 88.5 / 84.3 / 82.1 / 82.4 ms
+#endif
+constexpr int MSM_WBITS = SP_MSM_WBITS;                        // signed window width c
+constexpr int MSM_NWIN = (254 + MSM_WBITS - 1) / MSM_WBITS;     // windows covering a 253-bit scalar plus the recoding carry
+constexpr int MSM_TENT = 1 << (MSM_WBITS - 1);                 // entries per (point, window): magnitudes 1..2^(c-1)
 constexpr size_t MSM_PT_ENTRIES = (size_t)MSM_NWIN * MSM_TENT;
+static_assert(MSM_WBITS >= 4 && MSM_WBITS <= 15, "window width");
 
-// index of entry (point pt, window w, magnitude m in 1..128)
+// index of entry (point pt, window w, magnitude m in 1..MSM_TENT)
 SP_HD size_t msm_tidx(size_t pt, int w, int m) { return (pt * MSM_NWIN + (size_t)w) * MSM_TENT + (size_t)(m - 1); }
 
-// signed 8-bit recoding of a canonical scalar (< 2^253): digits d_w in [-128, 127], sum d_w 2^(8w) = s.
-// mag[w] = |d_w| (0..128) packed 4 per word, neg bit w = (d_w < 0).
-SP_HD void msm_recode(const Fq& s, uint32_t mag[8], uint32_t* neg) {
+// raw c-bit field of a canonical 256-bit integer at window w
+SP_HD uint32_t msm_field(const Fq& s, int w) {
+  int bit = w * MSM_WBITS, k = bit >> 6, sh = bit & 63;
+  if (k > 3) return 0;
+  uint64_t x = s.l[k] >> sh;
+  if (sh + MSM_WBITS > 64 && k < 3) x |= s.l[k + 1] << (64 - sh);
+  return (uint32_t)(x & ((1u << MSM_WBITS) - 1));
+}
+// signed recoding of a canonical scalar (< 2^253): digits d_w in [-2^(c-1), 2^(c-1) - 1], sum d_w 2^(c w) = s.
+// mag[w] = |d_w| (0..2^(c-1)), neg bit w = (d_w < 0).
+SP_HD void msm_recode(const Fq& s, uint16_t mag[MSM_NWIN], uint32_t* neg) {
   int carry = 0;
   uint32_t ng = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) mag[k] = 0;
-#pragma unroll
   for (int w = 0; w < MSM_NWIN; w++) {
-    int d = (int)((s.l[w >> 3] >> ((w & 7) * 8)) & 0xff) + carry;
-    carry = d > 127;
-    d -= carry << 8;
-    uint32_t m = (uint32_t)(d < 0 ? -d : d);
-    mag[w >> 2] |= m << ((w & 3) * 8);
+    int d = (int)msm_field(s, w) + carry;
+    carry = d >= MSM_TENT;
+    d -= carry << MSM_WBITS;
+    mag[w] = (uint16_t)(d < 0 ? -d : d);
     ng |= (uint32_t)(d < 0) << w;
   }
   *neg = ng;
+}
+// digit of window w only (latency-bound kernels: one thread per window)
+SP_HD int msm_digit(const Fq& s, int w) {
+  int carry = 0, d = 0;
+  for (int k = 0; k <= w; k++) {  // the carry into window w depends on all lower windows
+    d = (int)msm_field(s, k) + carry;
+    carry = d >= MSM_TENT;
+    d -= carry << MSM_WBITS;
+  }
+  return d;
 }
 
 // acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar. The table entry of the
@@ -44,14 +63,15 @@ SP_HD void msm_recode(const Fq& s, uint32_t mag[8], uint32_t* neg) {
 SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) {
   if (fq_is_zero(s_mont)) return;
   Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
-  uint32_t mag[8], neg;
+  uint16_t mag[MSM_NWIN];
+  uint32_t neg;
   msm_recode(s, mag, &neg);
   const Niels* base = table + pt * MSM_PT_ENTRIES;
-  uint32_t m = mag[0] & 0xff;
+  uint32_t m = mag[0];
   Niels cur = base[m ? m - 1 : 0];
-#pragma unroll 1
+#pragma unroll
   for (int w = 0; w < MSM_NWIN; w++) {
-    uint32_t mn = (w + 1 < MSM_NWIN) ? (mag[(w + 1) >> 2] >> (((w + 1) & 3) * 8)) & 0xff : 0;
+    uint32_t mn = (w + 1 < MSM_NWIN) ? mag[w + 1] : 0;
     Niels nxt = base[(size_t)((w + 1 < MSM_NWIN) ? w + 1 : w) * MSM_TENT + (mn ? mn - 1 : 0)];
     if (m != 0) acc = pt_madd(acc, cur, (neg >> w) & 1);
     cur = nxt;

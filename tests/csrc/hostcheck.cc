@@ -50,15 +50,27 @@ int hc_pt_dbl(const uint8_t* a, uint8_t* out) { Pt p; if (!pt_decompress(a, &p))
 // fixed-base table MSM exactly as the device does it: build tables like k_table_build, accumulate like k_msm_rows
 int hc_msm_fixed(const uint8_t* pts_comp, size_t n, const uint64_t* scalars, uint8_t* out) {
   std::vector<Niels> table(n * MSM_PT_ENTRIES);
+  std::vector<Pt> mults(MSM_TENT);
   for (size_t i = 0; i < n; i++) {
     Pt P;
     if (!pt_decompress(pts_comp + 32 * i, &P)) return 0;
     Pt base = P;
     for (int w = 0; w < MSM_NWIN; w++) {
+      // multiples 1..MSM_TENT with one inversion for the whole window (Montgomery's trick) — test helper only
       Pt acc = base;
+      std::vector<Fp> pref(MSM_TENT);
+      Fp run = fp_one();
       for (int m = 1; m <= MSM_TENT; m++) {
-        table[msm_tidx(i, w, m)] = pt_to_niels(acc, fp_invert(acc.Z));
+        mults[m - 1] = acc;
+        pref[m - 1] = run;
+        run = fp_mul(run, acc.Z);
         if (m < MSM_TENT) acc = pt_add(acc, base);
+      }
+      Fp inv = fp_invert(run);
+      for (int m = MSM_TENT; m >= 1; m--) {
+        Fp zinv = fp_mul(inv, pref[m - 1]);
+        inv = fp_mul(inv, mults[m - 1].Z);
+        table[msm_tidx(i, w, m)] = pt_to_niels(mults[m - 1], zinv);
       }
       for (int k = 0; k < MSM_WBITS; k++) base = pt_dbl(base);
     }
