@@ -30,7 +30,7 @@ def dist_setup(n_gpus):
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo for the CPU tests
     if backend == "nccl":
         import torch
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", str(rank))))
+        torch.cuda.set_device(int(os.environ.get("BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", str(rank)))))
     dist.init_process_group(backend=backend)
     return rank, world, dist
 
@@ -133,6 +133,8 @@ def main():
 
     rank, world, dist = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (with BENCH_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the prover has no CPU path")

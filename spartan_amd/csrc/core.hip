@@ -543,8 +543,6 @@ int32_t sp_job_wait(sp_job* j, uint8_t* out) {
     if (e != hipErrorNotReady) { rc = SP_EHIP; break; }
   }
   if (rc == SP_OK) {
-    MsmPlan m = msm_plan(j->rows, 1, false);  // only the sizes that depend on rows are needed below
-    (void)m;
     // result sits at the tail of the job scratch
     size_t off = j->scratch_bytes - ((32 * j->rows + 255) & ~(size_t)255);
     if (hipMemcpyAsync(out, j->scratch + off, 32 * j->rows, hipMemcpyDeviceToHost, c->stream_bg) != hipSuccess ||
