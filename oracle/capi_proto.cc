@@ -293,3 +293,32 @@ void* orc_instance_new_padded(size_t num_cons, size_t num_vars, size_t num_input
   return h;
 }
 }
+
+// ---- wire formats of public parameters and the computation commitment (serde derives; bincode 1.3) ----
+namespace {
+struct Wb { std::vector<uint8_t> b; void u64(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+            void pt(const Pt& p) { uint8_t c[32]; pt_compress(p, c); b.insert(b.end(), c, c + 32); } };
+void wb_mcg(Wb& w, const MultiCommitGens& g) { w.u64(g.n); w.u64(g.G.size()); for (auto& p : g.G) w.pt(p); w.pt(g.h); }  // commitments.rs:7-12
+void wb_pcg(Wb& w, const PolyCommitmentGens& g) { w.u64(g.gens.n); wb_mcg(w, g.gens.gens_n); wb_mcg(w, g.gens.gens_1); }   // dense_mlpoly.rs:24, nizk/mod.rs:407
+}  // namespace
+extern "C" {
+size_t orc_snark_gens_bincode(void* gv, uint8_t* out, size_t cap) {  // lib.rs:278-282
+  const SNARKGens& g = ((SnarkGensH*)gv)->g;
+  Wb w;
+  wb_mcg(w, g.gens_r1cs_sat.gens_sc.gens_1); wb_mcg(w, g.gens_r1cs_sat.gens_sc.gens_3); wb_mcg(w, g.gens_r1cs_sat.gens_sc.gens_4);
+  wb_pcg(w, g.gens_r1cs_sat.gens_pc);
+  wb_pcg(w, g.gens_r1cs_eval.gens_ops); wb_pcg(w, g.gens_r1cs_eval.gens_mem); wb_pcg(w, g.gens_r1cs_eval.gens_derefs);
+  if (out && cap >= w.b.size()) memcpy(out, w.b.data(), w.b.size());
+  return w.b.size();
+}
+size_t orc_commitment_bincode(void* ev, uint8_t* out, size_t cap) {  // lib.rs:44-48 -> r1cs.rs:50-56, sparse_mlpoly.rs:320-327
+  const R1CSCommitment& c = ((EncH*)ev)->comm;
+  Wb w;
+  w.u64(c.num_cons); w.u64(c.num_vars); w.u64(c.num_inputs);
+  w.u64(c.comm.batch_size); w.u64(c.comm.num_ops); w.u64(c.comm.num_mem_cells);
+  w.u64(c.comm.comm_comb_ops.C.size()); for (auto& x : c.comm.comm_comb_ops.C) w.b.insert(w.b.end(), x.begin(), x.end());
+  w.u64(c.comm.comm_comb_mem.C.size()); for (auto& x : c.comm.comm_comb_mem.C) w.b.insert(w.b.end(), x.begin(), x.end());
+  if (out && cap >= w.b.size()) memcpy(out, w.b.data(), w.b.size());
+  return w.b.size();
+}
+}

@@ -88,6 +88,13 @@ size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
   if (out && cap >= v.size()) memcpy(out, v.data(), v.size());
   return v.size();
 }
+// bincode of SNARKGens / ComputationCommitment (wire formats)
+size_t spz_snark_gens_bincode(void* g, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> b = ((SNARKGens*)g)->serialize();
+  if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
+  return b.size();
+}
+size_t spz_commitment_bincode(void* e, uint8_t* out, size_t cap);
 void* spz_snark_encode(void* ctx, void* inst, void* gens) {
   return guard([&]() -> void* {
     EncH* e = new EncH;
@@ -101,6 +108,11 @@ void* spz_snark_encode(void* ctx, void* inst, void* gens) {
   });
 }
 void spz_encode_free(void* e) { delete (EncH*)e; }
+size_t spz_commitment_bincode(void* e, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> b = ((EncH*)e)->comm.serialize();
+  if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
+  return b.size();
+}
 size_t spz_encode_comm(void* ev, int which, uint8_t* out, size_t cap) {
   EncH* e = (EncH*)ev;
   const PolyCommitment& c = which == 0 ? e->comm.comm.comm_comb_ops : e->comm.comm.comm_comb_mem;

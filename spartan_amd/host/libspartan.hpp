@@ -90,6 +90,9 @@ struct SNARKGens {  // src/lib.rs:276-309
   R1CSGens gens_r1cs_sat;
   SparseMatPolyCommitmentGens gens_r1cs_eval;
   SNARKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, size_t num_nz_entries);
+  // bincode of the serde-derived struct (lib.rs:278-282 -> r1csproof.rs:39-66, r1cs.rs:28-31, sparse_mlpoly.rs:284-289,
+  // dense_mlpoly.rs:24-27, nizk/mod.rs:407-412, commitments.rs:7-12): every MultiCommitGens is {n, Vec<G>, h}, points as 32 bytes
+  std::vector<uint8_t> serialize() const;
 };
 
 // ---- instance ----
@@ -186,6 +189,7 @@ struct SparseMatPolyCommitment {  // :339-346
 struct ComputationCommitment {  // lib.rs:44-48 -> r1cs.rs:50-56
   size_t num_cons, num_vars, num_inputs;
   SparseMatPolyCommitment comm;
+  std::vector<uint8_t> serialize() const;  // bincode (r1cs.rs:50-56, sparse_mlpoly.rs:320-327, dense_mlpoly.rs:42-45)
 };
 struct ComputationDecommitment {  // lib.rs:50-54 -> r1cs.rs:67-70
   MultiSparseMatPolynomialAsDense dense;

@@ -756,6 +756,40 @@ void w_evalproof(Wr& w, const SparseMatPolyEvalProof& p) {
   w_pe(w, h.proof_ops); w_pe(w, h.proof_mem); w_pe(w, h.proof_derefs);
 }
 }  // namespace
+namespace {
+void w_mcg(Wr& w, const MultiCommitGens& g, const std::vector<uint8_t>& comp) {  // commitments.rs:7-12
+  w.u64(g.n());
+  w.u64(g.n());
+  for (uint32_t i : g.G) w.b.insert(w.b.end(), comp.begin() + 32 * i, comp.begin() + 32 * i + 32);
+  w.b.insert(w.b.end(), comp.begin() + 32 * g.h, comp.begin() + 32 * g.h + 32);
+}
+void w_pcg(Wr& w, const PolyCommitmentGens& g, const std::vector<uint8_t>& comp) {  // dense_mlpoly.rs:24-27, nizk/mod.rs:407-412
+  w.u64(g.gens.n);
+  w_mcg(w, g.gens.gens_n, comp);
+  w_mcg(w, g.gens.gens_1, comp);
+}
+}  // namespace
+std::vector<uint8_t> SNARKGens::serialize() const {
+  Wr w;
+  const std::vector<uint8_t>& cs = stream_sat.compressed;
+  w_mcg(w, gens_r1cs_sat.gens_sc.gens_1, cs);  // R1CSSumcheckGens (r1csproof.rs:39-44)
+  w_mcg(w, gens_r1cs_sat.gens_sc.gens_3, cs);
+  w_mcg(w, gens_r1cs_sat.gens_sc.gens_4, cs);
+  w_pcg(w, gens_r1cs_sat.gens_pc, cs);         // R1CSGens.gens_pc (:61-65)
+  const std::vector<uint8_t>& ce = stream_eval.compressed;
+  w_pcg(w, gens_r1cs_eval.gens_ops, ce);       // SparseMatPolyCommitmentGens (sparse_mlpoly.rs:284-289)
+  w_pcg(w, gens_r1cs_eval.gens_mem, ce);
+  w_pcg(w, gens_r1cs_eval.gens_derefs, ce);
+  return w.b;
+}
+std::vector<uint8_t> ComputationCommitment::serialize() const {
+  Wr w;
+  w.u64(num_cons); w.u64(num_vars); w.u64(num_inputs);
+  w.u64(comm.batch_size); w.u64(comm.num_ops); w.u64(comm.num_mem_cells);
+  w.cpv(comm.comm_comb_ops.C);
+  w.cpv(comm.comm_comb_mem.C);
+  return w.b;
+}
 std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p) { Wr w; w_r1cs(w, p); return w.b; }
 std::vector<uint8_t> NIZK::serialize() const { Wr w; w_r1cs(w, r1cs_sat_proof); w.fqv(rx); w.fqv(ry); return w.b; }
 std::vector<uint8_t> SNARK::serialize() const {

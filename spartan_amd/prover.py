@@ -12,7 +12,7 @@ H = ctypes.CDLL(HOST_PATH)
 for f in ("spz_ctx_new", "spz_instance_new", "spz_instance_synthetic", "spz_snark_gens_new", "spz_nizk_gens_new", "spz_snark_encode",
           "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw"):
     getattr(H, f).restype = vp
-for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script"):
+for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script", "spz_snark_gens_bincode", "spz_commitment_bincode"):
     getattr(H, f).restype = sz
 H.spz_last_error.restype = ctypes.c_char_p
 for f in ("spz_ctx_free", "spz_instance_free", "spz_snark_gens_free", "spz_nizk_gens_free", "spz_encode_free", "spz_proof_free"):
@@ -73,6 +73,11 @@ class SNARKGens:
         n = H.spz_snark_gens_stream(self.h, ctypes.c_int(which), None, sz(0))
         b = (ctypes.c_uint8 * n)()
         H.spz_snark_gens_stream(self.h, ctypes.c_int(which), b, sz(n))
+        return bytes(b)
+
+    def serialize(self):
+        n = H.spz_snark_gens_bincode(self.h, None, sz(0)); b = (ctypes.c_uint8 * n)()
+        H.spz_snark_gens_bincode(self.h, b, sz(n))
         return bytes(b)
 
     def free(self):
@@ -137,6 +142,11 @@ class Encoded:
         n = H.spz_encode_comm(self.h, ctypes.c_int(which), None, sz(0))
         b = (ctypes.c_uint8 * (32 * n))()
         H.spz_encode_comm(self.h, ctypes.c_int(which), b, sz(32 * n))
+        return bytes(b)
+
+    def serialize_commitment(self):
+        n = H.spz_commitment_bincode(self.h, None, sz(0)); b = (ctypes.c_uint8 * n)()
+        H.spz_commitment_bincode(self.h, b, sz(n))
         return bytes(b)
 
     def free(self):

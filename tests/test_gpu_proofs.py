@@ -222,3 +222,30 @@ def test_concurrent_contexts_produce_identical_proofs(P, orc):
     assert oracle_bytes(orc, op) == work[k][5]
     for w in work:
         w[3].free(); w[2].free(); w[1].free(); w[0].close()
+
+
+def test_wire_formats_of_gens_and_commitment_match_oracle(P, ctx, orc):
+    """bincode of SNARKGens (lib.rs:278-282) and ComputationCommitment (lib.rs:44-48): same bytes as the oracle's writer; the
+    lengths follow from the serde struct definitions."""
+    s_ = 6; N = 1 << s_
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=4)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(4)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    def ob(fn, h):
+        n = fn(h, None, sz(0)); b = (ctypes.c_uint8 * n)(); fn(h, b, sz(n)); return bytes(b)
+    gb = gens.serialize()
+    assert gb == ob(orc.orc_snark_gens_bincode, og)
+    cb = enc.serialize_commitment()
+    assert cb == ob(orc.orc_commitment_bincode, oe)
+    # sizes from the struct layout: MultiCommitGens{n} = 16 + 32*(n+1); PolyCommitmentGens(n) = 8 + mcg(n) + mcg(1)
+    mcg = lambda n: 16 + 32 * (n + 1)
+    pcg = lambda n: 8 + mcg(n) + mcg(1)
+    r_sat = 1 << (s_ - s_ // 2)
+    v_ops, v_mem, v_der = s_ + 4, s_ + 2, s_ + 3   # log2(nnz)+log2(16), max(nvx, nvy)+1, log2(nnz)+log2(8)
+    R = lambda v: 1 << (v - v // 2)
+    assert len(gb) == mcg(1) + mcg(3) + mcg(4) + pcg(r_sat) + pcg(R(v_ops)) + pcg(R(v_mem)) + pcg(R(v_der))
+    assert len(cb) == 6 * 8 + (8 + 32 * (1 << (v_ops // 2))) + (8 + 32 * (1 << (v_mem // 2)))
+    enc.free(); gens.free(); inst.free()
