@@ -32,15 +32,15 @@ SP_HD Pt pt_identity() { return Pt{fp_zero(), fp_one(), fp_one(), fp_zero()}; }
 
 // RFC 9496 §4.2 SQRT_RATIO_M1
 SP_HD bool fp_sqrt_ratio_m1(const Fp& u, const Fp& v, Fp* out) {
-  Fp v3 = fp_mul_lat(fp_sqr_lat(v), v);
-  Fp v7 = fp_mul_lat(fp_sqr_lat(v3), v);
-  Fp r = fp_mul_lat(fp_mul_lat(u, v3), fp_pow_p58_serial(fp_mul_lat(u, v7)));
-  Fp check = fp_mul_lat(v, fp_sqr_lat(r));
+  Fp v3 = fp_mul(fp_sqr(v), v);
+  Fp v7 = fp_mul(fp_sqr(v3), v);
+  Fp r = fp_mul(fp_mul(u, v3), fp_pow_p58_serial(fp_mul(u, v7)));
+  Fp check = fp_mul(v, fp_sqr(r));
   Fp neg_u = fp_neg(u);
   bool correct_sign = fp_eq(check, u);
   bool flipped = fp_eq(check, neg_u);
-  bool flipped_i = fp_eq(check, fp_mul_lat(neg_u, fp_SQRT_M1()));
-  Fp r_i = fp_mul_lat(r, fp_SQRT_M1());
+  bool flipped_i = fp_eq(check, fp_mul(neg_u, fp_SQRT_M1()));
+  Fp r_i = fp_mul(r, fp_SQRT_M1());
   r = fp_select(r, r_i, flipped || flipped_i);
   *out = fp_abs(r);
   return correct_sign || flipped;
@@ -53,15 +53,6 @@ SP_HD Pt pt_add(const Pt& p, const Pt& q) {
   Fp Dd = fp_mul(fp_add(p.Z, p.Z), q.Z);
   Fp E = fp_sub(B, A), F = fp_sub(Dd, C), G = fp_add(Dd, C), H = fp_add(B, A);
   return Pt{fp_mul(E, F), fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
-}
-// same addition on the latency-oriented multiplier (LDS tree reductions executed by a handful of waves)
-SP_HD Pt pt_add_lat(const Pt& p, const Pt& q) {
-  Fp A = fp_mul_lat(fp_sub(p.Y, p.X), fp_sub(q.Y, q.X));
-  Fp B = fp_mul_lat(fp_add(p.Y, p.X), fp_add(q.Y, q.X));
-  Fp C = fp_mul_lat(fp_mul_lat(p.T, fp_D2()), q.T);
-  Fp Dd = fp_mul_lat(fp_add(p.Z, p.Z), q.Z);
-  Fp E = fp_sub(B, A), F = fp_sub(Dd, C), G = fp_add(Dd, C), H = fp_add(B, A);
-  return Pt{fp_mul_lat(E, F), fp_mul_lat(G, H), fp_mul_lat(F, G), fp_mul_lat(E, H)};
 }
 // p + n (neg=false) or p - n (neg=true)
 SP_HD Pt pt_madd(const Pt& p, const Niels& n, bool neg) {
@@ -84,7 +75,6 @@ SP_HD Pt pt_dbl(const Pt& p) {  // dbl-2008-hwcd, a = -1
   Fp G = fp_add(Dd, B), F = fp_sub(G, C), H = fp_sub(Dd, B);
   return Pt{fp_mul(E, F), fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
 }
-SP_HD Pt pt_neg(const Pt& p) { return Pt{fp_neg(p.X), p.Y, p.Z, fp_neg(p.T)}; }
 // affine Niels form of p given 1/Z
 SP_HD Niels pt_to_niels(const Pt& p, const Fp& zinv) {
   Fp x = fp_mul(p.X, zinv), y = fp_mul(p.Y, zinv);
@@ -97,20 +87,20 @@ SP_HD Niels pt_to_niels(const Pt& p, const Fp& zinv) {
 
 // RFC 9496 §4.3.2 Encode
 SP_HD void pt_compress(const Pt& p, uint8_t out[32]) {
-  Fp u1 = fp_mul_lat(fp_add(p.Z, p.Y), fp_sub(p.Z, p.Y));
-  Fp u2 = fp_mul_lat(p.X, p.Y);
+  Fp u1 = fp_mul(fp_add(p.Z, p.Y), fp_sub(p.Z, p.Y));
+  Fp u2 = fp_mul(p.X, p.Y);
   Fp invsqrt;
-  fp_sqrt_ratio_m1(fp_one(), fp_mul_lat(u1, fp_sqr_lat(u2)), &invsqrt);
-  Fp den1 = fp_mul_lat(invsqrt, u1), den2 = fp_mul_lat(invsqrt, u2);
-  Fp z_inv = fp_mul_lat(fp_mul_lat(den1, den2), p.T);
-  Fp ix0 = fp_mul_lat(p.X, fp_SQRT_M1()), iy0 = fp_mul_lat(p.Y, fp_SQRT_M1());
-  Fp ench = fp_mul_lat(den1, fp_INVSQRT_A_MINUS_D());
-  bool rotate = fp_is_negative(fp_mul_lat(p.T, z_inv));
+  fp_sqrt_ratio_m1(fp_one(), fp_mul(u1, fp_sqr(u2)), &invsqrt);
+  Fp den1 = fp_mul(invsqrt, u1), den2 = fp_mul(invsqrt, u2);
+  Fp z_inv = fp_mul(fp_mul(den1, den2), p.T);
+  Fp ix0 = fp_mul(p.X, fp_SQRT_M1()), iy0 = fp_mul(p.Y, fp_SQRT_M1());
+  Fp ench = fp_mul(den1, fp_INVSQRT_A_MINUS_D());
+  bool rotate = fp_is_negative(fp_mul(p.T, z_inv));
   Fp x = fp_select(p.X, iy0, rotate);
   Fp y = fp_select(p.Y, ix0, rotate);
   Fp den_inv = fp_select(den2, ench, rotate);
-  y = fp_cneg(y, fp_is_negative(fp_mul_lat(x, z_inv)));
-  Fp s = fp_abs(fp_mul_lat(den_inv, fp_sub(p.Z, y)));
+  y = fp_cneg(y, fp_is_negative(fp_mul(x, z_inv)));
+  Fp s = fp_abs(fp_mul(den_inv, fp_sub(p.Z, y)));
   fp_to_bytes(s, out);
 }
 // RFC 9496 §4.3.1 Decode

@@ -314,91 +314,6 @@ SP_HD Fp fp_sqr(const Fp& a) {
   t[7] += (uint64_t)c;
   return fp_reduce512(t);
 }
-// ---- latency-oriented variants (same values). The operand-scanning forms above chain every partial product
-// through one carry variable, which is what maximises throughput when thousands of waves hide each other's
-// latency (bench/ubench_fpmul.hip), but a lone wave on a serial chain (tree adds and the 254-squaring inverse
-// square root of the ristretto encode) then waits ~16 cycles per dependent 64-bit multiply-add. Here all partial
-// products are formed first, independently, and only the short column sums are serial.
-SP_HD Fp fp_reduce512_lat(const uint64_t t[8]) {
-  u128 q0 = (u128)t[4] * 38, q1 = (u128)t[5] * 38, q2 = (u128)t[6] * 38, q3 = (u128)t[7] * 38;
-  Fp r;
-  u128 c = (u128)t[0] + (uint64_t)q0;
-  r.v[0] = (uint64_t)c; c >>= 64;
-  c += (u128)t[1] + (uint64_t)q1 + (uint64_t)(q0 >> 64);
-  r.v[1] = (uint64_t)c; c >>= 64;
-  c += (u128)t[2] + (uint64_t)q2 + (uint64_t)(q1 >> 64);
-  r.v[2] = (uint64_t)c; c >>= 64;
-  c += (u128)t[3] + (uint64_t)q3 + (uint64_t)(q2 >> 64);
-  r.v[3] = (uint64_t)c; c >>= 64;
-  c += (uint64_t)(q3 >> 64);  // < 2^7
-  uint64_t c2 = fp_add_small(r, 38 * (uint64_t)c);
-  r.v[0] += 38 * c2;
-  return r;
-}
-SP_HD Fp fp_mul_lat(const Fp& a, const Fp& b) {
-  u128 p00 = (u128)a.v[0] * b.v[0], p01 = (u128)a.v[0] * b.v[1], p02 = (u128)a.v[0] * b.v[2], p03 = (u128)a.v[0] * b.v[3];
-  u128 p10 = (u128)a.v[1] * b.v[0], p11 = (u128)a.v[1] * b.v[1], p12 = (u128)a.v[1] * b.v[2], p13 = (u128)a.v[1] * b.v[3];
-  u128 p20 = (u128)a.v[2] * b.v[0], p21 = (u128)a.v[2] * b.v[1], p22 = (u128)a.v[2] * b.v[2], p23 = (u128)a.v[2] * b.v[3];
-  u128 p30 = (u128)a.v[3] * b.v[0], p31 = (u128)a.v[3] * b.v[1], p32 = (u128)a.v[3] * b.v[2], p33 = (u128)a.v[3] * b.v[3];
-#define SP_LO(x) ((u128)(uint64_t)(x))
-#define SP_HI(x) ((u128)(uint64_t)((x) >> 64))
-  uint64_t t[8];
-  u128 c = SP_LO(p00);
-  t[0] = (uint64_t)c; c >>= 64;
-  c += SP_HI(p00) + SP_LO(p01) + SP_LO(p10);
-  t[1] = (uint64_t)c; c >>= 64;
-  c += (SP_HI(p01) + SP_HI(p10)) + (SP_LO(p02) + SP_LO(p11) + SP_LO(p20));
-  t[2] = (uint64_t)c; c >>= 64;
-  c += (SP_HI(p02) + SP_HI(p11) + SP_HI(p20)) + (SP_LO(p03) + SP_LO(p12) + SP_LO(p21) + SP_LO(p30));
-  t[3] = (uint64_t)c; c >>= 64;
-  c += (SP_HI(p03) + SP_HI(p12) + SP_HI(p21) + SP_HI(p30)) + (SP_LO(p13) + SP_LO(p22) + SP_LO(p31));
-  t[4] = (uint64_t)c; c >>= 64;
-  c += (SP_HI(p13) + SP_HI(p22) + SP_HI(p31)) + (SP_LO(p23) + SP_LO(p32));
-  t[5] = (uint64_t)c; c >>= 64;
-  c += (SP_HI(p23) + SP_HI(p32)) + SP_LO(p33);
-  t[6] = (uint64_t)c; c >>= 64;
-  c += SP_HI(p33);
-  t[7] = (uint64_t)c;
-  return fp_reduce512_lat(t);
-}
-SP_HD Fp fp_sqr_lat(const Fp& a) {
-  u128 p00 = (u128)a.v[0] * a.v[0], p11 = (u128)a.v[1] * a.v[1], p22 = (u128)a.v[2] * a.v[2], p33 = (u128)a.v[3] * a.v[3];
-  u128 p01 = (u128)a.v[0] * a.v[1], p02 = (u128)a.v[0] * a.v[2], p03 = (u128)a.v[0] * a.v[3];
-  u128 p12 = (u128)a.v[1] * a.v[2], p13 = (u128)a.v[1] * a.v[3], p23 = (u128)a.v[2] * a.v[3];
-  uint64_t t[8];
-  u128 c = SP_LO(p00);
-  t[0] = (uint64_t)c; c >>= 64;
-  c += SP_HI(p00) + 2 * SP_LO(p01);
-  t[1] = (uint64_t)c; c >>= 64;
-  c += 2 * (SP_HI(p01) + SP_LO(p02)) + SP_LO(p11);
-  t[2] = (uint64_t)c; c >>= 64;
-  c += 2 * (SP_HI(p02) + SP_LO(p03) + SP_LO(p12)) + SP_HI(p11);
-  t[3] = (uint64_t)c; c >>= 64;
-  c += 2 * (SP_HI(p03) + SP_HI(p12) + SP_LO(p13)) + SP_LO(p22);
-  t[4] = (uint64_t)c; c >>= 64;
-  c += 2 * (SP_HI(p13) + SP_LO(p23)) + SP_HI(p22);
-  t[5] = (uint64_t)c; c >>= 64;
-  c += 2 * SP_HI(p23) + SP_LO(p33);
-  t[6] = (uint64_t)c; c >>= 64;
-  c += SP_HI(p33);
-  t[7] = (uint64_t)c;
-  return fp_reduce512_lat(t);
-#undef SP_LO
-#undef SP_HI
-}
-SP_HD Fp fp_mul_small(const Fp& a, uint64_t k) {  // k < 2^32
-  Fp r;
-  u128 c = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    c += (u128)a.v[i] * k;
-    r.v[i] = (uint64_t)c;
-    c >>= 64;
-  }
-  uint64_t c2 = fp_add_small(r, 38 * (uint64_t)c);
-  r.v[0] += 38 * c2;
-  return r;
-}
 // canonical representative in [0,p)
 SP_HD Fp fp_canon(const Fp& a) {
   Fp t = a;
@@ -455,32 +370,32 @@ SP_HD Fp fp_select(const Fp& a, const Fp& b, bool take_b) {
   return r;
 }
 SP_HD Fp fp_pow2k(Fp a, int k) {
-  for (int i = 0; i < k; i++) a = fp_sqr_lat(a);
+  for (int i = 0; i < k; i++) a = fp_sqr(a);
   return a;
 }
 // z^(2^250-1) and z^11, shared by inversion and the (p-5)/8 power
 SP_HD void fp_pow_ladder(const Fp& z, Fp* z2_250_0, Fp* z11) {
-  Fp z2 = fp_sqr_lat(z);
-  Fp z9 = fp_mul_lat(fp_pow2k(z2, 2), z);
-  *z11 = fp_mul_lat(z9, z2);
-  Fp z2_5_0 = fp_mul_lat(fp_sqr_lat(*z11), z9);
-  Fp z2_10_0 = fp_mul_lat(fp_pow2k(z2_5_0, 5), z2_5_0);
-  Fp z2_20_0 = fp_mul_lat(fp_pow2k(z2_10_0, 10), z2_10_0);
-  Fp z2_40_0 = fp_mul_lat(fp_pow2k(z2_20_0, 20), z2_20_0);
-  Fp z2_50_0 = fp_mul_lat(fp_pow2k(z2_40_0, 10), z2_10_0);
-  Fp z2_100_0 = fp_mul_lat(fp_pow2k(z2_50_0, 50), z2_50_0);
-  Fp z2_200_0 = fp_mul_lat(fp_pow2k(z2_100_0, 100), z2_100_0);
-  *z2_250_0 = fp_mul_lat(fp_pow2k(z2_200_0, 50), z2_50_0);
+  Fp z2 = fp_sqr(z);
+  Fp z9 = fp_mul(fp_pow2k(z2, 2), z);
+  *z11 = fp_mul(z9, z2);
+  Fp z2_5_0 = fp_mul(fp_sqr(*z11), z9);
+  Fp z2_10_0 = fp_mul(fp_pow2k(z2_5_0, 5), z2_5_0);
+  Fp z2_20_0 = fp_mul(fp_pow2k(z2_10_0, 10), z2_10_0);
+  Fp z2_40_0 = fp_mul(fp_pow2k(z2_20_0, 20), z2_20_0);
+  Fp z2_50_0 = fp_mul(fp_pow2k(z2_40_0, 10), z2_10_0);
+  Fp z2_100_0 = fp_mul(fp_pow2k(z2_50_0, 50), z2_50_0);
+  Fp z2_200_0 = fp_mul(fp_pow2k(z2_100_0, 100), z2_100_0);
+  *z2_250_0 = fp_mul(fp_pow2k(z2_200_0, 50), z2_50_0);
 }
 SP_HD Fp fp_invert(const Fp& z) {  // z^(p-2)
   Fp t, z11;
   fp_pow_ladder(z, &t, &z11);
-  return fp_mul_lat(fp_pow2k(t, 5), z11);
+  return fp_mul(fp_pow2k(t, 5), z11);
 }
 SP_HD Fp fp_pow_p58(const Fp& z) {  // z^((p-5)/8)
   Fp t, z11;
   fp_pow_ladder(z, &t, &z11);
-  return fp_mul_lat(fp_pow2k(t, 2), z);
+  return fp_mul(fp_pow2k(t, 2), z);
 }
 
 }  // namespace sp

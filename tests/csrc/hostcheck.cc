@@ -30,8 +30,6 @@ void hc_fp_invert(const uint8_t* a, uint8_t* o) { fp_to_bytes(fp_invert(fp_from_
 // raw 256-bit limbs (exercises weakly-reduced inputs >= p, >= 2^255)
 void hc_fp_mul_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_mul(x, y), o); }
 void hc_fp_sqr_raw(const uint64_t* a, uint8_t* o) { Fp x; memcpy(x.v, a, 32); fp_to_bytes(fp_sqr(x), o); }
-void hc_fp_mul_lat_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fp_mul_lat(x, y), o); }
-void hc_fp_sqr_lat_raw(const uint64_t* a, uint8_t* o) { Fp x; memcpy(x.v, a, 32); fp_to_bytes(fp_sqr_lat(x), o); }
 void hc_fe10_mul_raw(const uint64_t* a, const uint64_t* b, uint8_t* o) { Fp x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); fp_to_bytes(fe10_to_fp(fe10_mul(fe10_from_fp(x), fe10_from_fp(y))), o); }
 void hc_fe10_sqr_chain_raw(const uint64_t* a, int k, uint8_t* o) { Fp x; memcpy(x.v, a, 32); fp_to_bytes(fe10_to_fp(fe10_pow2k(fe10_from_fp(x), k)), o); }
 void hc_fp_pow_p58_serial(const uint64_t* a, uint8_t* o) { Fp x; memcpy(x.v, a, 32); fp_to_bytes(fp_pow_p58_serial(x), o); }

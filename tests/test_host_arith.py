@@ -46,8 +46,6 @@ def test_fp_matches_python(hc):
             a, b = vals[i], vals[j]
             hc.hc_fp_mul_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == a * b % P
             hc.hc_fp_sqr_raw(raw(a), out); assert int.from_bytes(bytes(out), "little") == a * a % P
-            hc.hc_fp_mul_lat_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == a * b % P
-            hc.hc_fp_sqr_lat_raw(raw(a), out); assert int.from_bytes(bytes(out), "little") == a * a % P
             hc.hc_fp_add_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == (a + b) % P
             hc.hc_fp_sub_raw(raw(a), raw(b), out); assert int.from_bytes(bytes(out), "little") == (a - b) % P
     for a in vals[1:40]:
