@@ -249,3 +249,30 @@ def test_wire_formats_of_gens_and_commitment_match_oracle(P, ctx, orc):
     assert len(gb) == mcg(1) + mcg(3) + mcg(4) + pcg(r_sat) + pcg(R(v_ops)) + pcg(R(v_mem)) + pcg(R(v_der))
     assert len(cb) == 6 * 8 + (8 + 32 * (1 << (v_ops // 2))) + (8 + 32 * (1 << (v_mem // 2)))
     enc.free(); gens.free(); inst.free()
+
+
+@pytest.mark.parametrize("lc,lv,ni", [(6, 4, 3), (4, 7, 10), (9, 6, 20), (5, 5, 31), (7, 8, 0)])
+def test_rectangular_instances_match_oracle(P, ctx, orc, lc, lv, ni):
+    """num_cons != num_vars (so rx and ry differ in length and SparseMatPolyEvalProof's `equalize` pads either side,
+    sparse_mlpoly.rs:1429-1445), and input counts from 0 to num_vars - 1."""
+    nc, nv = 1 << lc, 1 << lv
+    seed = lc * 100 + lv
+    inst = P.Instance.produce_synthetic_r1cs(ctx, nc, nv, ni, seed=seed)
+    gens = P.SNARKGens(ctx, nc, nv, ni, nc)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", seed)
+    got = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    oi = vp(orc.orc_instance_synthetic(sz(nc), sz(nv), sz(ni), ctypes.c_uint64(seed)))
+    assert orc.orc_instance_is_sat(oi) == 1
+    og = vp(orc.orc_snark_gens_new(sz(nc), sz(nv), sz(ni), sz(nc)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
+    assert orc.orc_snark_verify(op, oi, og, oe, b"snark_example") == 1
+    assert got == oracle_bytes(orc, op)
+    inst.set_digest(b"rect")
+    ngens = P.NIZKGens(ctx, nc, nv, ni)
+    gotn = P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, ngens, b"nizk_example", tape)
+    ong = vp(orc.orc_nizk_gens_new(sz(nc), sz(nv), sz(ni)))
+    onp = vp(orc.orc_nizk_prove(oi, ong, b"rect", sz(4), b"nizk_example", tape, None))
+    assert gotn == oracle_bytes(orc, onp)
+    ngens.free(); enc.free(); gens.free(); inst.free()
