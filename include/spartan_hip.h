@@ -115,6 +115,9 @@ int32_t sp_dot(sp_ctx* ctx, const sp_table* a, size_t a_off, const sp_table* b, 
 int32_t sp_evaluate(sp_ctx* ctx, const sp_table* Z, const uint64_t* r, size_t ell, uint64_t out[4]);
 /* Read element 0 of each table (final claims after the last round: poly[0]). */
 int32_t sp_table_heads(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, uint64_t* out /*4*ntabs*/);
+/* Read `count` consecutive elements starting at offs[k] from each table in one round trip (ProductCircuit::evaluate,
+ * product_tree.rs:58-63, reads the two roots of every circuit): out[(k*count + e)*4 ..]. */
+int32_t sp_table_gather(sp_ctx* ctx, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out);
 
 /* ---- sparse matrices: SparseMatPolynomial (src/sparse_mlpoly.rs:19-38, 429-481) ----------------------
  * Entries (row, col, val). Upload keeps a row-sorted (CSR) and a column-sorted (CSC) copy on the device so

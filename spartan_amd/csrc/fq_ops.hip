@@ -169,9 +169,10 @@ __global__ void __launch_bounds__(256) k_dot(const Fq* __restrict__ a, const Fq*
   block_sum_fq<1>(acc, sm);
   if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
 }
-__global__ void k_gather_heads(Tabs4 T, int ntabs, Fq* __restrict__ out) {
-  int k = threadIdx.x;
-  if (k < ntabs) st_fq(out + k, ld_fq(T.p[k]));
+// out[k*count + e] = *(ptrs[k] + e): pointer list read from the host-mapped page
+__global__ void k_gather_elems(const Fq* const* __restrict__ ptrs, size_t n, size_t count, Fq* __restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n * count) st_fq(out + t, ld_fq(ptrs[t / count] + t % count));
 }
 
 
@@ -332,21 +333,25 @@ int32_t sp_evaluate(sp_ctx* c, const sp_table* Z, const uint64_t* r, size_t ell,
   }
   return reduce_and_fetch(c, partials, nblk, 1, out);
 }
-int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t* out) {
-  if (!c || !tabs || !out || ntabs == 0) return SP_EINVAL;
+static int32_t gather_elems(sp_ctx* c, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out) {
+  if (!c || !tabs || !out || ntabs == 0 || count == 0) return SP_EINVAL;
+  if (32 * ntabs * count > HMAP_SIZE - HMAP_IN || 8 * ntabs > HMAP_IN) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  if (32 * ntabs > HMAP_SIZE - HMAP_IN) return SP_EINVAL;
-  for (size_t k0 = 0; k0 < ntabs; k0 += 4) {
-    size_t nk = ntabs - k0 < 4 ? ntabs - k0 : 4;
-    Tabs4 T = {{nullptr, nullptr, nullptr, nullptr}};
-    for (size_t k = 0; k < nk; k++) {
-      if (!tabs[k0 + k]) return SP_EINVAL;
-      T.p[k] = tabs[k0 + k]->d;
-    }
-    hipLaunchKernelGGL(k_gather_heads, dim3(1), dim3(64), 0, c->stream, T, (int)nk, (Fq*)hres(c) + k0);
+  std::vector<const Fq*> ptrs(ntabs);
+  for (size_t k = 0; k < ntabs; k++) {
+    size_t off = offs ? offs[k] : 0;
+    if (!tabs[k] || off + count > tabs[k]->cap) return SP_EINVAL;
+    ptrs[k] = tabs[k]->d + off;
   }
-  SPCHK(fetch_small(c, out, 32 * ntabs));
+  const Fq* const* dp = (const Fq* const*)stage_small(c, 0, ptrs.data(), 8 * ntabs);
+  size_t n = ntabs * count;
+  hipLaunchKernelGGL(k_gather_elems, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, dp, ntabs, count, (Fq*)hres(c));
+  SPCHK(fetch_small(c, out, 32 * n));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t* out) { return gather_elems(c, tabs, nullptr, ntabs, 1, out); }
+int32_t sp_table_gather(sp_ctx* c, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out) {
+  return gather_elems(c, tabs, offs, ntabs, count, out);
 }
 
 }  // extern "C"
