@@ -10,6 +10,10 @@ Multi-GPU (--gpus N, launched with torch.distributed.run, one rank per GPU): eac
 independent instance (different seed) — proofs are independent units, so there is no data-path collective;
 "scaling": "weak". Timing is bracketed by barrier + synchronize, and the MAX over ranks is used.
 
+--shard-commits (optional, N > 1): all ranks prove the SAME instance in lock-step and every DensePolynomial::commit is
+row-sharded over the ranks, with one RCCL all-gather of the 32-byte commitments per commit (SURVEY.md §8e, K1);
+"scaling": "strong", `value` = one proof's constraints / time. Each sharded proof is checked against the unsharded bytes.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse, ctypes, json, os, sys, time
@@ -128,6 +132,7 @@ def main():
     ap.add_argument("--cpu-log2-cons", type=int, default=15, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrent", type=int, default=4, help="also measure K independent proofs in flight on the GPU (0 = skip); reported separately, never as `value`")
+    ap.add_argument("--shard-commits", action="store_true", help="N>1: one proof, row commitments sharded over the ranks + all-gather (strong scaling)")
     ap.add_argument("--phases", action="store_true", help="also print the per-phase span times (timer.rs names) to stderr")
     args = ap.parse_args()
 
@@ -145,10 +150,12 @@ def main():
     s = args.log2_cons
     N = 1 << s
     ctx = P.Ctx(local_rank)
-    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=rank)  # profiler/snark.rs:23-31 shape
+    sharded = args.shard_commits and dist is not None
+    seed = 0 if sharded else rank
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=seed)  # profiler/snark.rs:23-31 shape
     gens = P.SNARKGens(ctx, N, N, 10, N)
     enc = P.SNARK.encode(ctx, inst, gens)
-    tape_seed = P.seed_scalar(b"tape", rank)
+    tape_seed = P.seed_scalar(b"tape", seed)
 
     def step(times=None):
         return P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape_seed, times)
@@ -161,8 +168,14 @@ def main():
 
     proof = None
     raw = ctx.raw()
+    if sharded:
+        proof = step()  # unsharded bytes: every sharded proof below must equal them
+        ctx.set_commit_shard(dist, dev if dist.get_backend() == "nccl" else "cpu")
     for _ in range(args.warmup):
-        proof = step()
+        p2 = step()
+        if proof is not None and p2 != proof:
+            raise SystemExit("sharded proof differs from the unsharded proof")
+        proof = p2
     # Untimed profiling step: HIP events on every kernel family -> per-family breakdown and the dominant kernel.
     # (Each recorded launch costs two hipEventRecord calls; with ~1500 launches per proof that is ~10% of a step,
     # so the timed region below instruments the dominant family only.)
@@ -174,6 +187,9 @@ def main():
     capi.lib.sp_prof_reset(raw)
     if not os.environ.get("BENCH_NO_PROF"):
         capi.lib.sp_prof_select(raw, dom.encode()); capi.lib.sp_prof_enable(raw, ctypes.c_int(1))
+    if sharded:
+        from spartan_amd import shard
+        shard.STATS.update(gathers=0, bytes=0)
     dist_barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -211,24 +227,27 @@ def main():
         gpu_ms_total = sum(v["ms"] for v in breakdown.values())
         out = {
             "metric": "R1CS constraints/sec in SNARK::prove (synthetic 2^%d); bit-exact proof" % s,
-            "value": world * N * args.steps / dt,
+            "value": (1 if sharded else world) * N * args.steps / dt,
             "unit": "constraints/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u64x4 (F_q Montgomery / F_p 2^255-19 limbs)",
             "data": "synthetic",
             "config": {"workload": f"SNARK::prove, Instance::produce_synthetic_r1cs(2^{s}, 2^{s}, 10), nnz 2^{s} per matrix; MSM + sum-checks + IPA + SPARK on GPU",
-                       "proof_bytes": len(proof), "parallelism": "1 proof per GPU, %d independent proofs" % world},
+                       "proof_bytes": len(proof), "parallelism": ("1 proof, row commitments sharded over %d GPUs + all-gather" % world) if sharded else ("1 proof per GPU, %d independent proofs" % world)},
             "roofline": roofline,
             "kernel_ms_per_step": {n: round(v["ms"], 4) for n, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])},
             "gpu_busy_ms_per_step": round(gpu_ms_total, 3),
             "kernel_ms_note": "per-family totals from one untimed fully-instrumented step; roofline from the timed steps",
         }
+        if sharded:
+            out["config"]["all_gathers_per_proof"] = shard.STATS["gathers"] / args.steps
+            out["config"]["all_gather_bytes_per_proof"] = shard.STATS["bytes"] / args.steps
         if args.concurrent > 1 and world == 1:
             out["throughput_concurrent"] = concurrent_throughput(P, local_rank, s, args.concurrent, max(2, args.steps))
         if not args.no_cpu_baseline and world == 1:

@@ -34,6 +34,16 @@ const char* spz_last_error() { return g_err.c_str(); }
 void* spz_ctx_new(int device) { return guard([&]() -> void* { return new Ctx(device); }); }
 void spz_ctx_free(void* c) { delete (Ctx*)c; }
 sp_ctx* spz_ctx_raw(void* c) { return ((Ctx*)c)->h; }
+// row-sharded commitments across `world` lock-step ranks (libspartan.hpp: set_commit_shard); 0 = ok
+int spz_ctx_set_commit_shard(void* c, int rank, int world, CommitGatherFn gather, void* user) {
+  try {
+    set_commit_shard(*(Ctx*)c, rank, world, gather, user);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
 
 // Instance::new (lib.rs:121-128): entries of A, B, C back to back as (row, col, [u8;32] canonical little-endian value).
 // Errors mirror R1CSError: "InvalidIndex", "InvalidScalar" (spz_last_error()).

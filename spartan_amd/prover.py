@@ -36,6 +36,17 @@ class Ctx:
         """the underlying sp_ctx* (for profiling calls through spartan_amd.capi.lib)"""
         return vp(H.spz_ctx_raw(self.h))
 
+    def set_commit_shard(self, dist, device="cpu"):
+        """row-shard every DensePolynomial::commit over the ranks of `dist` (spartan_amd/shard.py); None clears it. All
+        ranks must then run identical prove() calls in lock-step."""
+        from . import shard
+        if dist is None or dist.get_world_size() == 1:
+            H.spz_ctx_set_commit_shard(self.h, ctypes.c_int(0), ctypes.c_int(1), None, None); self._gather = None
+            return
+        self._gather = shard.make_gather_callback(dist, device)
+        if H.spz_ctx_set_commit_shard(self.h, ctypes.c_int(dist.get_rank()), ctypes.c_int(dist.get_world_size()), self._gather, None) != 0:
+            raise SpartanHipError(f"set_commit_shard: {H.spz_last_error().decode()}")
+
     def close(self):
         if self.h:
             H.spz_ctx_free(self.h); self.h = None
