@@ -123,6 +123,28 @@ def concurrent_throughput(P, device, s, K, steps):
             "note": "K host threads, one sp_ctx each, same GPU; each proof byte-identical to its single-stream run"}
 
 
+def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
+    """NIZK::prove (lib.rs:501-546) on the same instance, and SNARK::encode (lib.rs:320-335; the sparse_mlpoly commit path of
+    BASELINE config 5), timed the same way as the headline; reported next to it, never as `value`."""
+    import torch
+    ng = P.NIZKGens(ctx, N, N, 10)
+    P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, ng, b"nizk_example", tape_seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pr = P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, ng, b"nizk_example", tape_seed)
+    dt = (time.perf_counter() - t0) / steps
+    ng.free()
+    out = {"nizk_prove": {"value": N / dt, "unit": "constraints/s", "ms_per_proof": dt * 1e3, "proof_bytes": len(pr)}}
+    t0 = time.perf_counter()
+    for _ in range(2):
+        e = P.SNARK.encode(ctx, inst, gens); e.free()
+    dt = (time.perf_counter() - t0) / 2
+    # comb_ops: 16 * nnz scalars (row, col, val, 3 read timestamps per matrix padded), comb_mem: 4 * max(cons, vars+..) scalars
+    out["snark_encode"] = {"ms": dt * 1e3, "note": "SNARK::encode incl. AddrTimestamps::new on the host, upload, two multi_commits"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +153,7 @@ def main():
     ap.add_argument("--log2-cons", type=int, default=20, help="log2 of num_cons = num_vars = num_nz_entries (BASELINE: 20)")
     ap.add_argument("--cpu-log2-cons", type=int, default=15, help="size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-metrics", action="store_true", help="skip the NIZK::prove / SNARK::encode side measurements")
     ap.add_argument("--concurrent", type=int, default=4, help="also measure K independent proofs in flight on the GPU (0 = skip); reported separately, never as `value`")
     ap.add_argument("--shard-commits", action="store_true", help="N>1: one proof, row commitments sharded over the ranks + all-gather (strong scaling)")
     ap.add_argument("--phases", action="store_true", help="also print the per-phase span times (timer.rs names) to stderr")
@@ -250,6 +273,8 @@ def main():
             out["config"]["all_gather_bytes_per_proof"] = shard.STATS["bytes"] / args.steps
         if args.concurrent > 1 and world == 1:
             out["throughput_concurrent"] = concurrent_throughput(P, local_rank, s, args.concurrent, max(2, args.steps))
+        if world == 1 and not args.no_side_metrics:
+            out.update(side_metrics(P, ctx, inst, gens, N, s, tape_seed, max(2, args.steps)))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2_cons)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

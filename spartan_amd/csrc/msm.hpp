@@ -63,19 +63,31 @@ SP_HD int msm_digit(const Fq& s, int w) {
 SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) {
   if (fq_is_zero(s_mont)) return;
   Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
-  uint16_t mag[MSM_NWIN];
-  uint32_t neg;
-  msm_recode(s, mag, &neg);
   const Niels* base = table + pt * MSM_PT_ENTRIES;
-  uint32_t m = mag[0];
+  // digits are produced on the fly by shifting the scalar down one window per step (8 live registers instead of a
+  // 22-entry digit array; the loop stays rolled so the register budget allows a third wave per SIMD)
+  int d = (int)(s.l[0] & ((1u << MSM_WBITS) - 1));
+  int carry = d >= MSM_TENT;
+  d -= carry << MSM_WBITS;
+  uint32_t m = (uint32_t)(d < 0 ? -d : d);
+  bool ng = d < 0;
   Niels cur = base[m ? m - 1 : 0];
-#pragma unroll
+#pragma unroll 1
   for (int w = 0; w < MSM_NWIN; w++) {
-    uint32_t mn = (w + 1 < MSM_NWIN) ? mag[w + 1] : 0;
-    Niels nxt = base[(size_t)((w + 1 < MSM_NWIN) ? w + 1 : w) * MSM_TENT + (mn ? mn - 1 : 0)];
-    if (m != 0) acc = pt_madd(acc, cur, (neg >> w) & 1);
+    s.l[0] = (s.l[0] >> MSM_WBITS) | (s.l[1] << (64 - MSM_WBITS));
+    s.l[1] = (s.l[1] >> MSM_WBITS) | (s.l[2] << (64 - MSM_WBITS));
+    s.l[2] = (s.l[2] >> MSM_WBITS) | (s.l[3] << (64 - MSM_WBITS));
+    s.l[3] >>= MSM_WBITS;
+    int dn = (int)(s.l[0] & ((1u << MSM_WBITS) - 1)) + carry;  // window w+1 (zero past the top: s < 2^253)
+    carry = dn >= MSM_TENT;
+    dn -= carry << MSM_WBITS;
+    uint32_t mn = (uint32_t)(dn < 0 ? -dn : dn);
+    int wn = (w + 1 < MSM_NWIN) ? w + 1 : w;
+    Niels nxt = base[(size_t)wn * MSM_TENT + (mn ? mn - 1 : 0)];
+    if (m != 0) acc = pt_madd(acc, cur, ng);
     cur = nxt;
     m = mn;
+    ng = dn < 0;
   }
 }
 
