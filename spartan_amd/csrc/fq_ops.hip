@@ -2,52 +2,56 @@
 #include "internal.hpp"
 
 // ------------------------------------------------------------------------------------------------ F_q streaming kernels
-// chi table: thread computes 2^LOWB consecutive entries. r[0] <-> most significant index bit.
-constexpr int EQ_LOWB = 4;
-__device__ __forceinline__ Fq eq_prefix(const Fq* __restrict__ r, size_t ell, int lowb, size_t hi) {
-  // product over the (ell - lowb) high bits of index `hi` (hi = index >> lowb)
+// chi table (EqPolynomial::evals, dense_mlpoly.rs:68-84). r[0] <-> most significant index bit. Thread t owns the 2^TOPB
+// entries whose low (ell - TOPB) index bits equal t: it multiplies out the factors of those low variables once (a serial
+// chain), then doubles over the TOPB top variables in registers. Entry k of a thread sits at k * 2^(ell-TOPB) + t, so every
+// store instruction of a wave covers 64 consecutive scalars (2 KiB, fully coalesced).
+constexpr int EQ_TOPB = 4;
+__device__ __forceinline__ Fq eq_suffix(const Fq* __restrict__ r, size_t ell, int topb, size_t lo) {
   Fq acc = fq_one();
-  int nh = (int)ell - lowb;
-  for (int k = 0; k < nh; k++) {
-    Fq rk = ld_fq(r + k);
-    bool bit = (hi >> (nh - 1 - k)) & 1;
+  int nl = (int)ell - topb;
+  for (int k = 0; k < nl; k++) {
+    Fq rk = ld_fq(r + topb + k);
+    bool bit = (lo >> (nl - 1 - k)) & 1;
     acc = fq_mul(acc, bit ? rk : fq_sub(fq_one(), rk));
   }
   return acc;
 }
-__device__ __forceinline__ void eq_expand_low(Fq (&v)[1 << EQ_LOWB], const Fq* __restrict__ r, size_t ell, int lowb, const Fq& prefix) {
-  v[0] = prefix;
-  int size = 1;
-  for (int k = 0; k < lowb; k++) {
-    Fq rk = ld_fq(r + (ell - lowb + k));
-    for (int i = size - 1; i >= 0; i--) {
+template <int TOPB>
+__device__ __forceinline__ void eq_expand_top(Fq (&v)[1 << TOPB], const Fq* __restrict__ r, const Fq& suffix) {
+  v[0] = suffix;
+#pragma unroll
+  for (int k = 0; k < TOPB; k++) {
+    Fq rk = ld_fq(r + k);
+#pragma unroll
+    for (int i = (1 << k) - 1; i >= 0; i--) {
       Fq hi = fq_mul(v[i], rk);
       v[2 * i + 1] = hi;
       v[2 * i] = fq_sub(v[i], hi);
     }
-    size *= 2;
   }
 }
-__global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r, size_t ell, int lowb, Fq* __restrict__ out) {
-  size_t nthreads = (size_t)1 << (ell - lowb);
+template <int TOPB>
+__global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r, size_t ell, Fq* __restrict__ out) {
+  size_t nthreads = (size_t)1 << (ell - TOPB);
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nthreads) return;
-  Fq v[1 << EQ_LOWB];
-  eq_expand_low(v, r, ell, lowb, eq_prefix(r, ell, lowb, t));
-  int cnt = 1 << lowb;
-  for (int i = 0; i < cnt; i++) st_fq(out + (t << lowb) + i, v[i]);
+  Fq v[1 << TOPB];
+  eq_expand_top<TOPB>(v, r, eq_suffix(r, ell, TOPB, t));
+#pragma unroll
+  for (int k = 0; k < (1 << TOPB); k++) st_fq(out + ((size_t)k << (ell - TOPB)) + t, v[k]);
 }
 // <Z, chi(r)> without materialising chi; per-block partials.
-__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r, size_t ell, int lowb,
-                                                  Fq* __restrict__ partials) {
+template <int TOPB>
+__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r, size_t ell, Fq* __restrict__ partials) {
   __shared__ Fq sm[256];
-  size_t nthreads = (size_t)1 << (ell - lowb);
+  size_t nthreads = (size_t)1 << (ell - TOPB);
   Fq acc[1] = {fq_zero()};
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * blockDim.x) {
-    Fq v[1 << EQ_LOWB];
-    eq_expand_low(v, r, ell, lowb, eq_prefix(r, ell, lowb, t));
-    int cnt = 1 << lowb;
-    for (int i = 0; i < cnt; i++) acc[0] = fq_add(acc[0], fq_mul(v[i], ld_fq(Z + (t << lowb) + i)));
+    Fq v[1 << TOPB];
+    eq_expand_top<TOPB>(v, r, eq_suffix(r, ell, TOPB, t));
+#pragma unroll
+    for (int k = 0; k < (1 << TOPB); k++) acc[0] = fq_add(acc[0], fq_mul(v[k], ld_fq(Z + ((size_t)k << (ell - TOPB)) + t)));
   }
   block_sum_fq<1>(acc, sm);
   if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
@@ -193,11 +197,17 @@ int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   const Fq* dr = (const Fq*)stage_small(c, 0, r, 32 * ell);
   size_t len = (size_t)1 << ell;
   SPCHK(table_new(c, len, false, out));
-  int lowb = ell < (size_t)EQ_LOWB ? (int)ell : EQ_LOWB;
-  size_t nthreads = len >> lowb;
+  int topb = ell < (size_t)EQ_TOPB ? (int)ell : EQ_TOPB;
+  size_t nthreads = len >> topb;
   {
     ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
-    hipLaunchKernelGGL(k_eq_expand, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, dr, ell, lowb, (*out)->d);
+    dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
+    switch (topb) {
+      case 1: hipLaunchKernelGGL(k_eq_expand<1>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
+      case 2: hipLaunchKernelGGL(k_eq_expand<2>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
+      case 3: hipLaunchKernelGGL(k_eq_expand<3>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
+      default: hipLaunchKernelGGL(k_eq_expand<EQ_TOPB>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
+    }
   }
   SPCHK(sync_spin(c));  // the host-mapped input page is reusable
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
@@ -323,13 +333,20 @@ int32_t sp_evaluate(sp_ctx* c, const sp_table* Z, const uint64_t* r, size_t ell,
   if (!c || !Z || !r || !out || ell == 0 || ell > 40 || Z->len != ((size_t)1 << ell)) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   const Fq* dr = (const Fq*)stage_small(c, 0, r, 32 * ell);
-  int lowb = ell < (size_t)EQ_LOWB ? (int)ell : EQ_LOWB;
-  size_t nthreads = Z->len >> lowb, nblk = grid_for(nthreads, 1024);
+  int topb = ell < (size_t)EQ_TOPB ? (int)ell : EQ_TOPB;
+  size_t nthreads = Z->len >> topb, nblk = grid_for(nthreads, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
   Fq* partials = (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_DOT, 32.0 * (double)Z->len);
-    hipLaunchKernelGGL(k_evaluate, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)Z->d, dr, ell, lowb, partials);
+    dim3 grid((unsigned)nblk), blk(256);
+    const Fq* dz = (const Fq*)Z->d;
+    switch (topb) {
+      case 1: hipLaunchKernelGGL(k_evaluate<1>, grid, blk, 0, c->stream, dz, dr, ell, partials); break;
+      case 2: hipLaunchKernelGGL(k_evaluate<2>, grid, blk, 0, c->stream, dz, dr, ell, partials); break;
+      case 3: hipLaunchKernelGGL(k_evaluate<3>, grid, blk, 0, c->stream, dz, dr, ell, partials); break;
+      default: hipLaunchKernelGGL(k_evaluate<EQ_TOPB>, grid, blk, 0, c->stream, dz, dr, ell, partials); break;
+    }
   }
   return reduce_and_fetch(c, partials, nblk, 1, out);
 }
