@@ -154,6 +154,12 @@ void orc_bound_top(uint64_t* Z, size_t len, const uint64_t r[4]) { DensePoly p(l
 void orc_bound_vecmat(const uint64_t* Z, size_t num_vars, const uint64_t* L, uint64_t* out) {
   DensePoly p(limbs_vec(Z, pow2(num_vars))); out_vec(p.bound(limbs_vec(L, pow2(num_vars / 2))), out);
 }
+// UniPoly::from_evals / compress / evaluate (unipoly.rs:23-88) for the reference's known answers (unipoly.rs:127-183)
+void orc_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint64_t* coeffs, uint64_t* compressed, uint64_t eval_at_r[4]) {
+  UniPoly u = UniPoly::from_evals(limbs_vec(evals, n));
+  out_vec(u.coeffs, coeffs); out_vec(u.compress(), compressed);
+  Fq e = u.evaluate(limbs(r)); memcpy(eval_at_r, e.l, 32);
+}
 void orc_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
   Fq s = fq_zero(); for (size_t i = 0; i < n; i++) s += limbs(a + 4 * i) * limbs(b + 4 * i); memcpy(out, s.l, 32);
 }

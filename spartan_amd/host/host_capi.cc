@@ -81,6 +81,23 @@ void* spz_instance_synthetic(void* ctx, size_t num_cons, size_t num_vars, size_t
     return p.release();
   });
 }
+// UniPoly::from_evals / compress / evaluate (unipoly.rs) on n = 3 or 4 evaluations; scalars as Montgomery limbs. Test hook.
+int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint64_t* coeffs, uint64_t* compressed, uint64_t eval_at_r[4]) {
+  try {
+    FqVec e(n), c, cc;
+    memcpy(e.data(), evals, 32 * n);
+    Fq rr, ev;
+    memcpy(rr.l, r, 32);
+    unipoly_probe(e, rr, &c, &cc, &ev);
+    memcpy(coeffs, c.data(), 32 * c.size());
+    memcpy(compressed, cc.data(), 32 * cc.size());
+    memcpy(eval_at_r, ev.l, 32);
+    return 0;
+  } catch (const std::exception& ex) {
+    g_err = ex.what();
+    return -1;
+  }
+}
 void spz_seed_scalar(const char* domain, uint64_t seed, uint64_t out[4]) { Fq s = seed_scalar(domain, seed); memcpy(out, s.l, 32); }
 void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->digest.assign(d, d + n); }
 void spz_instance_free(void* i) { delete (Instance*)i; }

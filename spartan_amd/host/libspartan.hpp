@@ -38,6 +38,7 @@ struct Ctx {
 // lock-step; for a commitment of L rows rank r computes rows [r L/W, (r+1) L/W) and `gather` exchanges the 32-byte
 // compressed commitments (an all-gather of bytes: there is no elliptic-curve reduction in RCCL and none is needed).
 // gather(user, buf, total, off, len): on entry buf[off, off+len) holds this rank's bytes; on return buf[0,total) is complete.
+void unipoly_probe(const FqVec& evals, const Fq& r, FqVec* coeffs, FqVec* compressed, Fq* eval_at_r);  // test hook
 typedef int (*CommitGatherFn)(void* user, uint8_t* buf, size_t total, size_t off, size_t len);
 void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user);  // world <= 1 clears it
 struct DevTable {  // DensePolynomial with Z resident in HBM (src/dense_mlpoly.rs:14-18)

@@ -382,6 +382,13 @@ struct UniPoly {  // unipoly.rs
     t.append_message(label, "UniPoly_end");
   }
 };
+// test hook (tests/test_host_transcript.py): the reference's own UniPoly known answers (unipoly.rs:127-183)
+void unipoly_probe(const FqVec& evals, const Fq& r, FqVec* coeffs, FqVec* compressed, Fq* eval_at_r) {
+  UniPoly u = UniPoly::from_evals(evals);
+  *coeffs = u.coeffs;
+  *compressed = u.compress();
+  *eval_at_r = u.evaluate(r);
+}
 static Fq dot_host(const FqVec& a, const FqVec& b) {
   Fq s = fq_zero();
   for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i];

@@ -160,6 +160,20 @@ def test_vecmat_dot_evaluate_match_oracle(ctx, orc, v):
     t.free(); tb.free()
 
 
+def test_polynomial_evaluation_known_answer_on_device(ctx):
+    """dense_mlpoly.rs:433-452 check_polynomial_evaluation: Z = [1,2,1,4], r = [4,3] -> 28, via sp_evaluate and via the
+    L/R factorisation (sp_vecmat + host dot) the PolyEvalProof uses"""
+    from spartan_amd import capi
+    t = capi.Table.upload(ctx, mont_array([1, 2, 1, 4]), 4)
+    assert from_mont_limbs(capi.evaluate(ctx, t, mont_array([4, 3]), 2)) == 28
+    L = [(1 - 4) % Q, 4]; R_ = [(1 - 3) % Q, 3]           # EqPolynomial::compute_factored_evals (dense_mlpoly.rs:86-98)
+    LZ = from_mont_array(capi.vecmat(ctx, mont_array(L), 2, t), 2)
+    assert sum(a * b for a, b in zip(LZ, R_)) % Q == 28
+    chi = capi.Table.eq(ctx, mont_array([4, 3]), 2)
+    assert from_mont_array(chi.download(), 4) == [(a * b) % Q for a in L for b in R_]  # check_memoized_factored_chis
+    t.free(); chi.free()
+
+
 def test_background_commit_overlaps_and_matches(ctx, orc, gens40):
     """sp_commit_rows_dev_begin / sp_job_wait: the commit runs on the background stream while main-stream calls proceed;
     both results are bit-exact (the job must observe Z as written before begin, and its scratch must not alias)."""

@@ -276,3 +276,46 @@ def test_rectangular_instances_match_oracle(P, ctx, orc, lc, lv, ni):
     onp = vp(orc.orc_nizk_prove(oi, ong, b"rect", sz(4), b"nizk_example", tape, None))
     assert gotn == oracle_bytes(orc, onp)
     ngens.free(); enc.free(); gens.free(); inst.free()
+
+
+def test_tiny_r1cs_of_the_reference(P, ctx, orc):
+    """r1csproof.rs:474-560 produce_tiny_r1cs: three hand-written constraints in a 128 x 256 instance with 2 inputs — almost
+    every row and column of A, B, C is empty, and B, C address the constant and the inputs. is_sat, NIZK and SNARK bytes
+    equal the oracle's and verify."""
+    num_cons, num_vars, num_inputs = 128, 256, 2
+    le = lambda x: (x % Q).to_bytes(32, "little")
+    A = [(0, 0, le(1)), (0, 1, le(1)), (1, 0, le(1)), (1, num_vars + 2, le(1)), (2, 4, le(1))]
+    B = [(0, num_vars + 1, le(1)), (1, 2, le(1)), (2, num_vars, le(1))]
+    C = [(0, 2, le(1)), (1, 3, le(1))]
+    rng = random.Random(11)
+    i0, i1, z1, z2 = (rng.randrange(Q) for _ in range(4))
+    z3 = (z1 + z2) * i0 % Q
+    z4 = (z1 + i1) * z3 % Q
+    vars_py = [z1, z2, z3, z4, 0] + [0] * (num_vars - 5)
+    nnz = [len(A), len(B), len(C)]
+    ent = A + B + C
+    rows = (ctypes.c_uint64 * len(ent))(*[e[0] for e in ent]); cols = (ctypes.c_uint64 * len(ent))(*[e[1] for e in ent])
+    vals = b"".join(e[2] for e in ent)
+    vars_ = mont_array(vars_py); inputs = mont_array([i0, i1])
+    inst = P.Instance.new(ctx, num_cons, num_vars, num_inputs, nnz, rows, cols, vals)
+    err = ctypes.c_int(0)
+    oi = vp(orc.orc_instance_new_padded(sz(num_cons), sz(num_vars), sz(num_inputs), (sz * 3)(*nnz), rows, cols, vals, vars_, sz(num_vars), inputs,
+                                        ctypes.byref(err)))
+    assert err.value == 0 and oi and orc.orc_instance_is_sat(oi) == 1
+    tape = P.seed_scalar(b"tape", 5)
+    gens = P.SNARKGens(ctx, num_cons, num_vars, num_inputs, 5)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    got = P.SNARK.prove(ctx, inst, enc, vars_, inputs, gens, b"snark_example", tape)
+    og = vp(orc.orc_snark_gens_new(sz(num_cons), sz(num_vars), sz(num_inputs), sz(5)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
+    assert orc.orc_snark_verify(op, oi, og, oe, b"snark_example") == 1
+    assert got == oracle_bytes(orc, op)
+    inst.set_digest(b"tiny")
+    ngens = P.NIZKGens(ctx, num_cons, num_vars, num_inputs)
+    got = P.NIZK.prove(ctx, inst, vars_, inputs, ngens, b"nizk_example", tape)
+    ong = vp(orc.orc_nizk_gens_new(sz(num_cons), sz(num_vars), sz(num_inputs)))
+    onp = vp(orc.orc_nizk_prove(oi, ong, b"tiny", sz(4), b"nizk_example", tape, None))
+    assert orc.orc_nizk_verify(onp, oi, ong, b"tiny", sz(4), b"nizk_example") == 1
+    assert got == oracle_bytes(orc, onp)
+    ngens.free(); enc.free(); gens.free(); inst.free()

@@ -304,3 +304,48 @@ def test_oracle_verifies_its_own_serialized_bytes(orc):
     assert verify(bytes(bad)) in (0, -1)                # a flipped bit is rejected (or is no longer a canonical scalar)
     bad = bytearray(good); bad[40] ^= 1                 # inside comm_vars
     assert verify(bytes(bad)) in (0, -1)
+
+
+# ---- the reference's own known answers for the polynomial layer (unipoly.rs:127-183, dense_mlpoly.rs:433-452) ----
+UNIPOLY_KATS = [  # (evaluations at 0,1,2[,3]) -> coefficients low..high, (point, value)
+    ([1, 6, 15], [1, 3, 2], (3, 28)),          # 2x^2 + 3x + 1
+    ([1, 7, 23, 55], [1, 3, 2, 1], (4, 109)),  # x^3 + 2x^2 + 3x + 1
+]
+
+
+def _unipoly(lib, fn, evals, r):
+    n = len(evals)
+    co = (ctypes.c_uint64 * (4 * n))(); cc = (ctypes.c_uint64 * (4 * (n - 1)))(); ev = (ctypes.c_uint64 * 4)()
+    getattr(lib, fn)(mont_array(evals), sz(n), mont_array([r]), co, cc, ev)
+    return from_mont_array(co, n), from_mont_array(cc, n - 1), from_mont_array(ev, 1)[0]
+
+
+@pytest.mark.parametrize("evals,coeffs,pt", UNIPOLY_KATS)
+def test_unipoly_known_answers_oracle(orc, evals, coeffs, pt):
+    co, cc, ev = _unipoly(orc, "orc_unipoly_probe", evals, pt[0])
+    assert co == coeffs and ev == pt[1]
+    assert cc == [coeffs[0]] + coeffs[2:]           # CompressedUniPoly drops the linear term (unipoly.rs:82-88)
+    assert coeffs[0] == evals[0] and sum(coeffs) % Q == evals[1]  # eval_at_zero / eval_at_one
+
+
+@pytest.mark.parametrize("evals,coeffs,pt", UNIPOLY_KATS)
+def test_unipoly_known_answers_host_driver(evals, coeffs, pt):
+    from spartan_amd import prover
+    co, cc, ev = _unipoly(prover.H, "spz_unipoly_probe", evals, pt[0])
+    assert co == coeffs and ev == pt[1] and cc == [coeffs[0]] + coeffs[2:]
+
+
+def test_polynomial_evaluation_known_answer(orc):
+    """dense_mlpoly.rs:433-452: Z = [1,2,1,4], r = [4,3] -> 28, directly and through the L/R factorisation"""
+    Z, r = [1, 2, 1, 4], [4, 3]
+    chi = (ctypes.c_uint64 * 16)()
+    orc.orc_eq_evals(mont_array(r), sz(2), chi)
+    out = (ctypes.c_uint64 * 4)()
+    orc.orc_dot(mont_array(Z), chi, sz(4), out)
+    assert from_mont_array(out, 1)[0] == 28
+    L = (ctypes.c_uint64 * 8)(); R = (ctypes.c_uint64 * 8)()
+    orc.orc_eq_evals(mont_array(r[:1]), sz(1), L); orc.orc_eq_evals(mont_array(r[1:]), sz(1), R)
+    LZ = (ctypes.c_uint64 * 8)()
+    orc.orc_bound_vecmat(mont_array(Z), sz(2), L, LZ)
+    orc.orc_dot(LZ, R, sz(2), out)
+    assert from_mont_array(out, 1)[0] == 28
