@@ -30,10 +30,44 @@ struct CallStats {
   }
 };
 static CallStats g_calls;
+#ifdef SPZ_HOSTPROF
+// diagnostic build only: host-exclusive time per driver function = wall - device-API time - nested spans
+static double g_api_t = 0;
+struct HostSpan {
+  const char* name; double t0, api0, child = 0; HostSpan* parent;
+  static HostSpan*& top() { static HostSpan* t = nullptr; return t; }
+  static std::map<std::string, std::pair<double, size_t>>& acc() { static std::map<std::string, std::pair<double, size_t>> m; return m; }
+  explicit HostSpan(const char* n) : name(n), t0(now_s()), api0(g_api_t), parent(top()) { top() = this; }
+  ~HostSpan() {
+    double wall = now_s() - t0, api = g_api_t - api0;
+    auto& e = acc()[name]; e.first += wall - api - child; e.second++;
+    if (parent) parent->child += wall - api;
+    top() = parent;
+  }
+  static void dump() {
+    for (auto& kv : acc()) fprintf(stderr, "[hostprof] %-28s %6zu calls %9.3f ms host-exclusive\n", kv.first.c_str(), kv.second.second, kv.second.first * 1e3);
+    acc().clear();
+  }
+};
+#define HSPAN(n) HostSpan hspan_(n)
+#define HAPI(dt) g_api_t += (dt)
+#else
+#define HSPAN(n)
+#define HAPI(dt)
+#endif
+#ifdef SPZ_HOSTPROF
+#define SPX_T0(v) v = now_s();
+#define SPX_T1(v) HAPI(now_s() - v);
+#else
+#define SPX_T0(v)
+#define SPX_T1(v)
+#endif
 #define SPX(call)                                                                                        \
   do {                                                                                                   \
-    double t0_ = g_calls.on ? now_s() : 0;                                                               \
+    double t0_ = (g_calls.on || sizeof(#call) == 0) ? now_s() : 0;                                       \
+    SPX_T0(t0_)                                                                                          \
     int32_t rc_ = (call);                                                                                \
+    SPX_T1(t0_)                                                                                          \
     if (g_calls.on) {                                                                                    \
       std::string k_(#call);                                                                             \
       auto& e_ = g_calls.m[k_.substr(0, k_.find('('))];                                                  \
@@ -303,7 +337,7 @@ static CP commit_vec(sp_ctx* c, const FqVec& v, const Fq& blind, const MultiComm
   return msm_rows(c, gn.g, idx, s, 1)[0];
 }
 // DensePolynomial::commit (dense_mlpoly.rs:179-204): L row commitments of the R-wide rows of a device table
-static PolyCommitment poly_commit(sp_ctx* c, const DevTable& Z, size_t num_vars, const PolyCommitmentGens& gens, const FqVec* blinds) {
+static PolyCommitment poly_commit(sp_ctx* c, const DevTable& Z, size_t num_vars, const PolyCommitmentGens& gens, const FqVec* blinds) { HSPAN("poly_commit");
   size_t Ls = pow2(num_vars / 2), Rs = pow2(num_vars - num_vars / 2);
   const MultiCommitGens& g = gens.gens.gens_n;
   REQUIRE(g.n() == Rs && Z.len() == Ls * Rs);
@@ -322,14 +356,14 @@ static PolyCommitment poly_commit(sp_ctx* c, const DevTable& Z, size_t num_vars,
   for (size_t i = 0; i < Ls; i++) pc.C[i] = to_cp(&out[32 * i]);
   return pc;
 }
-static void append_poly_commitment(Transcript& t, const char* label, const PolyCommitment& c) {  // dense_mlpoly.rs:292-300
+static void append_poly_commitment(Transcript& t, const char* label, const PolyCommitment& c) { HSPAN("append_poly_commitment");  // dense_mlpoly.rs:292-300
   t.append_message(label, "poly_commitment_begin");
   for (auto& pt : c.C) t.append_point("poly_commitment_share", pt.data());
   t.append_message(label, "poly_commitment_end");
 }
 
 // ------------------------------------------------------------------ small host-side algebra (O(log n) / O(sqrt n) sized)
-static FqVec eq_evals_host(const FqVec& r) {  // EqPolynomial::evals (dense_mlpoly.rs:68-84); used only for the sqrt(N)-sized L/R vectors
+static FqVec eq_evals_host(const FqVec& r) { HSPAN("eq_evals_host");  // EqPolynomial::evals (dense_mlpoly.rs:68-84); used only for the sqrt(N)-sized L/R vectors
   size_t ell = r.size();
   FqVec evals(pow2(ell), fq_one());
   size_t size = 1;
@@ -396,7 +430,7 @@ static Fq dot_host(const FqVec& a, const FqVec& b) {
 }
 
 // ------------------------------------------------------------------ nizk/mod.rs Sigma protocols
-static KnowledgeProof knowledge_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& x, const Fq& r, CP* C_out) {
+static KnowledgeProof knowledge_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& x, const Fq& r, CP* C_out) { HSPAN("knowledge_prove");
   t.append_protocol_name("knowledge proof");  // :27-52
   Fq t1 = tape.random_scalar("t1"), t2 = tape.random_scalar("t2");
   std::vector<CP> cm = msm_rows(c, g.g, {g.G[0], g.h}, {x, r, t1, t2}, 2);
@@ -407,7 +441,7 @@ static KnowledgeProof knowledge_prove(sp_ctx* c, const MultiCommitGens& g, Trans
   return KnowledgeProof{cm[1], x * ch + t1, r * ch + t2};
 }
 static EqualityProof equality_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& v1, const Fq& s1, const Fq& v2,
-                                    const Fq& s2) {
+                                    const Fq& s2) { HSPAN("equality_prove");
   t.append_protocol_name("equality proof");  // :88-116
   Fq r = tape.random_scalar("r");
   std::vector<CP> cm = msm_rows(c, g.g, {g.G[0], g.h}, {v1, s1, v2, s2, fq_zero(), r}, 3);  // C1, C2, alpha = r*h
@@ -418,7 +452,7 @@ static EqualityProof equality_prove(sp_ctx* c, const MultiCommitGens& g, Transcr
   return EqualityProof{cm[2], ch * (s1 - s2) + r};
 }
 static ProductProof product_prove(sp_ctx* c, const MultiCommitGens& g, Transcript& t, RandomTape& tape, const Fq& x, const Fq& rX, const Fq& y,
-                                  const Fq& rY, const Fq& z, const Fq& rZ, CP* Xo, CP* Yo, CP* Zo) {
+                                  const Fq& rY, const Fq& z, const Fq& rZ, CP* Xo, CP* Yo, CP* Zo) { HSPAN("product_prove");
   t.append_protocol_name("product proof");  // :159-227
   Fq b1 = tape.random_scalar("b1"), b2 = tape.random_scalar("b2"), b3 = tape.random_scalar("b3");
   Fq b4 = tape.random_scalar("b4"), b5 = tape.random_scalar("b5");
@@ -443,7 +477,7 @@ static ProductProof product_prove(sp_ctx* c, const MultiCommitGens& g, Transcrip
 // kind 0: prove_quad (:428-586), tables (A,B), comb A*B, gens_n = gens_3
 static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& claim, const Fq& blind_claim, size_t num_rounds,
                                                  std::vector<sp_table*> tabs, const MultiCommitGens& g1, const MultiCommitGens& gn, Transcript& t,
-                                                 RandomTape& tape, FqVec* r_out, FqVec* final_claims, Fq* blind_post) {
+                                                 RandomTape& tape, FqVec* r_out, FqVec* final_claims, Fq* blind_post) { HSPAN("zk_sumcheck_prove");
   FqVec blinds_poly = tape.random_vector("blinds_poly", num_rounds);
   FqVec blinds_evals = tape.random_vector("blinds_evals", num_rounds);
   Fq claim_per_round = claim;
@@ -553,7 +587,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
 
 // ------------------------------------------------------------------ DotProductProofLog (nizk/mod.rs:440-525) + bullet.rs:32-132
 static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGens& gens, Transcript& t, RandomTape& tape, const FqVec& x,
-                                              const Fq& blind_x, const FqVec& a, const Fq& y, const Fq& blind_y, CP* Cy_out) {
+                                              const Fq& blind_x, const FqVec& a, const Fq& y, const Fq& blind_y, CP* Cy_out) { HSPAN("dotproductlog_prove");
   t.append_protocol_name("dot product proof (log)");
   size_t n = x.size();
   REQUIRE(a.size() == n && gens.n == n);
@@ -611,7 +645,7 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
 
 // PolyEvalProof::prove (dense_mlpoly.rs:312-365)
 static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec* blinds_opt, const FqVec& r, const Fq& Zr, const Fq* blind_Zr_opt,
-                                    const PolyCommitmentGens& gens, Transcript& t, RandomTape& tape, CP* C_Zr) {
+                                    const PolyCommitmentGens& gens, Transcript& t, RandomTape& tape, CP* C_Zr) { HSPAN("polyeval_prove");
   t.append_protocol_name("polynomial evaluation proof");
   size_t Ls = pow2(r.size() / 2), Rs = pow2(r.size() - r.size() / 2);
   REQUIRE(poly.len() == Ls * Rs);
@@ -632,7 +666,7 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
 
 // ------------------------------------------------------------------ R1CSProof::prove (r1csproof.rs:144-349)
 static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& input, const R1CSGens& gens,
-                            Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm) {
+                            Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm) { HSPAN("r1cs_prove");
   double t0 = now_s();
   t.append_protocol_name("R1CS proof");
   // lib.rs:360-368 / 519-526: the assignment is zero-padded to the instance's (padded) num_vars — done in the device table

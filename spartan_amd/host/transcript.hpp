@@ -3,6 +3,7 @@
 // over Merlin 1.0 (STROBE-128 / Keccak-f[1600]); SHAKE256 for MultiCommitGens::new (src/commitments.rs:16-24).
 // The transcript stays on the host exactly as it stays in Rust in the drop-in design.
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -16,7 +17,20 @@ using sp::Fq;
 inline uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }  // n in 1..63
 
 // Keccak-f[1600], state kept in 25 locals (A[x + 5y]); theta, rho+pi and chi written out per lane.
+#ifdef SPZ_HOSTPROF
+struct KeccakProf { uint64_t n = 0; double t = 0; };
+inline KeccakProf& keccak_prof() { static KeccakProf p; return p; }
+inline void keccak_f1600_impl(uint64_t A[25]);
 inline void keccak_f1600(uint64_t A[25]) {
+  auto t0 = std::chrono::steady_clock::now();
+  keccak_f1600_impl(A);
+  keccak_prof().t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  keccak_prof().n++;
+}
+inline void keccak_f1600_impl(uint64_t A[25]) {
+#else
+inline void keccak_f1600(uint64_t A[25]) {
+#endif
   static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
                                   0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
                                   0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
@@ -121,18 +135,31 @@ class Strobe128 {  // STROBE v1.0.2, the subset Merlin uses (AD, meta-AD, PRF), 
     pos_ = 0;
     pos_begin_ = 0;
   }
+  // duplex in runs of up to R - pos bytes (a proof absorbs ~1.3 MB: every commitment share and the vectors of the
+  // inner-product arguments), the permutation runs exactly where the byte-at-a-time definition runs it
   void absorb(const uint8_t* d, size_t n) {
     uint8_t* s = (uint8_t*)st_;
-    for (size_t i = 0; i < n; i++) {
-      s[pos_++] ^= d[i];
+    while (n) {
+      size_t k = (size_t)R - pos_;
+      if (k > n) k = n;
+      uint8_t* dst = s + pos_;
+      for (size_t i = 0; i < k; i++) dst[i] ^= d[i];
+      pos_ = (uint8_t)(pos_ + k);
+      d += k;
+      n -= k;
       if (pos_ == R) run_f();
     }
   }
   void squeeze(uint8_t* out, size_t n) {
     uint8_t* s = (uint8_t*)st_;
-    for (size_t i = 0; i < n; i++) {
-      out[i] = s[pos_];
-      s[pos_++] = 0;
+    while (n) {
+      size_t k = (size_t)R - pos_;
+      if (k > n) k = n;
+      memcpy(out, s + pos_, k);
+      memset(s + pos_, 0, k);
+      pos_ = (uint8_t)(pos_ + k);
+      out += k;
+      n -= k;
       if (pos_ == R) run_f();
     }
   }
