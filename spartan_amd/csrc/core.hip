@@ -236,7 +236,12 @@ __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ i
   if (t == 0) out[row * nchunks + ck] = sm[0];
 }
 // one block per row: sum the row's partials, RFC 9496 encode. IN10: partials already in Pt10 form (second pass).
-template <bool IN10>
+// ENCODE = false: the sum is written as an extended point (4 x 32 B, canonical coordinates) and the caller encodes it on
+// the host. The encode is ONE serial chain of ~265 field multiplications (an inverse square root): ~100 us for a lone
+// wavefront at one instruction per ~5 cycles, ~3 us for a CPU core with a 64-bit multiplier. Commitments of a few rows
+// (every Sigma-protocol and inner-product round: 151 sequential ones per 2^20 proof) take the host route, batched row
+// commitments (hundreds of rows in parallel) the device route.
+template <bool IN10, bool ENCODE>
 __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ partial_, size_t nstrips, uint8_t* __restrict__ out) {
   __shared__ Pt10 sm[256];
   size_t row = blockIdx.x;
@@ -257,11 +262,15 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ par
     __syncthreads();
   }
   if (t == 0) {
-    uint8_t c[32];
     Pt10 r = sm[0];
-    fe10_pin(r.X); fe10_pin(r.Y); fe10_pin(r.Z); fe10_pin(r.T);
-    pt10_compress(r, c);
-    for (int k = 0; k < 32; k++) out[32 * row + k] = c[k];
+    if (ENCODE) {
+      uint8_t c[32];
+      fe10_pin(r.X); fe10_pin(r.Y); fe10_pin(r.Z); fe10_pin(r.T);
+      pt10_compress(r, c);
+      for (int k = 0; k < 32; k++) out[32 * row + k] = c[k];
+    } else {
+      ((Pt*)out)[row] = Pt{fe10_to_fp(r.X), fe10_to_fp(r.Y), fe10_to_fp(r.Z), fe10_to_fp(r.T)};
+    }
   }
 }
 
@@ -427,6 +436,7 @@ void sp_gens_free(sp_gens* g) {
   delete g;
 }
 
+constexpr size_t SP_HOST_ENCODE_ROWS = 8;  // commitments of up to this many rows are encoded by the host core (see k_msm_reduce)
 // MSM launch plan: kernel shapes and scratch sizes for a (rows x cols) fixed-base commit
 struct MsmPlan {
   bool windowed, two_pass;
@@ -453,8 +463,10 @@ static MsmPlan msm_plan(size_t rows, size_t cols, bool has_blinds) {
   return m;
 }
 // enqueue the kernels of one commit on `st`; scratch holds part_bytes + part2_bytes; dout receives 32*rows bytes
+// (encode) or, with encode = false, 128*rows bytes of extended points
 static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows,
-                        size_t cols, size_t g_off, const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* scratch, uint8_t* dout) {
+                        size_t cols, size_t g_off, const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* scratch, uint8_t* dout,
+                        bool encode = true) {
   size_t total = rows * cols;
   Pt* partial = (Pt*)scratch;
   Pt10* partial2 = (Pt10*)(scratch + m.part_bytes);
@@ -479,10 +491,12 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
       hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)m.nchunks), dim3(256), 0, st, (const Pt*)partial, m.P, m.chunk, partial2);
     }
     ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.nchunks * sizeof(Pt10)) + 32.0 * (double)rows);
-    hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
+    if (encode) hipLaunchKernelGGL((k_msm_reduce<true, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
+    else hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
   } else {
     ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.P * sizeof(Pt)) + 32.0 * (double)rows);
-    hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
+    if (encode) hipLaunchKernelGGL((k_msm_reduce<false, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
+    else hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
   }
 }
 // core: Z on device (row stride in elements), optional idx (device), optional blinds (device); synchronous
@@ -490,6 +504,14 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
   MsmPlan m = msm_plan(rows, cols, dblinds != nullptr);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + 32 * rows));
+  if (rows <= SP_HOST_ENCODE_ROWS) {  // latency path: the device sums, the host core runs the encode chain
+    msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, hres(c), false);
+    Pt sums[SP_HOST_ENCODE_ROWS];
+    SPCHK(fetch_small(c, sums, sizeof(Pt) * rows));
+    if (hipGetLastError() != hipSuccess) return SP_EHIP;
+    for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
+    return SP_OK;
+  }
   bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
   uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + m.part_bytes + m.part2_bytes;
   msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, dout);
