@@ -54,6 +54,7 @@ int32_t ensure_pinned(sp_ctx* c, size_t need) {
 void prof_drain(sp_ctx* c) {
   if (c->pending.empty()) return;
   (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream_bg);
   for (auto& r : c->pending) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -161,20 +162,20 @@ __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __res
 // thread <-> (row, strip): accumulates sum_{j in strip} Z[row][j] * P[col(j)] into one extended point.
 // Lanes run fastest over rows so a wave shares the generator (and its 12 KiB window sub-table) whenever
 // rows >= 64: table gathers then hit L1/L2, while the scalar load (32 B per 32 additions) is the strided one.
-__global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
-                                                  size_t nstrips, const Niels* __restrict__ table, size_t g_off,
-                                                  const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx,
-                                                  Pt* __restrict__ partial, int xcd_map) {
+__device__ __forceinline__ void msm_rows_tile(size_t lb, unsigned tid, const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols,
+                                              size_t strip, size_t nstrips, const Niels* __restrict__ table, size_t g_off,
+                                              const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial,
+                                              int xcd_map) {
   size_t row, s;
   if (xcd_map) {
     // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): all row-blocks of a column strip are
     // given to the SAME XCD, back to back, so the strip's window tables are fetched into one L2 instead of eight.
-    size_t rb_count = rows / 256, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
+    size_t rb_count = rows / 256, xcd = lb % 8, k = lb / 8;
     s = xcd + 8 * (k / rb_count);
     if (s >= nstrips) return;
-    row = (k % rb_count) * 256 + threadIdx.x;
+    row = (k % rb_count) * 256 + tid;
   } else {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = lb * 256 + tid;
     if (t >= rows * nstrips) return;
     row = t % rows;
     s = t / rows;
@@ -189,6 +190,23 @@ __global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size
   }
   if (blinds && s == 0) msm_accumulate(acc, ld_fq(blinds + row), table, h_idx);
   partial[row * nstrips + s] = acc;
+}
+__global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
+                                                  size_t nstrips, const Niels* __restrict__ table, size_t g_off,
+                                                  const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx,
+                                                  Pt* __restrict__ partial, int xcd_map) {
+  msm_rows_tile(blockIdx.x, threadIdx.x, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, idx, blinds, h_idx, partial, xcd_map);
+}
+// Background form: persistent 1024-thread workgroups, launched on fewer workgroups than the chip has CUs. At 127 VGPRs a
+// CU holds exactly one of them (16 waves, 508 of 512 registers per lane), so the CUs left over cannot receive a second
+// MSM workgroup and the main stream keeps a reserve of idle CUs for its latency-bound kernels — the partition a CU mask
+// would give, which this platform does not honour.
+__global__ void __launch_bounds__(1024) k_msm_rows_bg(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
+                                                      size_t nstrips, const Niels* __restrict__ table, size_t g_off, Pt* __restrict__ partial,
+                                                      int xcd_map, size_t ntiles) {
+  extern __shared__ uint8_t occupancy_fence[];
+  for (size_t lb = (size_t)blockIdx.x * 4 + threadIdx.x / 256; lb < ntiles; lb += (size_t)gridDim.x * 4)
+    msm_rows_tile(lb, threadIdx.x % 256, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, nullptr, nullptr, 0, partial, xcd_map);
 }
 // Latency-bound shapes (Sigma-protocol commits, IPA rounds, single-row commits): one thread per (row, column,
 // window) performs a single table lookup, so the serial chain per thread is one mixed addition instead of 32.
@@ -313,20 +331,24 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   memset(c->prof_ms, 0, sizeof c->prof_ms);
   memset(c->prof_n, 0, sizeof c->prof_n);
   memset(c->prof_bytes, 0, sizeof c->prof_bytes);
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   {
-    // Background stream confined to 7/8 of the CUs: a long-running MSM cannot be preempted, so without a reserve the
-    // latency-critical kernels of the main stream would queue behind its workgroups for milliseconds.
+    // main stream: the Fiat-Shamir critical path, highest priority; background stream: throughput MSMs queued under it,
+    // lowest priority. (CU masks would be the cleaner partition, but hipExtStreamCreateWithCUMask is not honoured on this
+    // platform: it succeeds, and a 1/8 mask runs an MSM exactly as fast as 8/8 — bench/bg_probe.py.)
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream_bg, hipStreamNonBlocking, lo));
+    // background MSMs: one 1024-thread workgroup per CU on half of the CUs (k_msm_rows_bg). Measured at 2^20 with the
+    // derefs row half in the background, share in eighths 2 / 3 / 4 / 5 / 6 / 8 -> 63.1 / 59.2 / 58.0 / 59.0 / 61.5 / 62.5 ms
+    // per proof (63.3 without the overlap): less and the MSM is not done when it is needed, more and the second
+    // sum-check's kernels queue behind MSM workgroups.
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
-    int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-    std::vector<uint32_t> mask(words, 0);
-    for (int i = 0; i < ncu; i++)
-      if (i % 8 != 7) mask[i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&c->stream_bg, (uint32_t)words, mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      HIPCHK(hipStreamCreateWithFlags(&c->stream_bg, hipStreamNonBlocking));
-    }
+    int share = 4;
+    if (const char* e = getenv("SPARTAN_BG_EIGHTHS")) { int v = atoi(e); if (v >= 0 && v <= 8) share = v; }
+    c->bg_lds = 0;
+    c->bg_blocks = prop.multiProcessorCount * share / 8;
   }
   HIPCHK(hipHostMalloc((void**)&c->hmap, HMAP_SIZE, hipHostMallocDefault));
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
@@ -470,8 +492,8 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
   size_t total = rows * cols;
   Pt* partial = (Pt*)scratch;
   Pt10* partial2 = (Pt10*)(scratch + m.part_bytes);
-  sp_ctx* pc = prof ? c : nullptr;  // HIP-event timing only for work on the main stream
-  auto scope = [&](int fam, double bytes) { return ProfScope(pc ? pc : c, pc ? fam : -1, bytes); };
+  (void)prof;
+  auto scope = [&](int fam, double bytes) { return ProfScope(c, fam, bytes, st); };  // HIP events on the stream the kernels run on
   if (m.windowed) {
     ProfScope ps = scope(PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * m.P));
     size_t nthreads = rows * m.P;
@@ -482,8 +504,13 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     ProfScope ps = scope(PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
-    hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips, (const Niels*)g->table,
-                       g_off, didx, dblinds, h_idx, partial, xcd_map);
+    if (st != c->stream && !didx && !dblinds && c->bg_blocks > 0) {
+      hipLaunchKernelGGL(k_msm_rows_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
+                         (const Niels*)g->table, g_off, partial, xcd_map, nblocks);
+    } else {
+      hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
+                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map);
+    }
   }
   if (m.two_pass) {
     {

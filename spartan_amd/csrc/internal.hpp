@@ -47,6 +47,8 @@ struct sp_ctx {
   int dev;
   hipStream_t stream;
   hipStream_t stream_bg;  // lower-priority background stream: throughput MSMs overlapped with latency-bound rounds
+  int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
+  size_t bg_lds;          // dynamic LDS each of them claims (a whole CU's)
   // scratch
   void* scratch;
   size_t scratch_cap;
@@ -108,7 +110,9 @@ struct ProfScope {
   int fam;
   hipEvent_t e0, e1;
   bool on;
-  ProfScope(sp_ctx* c_, int fam_, double bytes) : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)) {
+  hipStream_t st;  // the stream the timed kernels are launched on
+  ProfScope(sp_ctx* c_, int fam_, double bytes, hipStream_t st_ = nullptr)
+      : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)), st(st_ ? st_ : c_->stream) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -123,11 +127,11 @@ struct ProfScope {
     e0 = get();
     e1 = get();
     c->prof_bytes[fam] += bytes;
-    (void)hipEventRecord(e0, c->stream);
+    (void)hipEventRecord(e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventRecord(e1, st);
     c->pending.push_back(ProfRec{e0, e1, fam});
   }
 };

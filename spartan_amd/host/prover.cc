@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <mutex>
 
@@ -107,6 +108,7 @@ CommitShard commit_shard_of(sp_ctx* c) {
   return it == g_shard.end() ? CommitShard() : it->second;
 }
 }  // namespace
+static bool commit_shard_active(sp_ctx* c) { return commit_shard_of(c).world > 1; }
 void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user) {
   std::lock_guard<std::mutex> lk(g_shard_mu);
   if (world <= 1) { g_shard.erase(c.h); return; }
@@ -665,8 +667,10 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
 }
 
 // ------------------------------------------------------------------ R1CSProof::prove (r1csproof.rs:144-349)
+// on_rx: called as soon as the first sum-check has fixed rx (SNARK::prove starts work that only depends on rx there)
 static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& input, const R1CSGens& gens,
-                            Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm) { HSPAN("r1cs_prove");
+                            Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm,
+                            const std::function<void(const FqVec&)>* on_rx = nullptr) { HSPAN("r1cs_prove");
   double t0 = now_s();
   t.append_protocol_name("R1CS proof");
   // lib.rs:360-368 / 519-526: the assignment is zero-padded to the instance's (padded) num_vars — done in the device table
@@ -707,6 +711,7 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   P.sc_proof_phase1 = zk_sumcheck_prove(c, 2, fq_zero(), fq_zero(), num_rounds_x, {poly_tau.h, poly_Az.h, poly_Bz.h, poly_Cz.h},
                                         gens.gens_sc.gens_1, gens.gens_sc.gens_4, t, tape, &rx, &claims1, &blind_claim_postsc1);
   if (tm) tm->sc_phase_one = now_s() - t1;
+  if (on_rx) (*on_rx)(rx);
   const Fq &tau_claim = claims1[0], &Az_claim = claims1[1], &Bz_claim = claims1[2], &Cz_claim = claims1[3];
   Fq Az_blind = tape.random_scalar("Az_blind"), Bz_blind = tape.random_scalar("Bz_blind");
   Fq Cz_blind = tape.random_scalar("Cz_blind"), prod_Az_Bz_blind = tape.random_scalar("prod_Az_Bz_blind");
