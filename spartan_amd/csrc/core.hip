@@ -230,6 +230,51 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
   }
   partial[row * (ncol * MSM_NWIN) + (size_t)w * ncol + j] = acc;
 }
+// Latency path, fused form (rows <= SP_HOST_ENCODE_ROWS): grid (nblk, rows). Thread p of a row looks up the table entry
+// of its (column, window) pair and the block sums its 256 entries in an LDS tree, so a Sigma-protocol commitment is ONE
+// launch (nblk = 1, FINAL: the sum goes out as an extended point for the host to encode) and an inner-product round is two
+// (Pt10 partials, then k_msm_reduce) instead of three. An affine table entry (y+x, y-x, 2dxy) becomes the extended point
+// (2(yp-ym), 2(yp+ym), 4, (yp-ym)(yp+ym)) = 4*(x, y, 1, xy) with one multiplication.
+template <bool FINAL>
+__global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__ Z, size_t z_row_stride, size_t cols,
+                                                          const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
+                                                          const Fq* __restrict__ blinds, size_t h_idx, void* __restrict__ out) {
+  __shared__ Pt10 sm[256];
+  size_t ncol = cols + (blinds ? 1 : 0), P = ncol * MSM_NWIN, row = blockIdx.y;
+  int t = threadIdx.x;
+  size_t p = (size_t)blockIdx.x * 256 + t;
+  Pt10 acc = pt10_identity();
+  if (p < P) {
+    size_t j = p % ncol;
+    int w = (int)(p / ncol);
+    Fq sc = j < cols ? ld_fq(Z + row * z_row_stride + j) : ld_fq(blinds + row);
+    size_t pt = j < cols ? (idx ? (size_t)idx[j] : g_off + j) : h_idx;
+    if (!fq_is_zero(sc)) {
+      int d = msm_digit(fq_from_mont(sc), w);
+      if (d != 0) {
+        Niels n = table[msm_tidx(pt, w, d < 0 ? -d : d)];
+        Fp dx = fp_sub(n.yp, n.ym), sy = fp_add(n.yp, n.ym);
+        Fp X = fp_add(dx, dx), T = fp_mul(dx, sy);
+        if (d < 0) { X = fp_neg(X); T = fp_neg(T); }
+        acc = Pt10{fe10_load(X), fe10_load(fp_add(sy, sy)), Fe10{{4, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, fe10_load(T)};
+      }
+    }
+  }
+  sm[t] = acc;
+  __syncthreads();
+  size_t live = P - (size_t)blockIdx.x * 256;  // partial indices of this block that exist
+  int top = 128;
+  while (top > 1 && (size_t)top >= live) top >>= 1;
+  for (int s = top; s > 0; s >>= 1) {
+    if (t < s && (size_t)(t + s) < live) sm[t] = pt10_add(sm[t], sm[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    Pt10 r = sm[0];
+    if (FINAL) ((Pt*)out)[row] = Pt{fe10_to_fp(r.X), fe10_to_fp(r.Y), fe10_to_fp(r.Z), fe10_to_fp(r.T)};
+    else ((Pt10*)out)[row * gridDim.x + blockIdx.x] = r;
+  }
+}
 // reduction pass: grid (rows, nchunks); block sums `chunk` consecutive partials of its row into one point.
 // Reductions run on the radix-2^25.5 serial-chain arithmetic (fe10.hpp): few waves, latency-bound.
 __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt10* __restrict__ out) {
@@ -292,6 +337,17 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ par
   }
 }
 
+
+// RFC 9496 encode of many row sums at once: one LANE per row. (With the encode inside k_msm_reduce one lane per BLOCK runs
+// the ~100 us inverse-square-root chain while 255 wait: a 1024-row commit spent 0.6 ms there; this way the 1024 chains
+// run side by side in 16 wavefronts.)
+__global__ void __launch_bounds__(64) k_pt_encode(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) {
+  size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (row >= rows) return;
+  uint8_t c[32];
+  pt10_compress(pt10_load(in[row]), c);
+  for (int k = 0; k < 32; k++) out[32 * row + k] = c[k];
+}
 
 extern "C" {
 
@@ -488,10 +544,15 @@ static MsmPlan msm_plan(size_t rows, size_t cols, bool has_blinds) {
 // (encode) or, with encode = false, 128*rows bytes of extended points
 static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows,
                         size_t cols, size_t g_off, const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* scratch, uint8_t* dout,
-                        bool encode = true) {
+                        bool encode = true, uint8_t* sums_extra = nullptr /* 128*rows bytes for the row sums, or null */) {
   size_t total = rows * cols;
   Pt* partial = (Pt*)scratch;
   Pt10* partial2 = (Pt10*)(scratch + m.part_bytes);
+  // many rows: sums first, then one lane per row encodes (k_pt_encode). The sums reuse the head of the partial buffer of
+  // the pass that has already been consumed: two-pass -> `partial`, one-pass -> needs rows*128 B <= part2... so one-pass
+  // shapes keep them behind the partials (the caller's scratch has 32*rows spare there only when sums_extra is set)
+  bool batch_encode = encode && rows >= 64 && sums_extra != nullptr;
+  Pt* sums = (Pt*)sums_extra;
   (void)prof;
   auto scope = [&](int fam, double bytes) { return ProfScope(c, fam, bytes, st); };  // HIP events on the stream the kernels run on
   if (m.windowed) {
@@ -518,21 +579,46 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
       hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)m.nchunks), dim3(256), 0, st, (const Pt*)partial, m.P, m.chunk, partial2);
     }
     ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.nchunks * sizeof(Pt10)) + 32.0 * (double)rows);
-    if (encode) hipLaunchKernelGGL((k_msm_reduce<true, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
+    if (encode && batch_encode) hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, (uint8_t*)sums);
+    else if (encode) hipLaunchKernelGGL((k_msm_reduce<true, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
     else hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
   } else {
     ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.P * sizeof(Pt)) + 32.0 * (double)rows);
-    if (encode) hipLaunchKernelGGL((k_msm_reduce<false, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
+    if (encode && batch_encode) hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, (uint8_t*)sums);
+    else if (encode) hipLaunchKernelGGL((k_msm_reduce<false, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
     else hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
+  }
+  if (encode && batch_encode) {
+    ProfScope ps = scope(PF_MSM_REDUCE, 160.0 * (double)rows);
+    hipLaunchKernelGGL(k_pt_encode, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (const Pt*)sums, rows, dout);
   }
 }
 // core: Z on device (row stride in elements), optional idx (device), optional blinds (device); synchronous
 int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
   MsmPlan m = msm_plan(rows, cols, dblinds != nullptr);
-  SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + 32 * rows));
+  size_t out_al = (32 * rows + 255) & ~(size_t)255;
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
   if (rows <= SP_HOST_ENCODE_ROWS) {  // latency path: the device sums, the host core runs the encode chain
-    msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, hres(c), false);
+    if (m.windowed) {
+      size_t nblk = (m.P + 255) / 256;
+      Pt10* part = (Pt10*)c->scratch;  // nblk * rows * 160 B <= part_bytes
+      {
+        ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));
+        if (nblk == 1)
+          hipLaunchKernelGGL((k_msm_windows_tree<true>), dim3(1, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols, (const Niels*)g->table,
+                             g_off, didx, dblinds, h_idx, (void*)hres(c));
+        else
+          hipLaunchKernelGGL((k_msm_windows_tree<false>), dim3((unsigned)nblk, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols,
+                             (const Niels*)g->table, g_off, didx, dblinds, h_idx, (void*)part);
+      }
+      if (nblk > 1) {
+        ProfScope ps(c, PF_MSM_REDUCE, 160.0 * (double)(rows * nblk) + 128.0 * (double)rows);
+        hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)part, nblk, hres(c));
+      }
+    } else {
+      msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, hres(c), false);
+    }
     Pt sums[SP_HOST_ENCODE_ROWS];
     SPCHK(fetch_small(c, sums, sizeof(Pt) * rows));
     if (hipGetLastError() != hipSuccess) return SP_EHIP;
@@ -541,7 +627,8 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
   }
   bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
   uint8_t* dout = small_out ? hres(c) : (uint8_t*)c->scratch + m.part_bytes + m.part2_bytes;
-  msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, dout);
+  msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, dout, true,
+              (uint8_t*)c->scratch + m.part_bytes + m.part2_bytes + out_al);
   if (small_out) SPCHK(fetch_small(c, out_host, 32 * rows));
   else SPCHK(fetch_out(c, dout, out_host, 32 * rows));
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
@@ -552,7 +639,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
 struct sp_job {
   sp_ctx* ctx;
   uint8_t* scratch;
-  size_t scratch_bytes, rows;
+  size_t scratch_bytes, rows, out_off;
   hipEvent_t done;
 };
 int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
@@ -563,7 +650,9 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr;
-  j->scratch_bytes = m.part_bytes + m.part2_bytes + ((32 * rows + 255) & ~(size_t)255);
+  size_t out_al = (32 * rows + 255) & ~(size_t)255;
+  j->out_off = m.part_bytes + m.part2_bytes;
+  j->scratch_bytes = j->out_off + out_al + sizeof(Pt) * rows;
   int32_t rc = pool_alloc(c, j->scratch_bytes, (void**)&j->scratch);
   if (rc != SP_OK) { delete j; return rc; }
   hipEvent_t ready;
@@ -573,8 +662,8 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
   // the job reads Z as produced by everything queued so far on the main stream
   (void)hipEventRecord(ready, c->stream);
   (void)hipStreamWaitEvent(c->stream_bg, ready, 0);
-  msm_enqueue(c, c->stream_bg, false, m, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, nullptr, 0, j->scratch,
-              j->scratch + m.part_bytes + m.part2_bytes);
+  msm_enqueue(c, c->stream_bg, false, m, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, nullptr, 0, j->scratch, j->scratch + j->out_off, true,
+              j->scratch + j->out_off + out_al);
   (void)hipEventRecord(j->done, c->stream_bg);
   (void)hipEventDestroy(ready);
   if (hipGetLastError() != hipSuccess) { (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
@@ -592,9 +681,7 @@ int32_t sp_job_wait(sp_job* j, uint8_t* out) {
     if (e != hipErrorNotReady) { rc = SP_EHIP; break; }
   }
   if (rc == SP_OK) {
-    // result sits at the tail of the job scratch
-    size_t off = j->scratch_bytes - ((32 * j->rows + 255) & ~(size_t)255);
-    if (hipMemcpyAsync(out, j->scratch + off, 32 * j->rows, hipMemcpyDeviceToHost, c->stream_bg) != hipSuccess ||
+    if (hipMemcpyAsync(out, j->scratch + j->out_off, 32 * j->rows, hipMemcpyDeviceToHost, c->stream_bg) != hipSuccess ||
         hipStreamSynchronize(c->stream_bg) != hipSuccess)
       rc = SP_EHIP;
   }
