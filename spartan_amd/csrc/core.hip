@@ -76,14 +76,24 @@ void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes) {
   memcpy(c->hmap + off, src, bytes);
   return c->hmap + off;
 }
+__global__ void k_done(volatile uint32_t* flag, uint32_t seq) {
+  __threadfence_system();
+  *flag = seq;
+}
+// Wait until everything queued on the main stream has run. The stream is in-order, so the flag kernel runs after the
+// kernels (and copies) before it have completed, and their results in host memory precede the flag on the way to the host.
 int32_t sync_spin(sp_ctx* c) {
-  HIPCHK(hipEventRecord(c->sync_ev, c->stream));
-  for (;;) {
-    hipError_t e = hipEventQuery(c->sync_ev);
-    if (e == hipSuccess) return SP_OK;
-    if (e != hipErrorNotReady) {
-      fprintf(stderr, "spartan_hip: hipEventQuery failed: %s\n", hipGetErrorString(e));
-      return SP_EHIP;
+  uint32_t seq = ++c->done_seq;
+  hipLaunchKernelGGL(k_done, dim3(1), dim3(1), 0, c->stream, c->done_flag, seq);
+  for (uint64_t spins = 1;; spins++) {
+    if (*c->done_flag == seq) return SP_OK;
+    if ((spins & 0xFFFFF) == 0) {  // every ~ms: a faulted queue never delivers the flag
+      hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) return *c->done_flag == seq ? SP_OK : SP_EHIP;
+      if (e != hipErrorNotReady) {
+        fprintf(stderr, "spartan_hip: stream failed: %s\n", hipGetErrorString(e));
+        return SP_EHIP;
+      }
     }
   }
 }
@@ -381,6 +391,7 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   c->pinned = nullptr;
   c->pinned_cap = 0;
   c->hmap = nullptr;
+  c->done_flag = nullptr;
   c->prof_on = 0;
   c->prof_mask = ~0ULL;
   c->pool_bytes = 0;
@@ -407,6 +418,9 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
     c->bg_blocks = prop.multiProcessorCount * share / 8;
   }
   HIPCHK(hipHostMalloc((void**)&c->hmap, HMAP_SIZE, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&c->done_flag, 64, hipHostMallocDefault));
+  *c->done_flag = 0;
+  c->done_seq = 0;
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
   *out = c;
   return SP_OK;
@@ -423,6 +437,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->dstage) (void)hipFree(c->dstage);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->hmap) (void)hipHostFree(c->hmap);
+  if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   (void)hipEventDestroy(c->sync_ev);
   (void)hipStreamDestroy(c->stream_bg);
   (void)hipStreamDestroy(c->stream);

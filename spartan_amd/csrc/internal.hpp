@@ -58,7 +58,11 @@ struct sp_ctx {
   size_t pinned_cap;
   void* dstage;  // device staging for host inputs copied by DMA
   size_t dstage_cap;
-  hipEvent_t sync_ev;  // completion is polled (hipEventQuery spin): lower wake-up latency than a blocking stream sync
+  hipEvent_t sync_ev;
+  // completion of the main stream is signalled by a one-thread kernel that stores a sequence number into host memory,
+  // which the host polls: 6-9 us per round trip against 11-14 us for hipEventRecord + hipEventQuery (bench/flag_probe.hip)
+  volatile uint32_t* done_flag;
+  uint32_t done_seq;
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
 
   // size-class pool of device buffers: per-proof tables are recycled instead of hipMalloc/hipFree'd
