@@ -10,6 +10,7 @@ __global__ void k_flag(volatile uint32_t* flag, uint32_t seq, uint64_t* out) {
   if (threadIdx.x == 0) { __threadfence_system(); *flag = seq; }
 }
 __global__ void k_done(volatile uint32_t* flag, uint32_t seq) { __threadfence_system(); *flag = seq; }
+__global__ void k_done_nofence(volatile uint32_t* flag, uint32_t seq) { *flag = seq; }
 __global__ void k_plain(uint64_t* out, uint32_t seq) { out[threadIdx.x] = seq + threadIdx.x; }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
@@ -44,6 +45,15 @@ int main() {
       if (out[0] != (uint64_t)sq) { printf("bad3\n"); return 1; }
     }
     printf("flag kernel appended: %.2f us per round trip\n", (now() - t0) / N * 1e6);
+    t0 = now();
+    for (int i = 1; i <= N; i++) {
+      uint32_t sq = (uint32_t)(i + rep * N + 2000000);
+      hipLaunchKernelGGL(k_plain, dim3(1), dim3(64), 0, st, out, sq);
+      hipLaunchKernelGGL(k_done_nofence, dim3(1), dim3(1), 0, st, flag, sq);
+      while (*flag != sq) {}
+      if (out[0] != (uint64_t)sq || out[63] != (uint64_t)sq + 63) { printf("bad4\n"); return 1; }
+    }
+    printf("flag kernel appended, no fence: %.2f us per round trip\n", (now() - t0) / N * 1e6);
   }
   hipStreamSynchronize(st);
   return 0;

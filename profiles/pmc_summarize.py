@@ -5,7 +5,8 @@ requests at 64 B, i.e. reports half the bytes of a wide (16 B/lane) coalesced st
 16 B per lane (ulonglong2). WRITE_SIZE is uncalibrated on gfx950 (reported as is).
 usage: python profiles/pmc_summarize.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv"""
 import csv, json, sys, collections
-FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_reduce": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
+FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed",
+          "k_msm_reduce": "msm_reduce_compress", "k_pt_encode": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
           "k_cubic_bind_eval_batched": "sumcheck_bind_eval", "k_sc_bind_eval": "sumcheck_bind_eval", "k_sc_eval": "sumcheck_eval",
           "k_cubic_eval_batched": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand"}
 def load(path, counter):
