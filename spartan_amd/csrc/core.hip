@@ -373,8 +373,10 @@ const char* sp_strerror(int32_t s) {
 }
 const char* sp_version(void) { return "spartan_amd 0.1 (gfx950)"; }
 
+static int32_t ctx_init(sp_ctx* c, int device_id);
 int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   if (!out) return SP_EINVAL;
+  *out = nullptr;
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -385,7 +387,18 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   HIPCHK(hipSetDevice(device_id));
   sp_ctx* c = new (std::nothrow) sp_ctx();
   if (!c) return SP_ENOMEM;
+  int32_t rc = ctx_init(c, device_id);
+  if (rc != SP_OK) {  // release whatever was created before the failing step
+    sp_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return SP_OK;
+}
+static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->dev = device_id;
+  c->stream = c->stream_bg = nullptr;
+  c->sync_ev = nullptr;
   c->scratch = c->scratch2 = c->dstage = nullptr;
   c->scratch_cap = c->scratch2_cap = c->dstage_cap = 0;
   c->pinned = nullptr;
@@ -422,7 +435,6 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   *c->done_flag = 0;
   c->done_seq = 0;
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
-  *out = c;
   return SP_OK;
 }
 void sp_ctx_destroy(sp_ctx* c) {
@@ -438,9 +450,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
-  (void)hipEventDestroy(c->sync_ev);
-  (void)hipStreamDestroy(c->stream_bg);
-  (void)hipStreamDestroy(c->stream);
+  if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
+  if (c->stream_bg) (void)hipStreamDestroy(c->stream_bg);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 int32_t sp_prof_enable(sp_ctx* c, int on) {
