@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
 template <bool FINAL>
 __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__ Z, size_t z_row_stride, size_t cols,
                                                           const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
-                                                          const Fq* __restrict__ blinds, size_t h_idx, void* __restrict__ out) {
+                                                          size_t idx_row_stride, const Fq* __restrict__ blinds, size_t h_idx,
+                                                          void* __restrict__ out) {
   __shared__ Pt10 sm[256];
   size_t ncol = cols + (blinds ? 1 : 0), P = ncol * MSM_NWIN, row = blockIdx.y;
   int t = threadIdx.x;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
     size_t j = p % ncol;
     int w = (int)(p / ncol);
     Fq sc = j < cols ? ld_fq(Z + row * z_row_stride + j) : ld_fq(blinds + row);
-    size_t pt = j < cols ? (idx ? (size_t)idx[j] : g_off + j) : h_idx;
+    size_t pt = j < cols ? (idx ? (size_t)idx[row * idx_row_stride + j] : g_off + j) : h_idx;
     if (!fq_is_zero(sc)) {
       int d = msm_digit(fq_from_mont(sc), w);
       if (d != 0) {
@@ -622,7 +623,8 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
 }
 // core: Z on device (row stride in elements), optional idx (device), optional blinds (device); synchronous
 int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host) {
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride) {
+  if (idx_row_stride && (!didx || rows > SP_HOST_ENCODE_ROWS)) return SP_EINVAL;
   MsmPlan m = msm_plan(rows, cols, dblinds != nullptr);
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
@@ -634,10 +636,10 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
         ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));
         if (nblk == 1)
           hipLaunchKernelGGL((k_msm_windows_tree<true>), dim3(1, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols, (const Niels*)g->table,
-                             g_off, didx, dblinds, h_idx, (void*)hres(c));
+                             g_off, didx, idx_row_stride, dblinds, h_idx, (void*)hres(c));
         else
           hipLaunchKernelGGL((k_msm_windows_tree<false>), dim3((unsigned)nblk, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols,
-                             (const Niels*)g->table, g_off, didx, dblinds, h_idx, (void*)part);
+                             (const Niels*)g->table, g_off, didx, idx_row_stride, dblinds, h_idx, (void*)part);
       }
       if (nblk > 1) {
         ProfScope ps(c, PF_MSM_REDUCE, 160.0 * (double)(rows * nblk) + 128.0 * (double)rows);

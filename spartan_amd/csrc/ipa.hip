@@ -8,27 +8,31 @@ struct sp_ipa {
   const sp_gens* g;
   size_t n0, n_cur, g_off, q_idx, h_idx;
   Fq q_scale;
-  Fq *a, *b, *s, *s2, *rows;  // device: a[n0], b[n0], s[n0], s2[n0], rows[2][n0+2]
-  uint32_t* idx;              // device: n0+2 generator indices
+  Fq *a, *b, *s, *s2, *rows;  // device: a[n0], b[n0], s[n0], s2[n0], rows[2][n0+2] (round L/R use [2][n0/2+2] of it)
+  uint32_t* idx;              // device: n0+2 generator indices (all generators, Q, H)
+  uint32_t* idx_lr;           // device: [2][n0/2+2] per-row generator lists of the current round
   size_t bytes;
 };
 
-// rows[0] = scalars of L, rows[1] = scalars of R over (G[0..n0), Qbase, H). Blocks 0..nb-1 fill the generator
-// columns; the extra last block computes c_L, c_R (LDS reduce) and the two trailing columns.
+// L = <a_L, G_R> + c_L Q + blind_L H and R = <a_R, G_L> + c_R Q + blind_R H (bullet.rs:83-97) over the ORIGINAL generators:
+// generator j = p*n_cur + i belongs to L when i >= h (scalar a[i-h]*s[p]) and to R when i < h (scalar a[h+i]*s[p]), so
+// each row has m = n0/2 + 2 columns with its own generator list: rows[r][q], idx_lr[r][q], q = p*h + (i mod h), then Q, H.
+// Blocks 0..nb-1 fill the generator columns; the extra last block computes c_L, c_R (LDS reduce) and the trailing columns.
 __global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
-                                                     size_t n0, Fq q_scale, Fq blind_L, Fq blind_R, Fq* __restrict__ rows) {
+                                                     size_t n0, size_t g_off, uint32_t q_idx, uint32_t h_idx, Fq q_scale, Fq blind_L, Fq blind_R,
+                                                     Fq* __restrict__ rows, uint32_t* __restrict__ idx_lr) {
   __shared__ Fq sm[256];
-  size_t h = n_cur / 2, stride = n0 + 2;
+  size_t h = n_cur / 2, m = n0 / 2 + 2;
   if (blockIdx.x + 1 < gridDim.x) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n0) return;
     size_t p = j / n_cur, i = j % n_cur;
     Fq sp_ = ld_fq(s + p);
-    Fq l = fq_zero(), r = fq_zero();
-    if (i >= h) l = fq_mul(ld_fq(a + (i - h)), sp_);  // a_L[i-h] * G_R[i-h]
-    else r = fq_mul(ld_fq(a + h + i), sp_);           // a_R[i] * G_L[i]
-    st_fq(rows + j, l);
-    st_fq(rows + stride + j, r);
+    bool is_l = i >= h;
+    size_t q = p * h + (is_l ? i - h : i);
+    Fq v = fq_mul(ld_fq(a + (is_l ? i - h : h + i)), sp_);  // a_L[i-h] * G_R[i-h]  |  a_R[i] * G_L[i]
+    st_fq(rows + (is_l ? 0 : m) + q, v);
+    idx_lr[(is_l ? 0 : m) + q] = (uint32_t)(g_off + j);
     return;
   }
   Fq c[2] = {fq_zero(), fq_zero()};
@@ -38,10 +42,13 @@ __global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, c
   }
   block_sum_fq<2>(c, sm);
   if (threadIdx.x == 0) {
-    st_fq(rows + n0, fq_mul(c[0], q_scale));
-    st_fq(rows + n0 + 1, blind_L);
-    st_fq(rows + stride + n0, fq_mul(c[1], q_scale));
-    st_fq(rows + stride + n0 + 1, blind_R);
+    size_t t = n0 / 2;
+    st_fq(rows + t, fq_mul(c[0], q_scale));
+    st_fq(rows + t + 1, blind_L);
+    st_fq(rows + m + t, fq_mul(c[1], q_scale));
+    st_fq(rows + m + t + 1, blind_R);
+    idx_lr[t] = q_idx; idx_lr[t + 1] = h_idx;
+    idx_lr[m + t] = q_idx; idx_lr[m + t + 1] = h_idx;
   }
 }
 // bullet.rs:105-109 (a, b) and the coefficient update replacing the G fold
@@ -91,12 +98,13 @@ int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t
   ipa->q_scale = limbs(q_scale);
   size_t fq_count = 4 * n + 2 * (n + 2);
   uint8_t* base = nullptr;
-  ipa->bytes = 32 * fq_count + 4 * (n + 2);
+  ipa->bytes = 32 * fq_count + 4 * (n + 2) + 4 * (n + 4);
   ipa->a = nullptr;
   int32_t prc = pool_alloc(c, ipa->bytes, (void**)&base);
   if (prc != SP_OK) { delete ipa; return prc; }
   ipa->a = (Fq*)base; ipa->b = ipa->a + n; ipa->s = ipa->b + n; ipa->s2 = ipa->s + n; ipa->rows = ipa->s2 + n;
   ipa->idx = (uint32_t*)(ipa->rows + 2 * (n + 2));
+  ipa->idx_lr = ipa->idx + (n + 2);
   std::vector<uint32_t> idx(n + 2);
   for (size_t j = 0; j < n; j++) idx[j] = (uint32_t)(g_off + j);
   idx[n] = (uint32_t)q_idx;
@@ -120,10 +128,12 @@ int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t b
   {
     ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);
     hipLaunchKernelGGL(k_ipa_prepare, dim3((unsigned)((ipa->n0 + 255) / 256 + 1)), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
-                       ipa->n0, ipa->q_scale, limbs(blind_L), limbs(blind_R), ipa->rows);
+                       ipa->n0, ipa->g_off, (uint32_t)ipa->q_idx, (uint32_t)ipa->h_idx, ipa->q_scale, limbs(blind_L), limbs(blind_R), ipa->rows,
+                       ipa->idx_lr);
   }
   uint8_t lr[64];
-  SPCHK(msm_launch(c, ipa->g, ipa->rows, ipa->n0 + 2, 2, ipa->n0 + 2, 0, ipa->idx, nullptr, 0, lr));
+  size_t m = ipa->n0 / 2 + 2;
+  SPCHK(msm_launch(c, ipa->g, ipa->rows, m, 2, m, 0, ipa->idx_lr, nullptr, 0, lr, m));
   memcpy(L_out, lr, 32);
   memcpy(R_out, lr + 32, 32);
   return SP_OK;
