@@ -74,7 +74,9 @@ int32_t sp_commit_rows(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx
 int32_t sp_commit_rows_dev(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows,
                            size_t cols, const uint64_t* blinds, uint8_t* out);
 /* Background variant (no blinds): the commit is queued on a lower-priority HIP stream behind everything issued so far and
- * runs concurrently with later calls on the context; sp_job_wait blocks, copies the 32*rows bytes out and frees the job.
+ * runs concurrently with later calls on the context (persistent workgroups on half the CUs, so the latency-bound kernels
+ * of those calls keep idle CUs to run on); sp_job_wait blocks, copies the 32*rows bytes out and frees the job.
+ * Z and g must stay alive and Z[z_off, z_off + rows*cols) unmodified until sp_job_wait returns.
  * Used to overlap the row half of the SPARK `derefs` commitment (sparse_mlpoly.rs:1473-1478), which only depends on rx,
  * with the latency-bound second sum-check of R1CSProof::prove. */
 typedef struct sp_job sp_job;

@@ -538,6 +538,7 @@ void sp_gens_free(sp_gens* g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->dev);
   (void)hipStreamSynchronize(g->ctx->stream);
+  (void)hipStreamSynchronize(g->ctx->stream_bg);  // a background commit may still be reading the tables
   (void)hipFree(g->table);
   delete g;
 }

@@ -15,7 +15,8 @@ namespace spz {
 using namespace sp;
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-// optional per-entry-point wall-clock accounting (SPARTAN_CALLSTATS=1): where the latency of a proof accumulates
+// optional per-entry-point wall-clock accounting (SPARTAN_CALLSTATS=1): where the latency of a proof accumulates.
+// Diagnostic only: the table is process-wide and unsynchronised, so use it with one proving thread.
 struct CallStats {
   struct E { double t = 0; size_t n = 0; };
   std::map<std::string, E> m;
