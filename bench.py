@@ -34,7 +34,8 @@ def dist_setup(n_gpus):
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo for the CPU tests
     if backend == "nccl":
         import torch
-        torch.cuda.set_device(int(os.environ.get("BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", str(rank)))))
+        dev = int(os.environ.get("BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", str(rank))))
+        torch.cuda.set_device(dev % max(1, torch.cuda.device_count()))
     dist.init_process_group(backend=backend)
     return rank, world, dist
 
@@ -161,6 +162,12 @@ def main():
 
     rank, world, dist = dist_setup(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    try:  # a launcher may expose one device per rank (HIP_VISIBLE_DEVICES): fold the rank onto what is visible
+        import torch as _t
+        if _t.cuda.is_available():
+            local_rank %= max(1, _t.cuda.device_count())
+    except ImportError:
+        pass
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (with BENCH_DIST_BACKEND=gloo)
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     import torch
@@ -278,6 +285,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2_cons)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # the reference's `multicore` feature parallelises the rows of a commitment (dense_mlpoly.rs:148-162); same sample
+            nthr = min(os.cpu_count() or 1, 32)
+            if nthr > 1:
+                out["cpu_baseline_multicore"] = cpu_baseline(args.cpu_log2_cons, threads=nthr)
         if args.phases:
             print("phases (s):", json.dumps({k_: round(v, 5) for k_, v in phase.items()}), file=sys.stderr)
         print(json.dumps(out))
