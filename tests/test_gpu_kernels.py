@@ -56,6 +56,31 @@ def test_commit_rows_matches_oracle(ctx, orc, gens40, rows, cols, kind, blind):
     assert got == bytes(want)
 
 
+@pytest.fixture(scope="module")
+def gens301(ctx, orc):
+    from spartan_amd import capi
+    g = capi.Gens(ctx, compressed=gens_bytes(orc, 300))  # 301 points: G[0..300), h = P[300]
+    yield g
+    g.free()
+
+
+# every launch plan of msm_launch (core.hip): lookups+tree in one launch / + second reduce (rows <= 8, host encode);
+# windowed one-pass and two-pass trees with per-block and one-lane-per-row encodes; row-strip kernel with and without the
+# XCD-aware tile order
+@pytest.mark.parametrize("rows,cols,blind", [(1, 300, True), (8, 300, False), (16, 128, True), (100, 128, False), (256, 128, True),
+                                             (70, 300, True), (512, 64, False)])
+def test_commit_rows_launch_plans_match_oracle(ctx, orc, gens301, rows, cols, blind):
+    rng = random.Random(rows * 7919 + cols)
+    Z = rand_scalars(rng, rows * cols, "uniform")
+    bl = rand_scalars(rng, rows, "uniform") if blind else None
+    g = gens301.compressed
+    got = gens301.commit_rows(mont_array(Z), rows, cols, mont_array(bl) if blind else None, g_off=0, h_idx=300)
+    want = (ctypes.c_uint8 * (32 * rows))()
+    rc = orc.orc_commit_rows(g[:32 * cols], sz(cols), g[32 * 300:32 * 301], mont_array(Z), sz(rows), sz(cols), mont_array(bl) if blind else None, want)
+    assert rc == 0
+    assert got == bytes(want)
+
+
 def test_commit_rows_dev_and_offset(ctx, orc, gens40):
     from spartan_amd import capi
     rng = random.Random(5)

@@ -27,7 +27,7 @@ def oracle_bytes(orc, p):
     return bytes(b)
 
 
-@pytest.mark.parametrize("s,seed", [(1, 0), (2, 1), (4, 2), (7, 3), (10, 4)])
+@pytest.mark.parametrize("s,seed", [(1, 0), (2, 1), (4, 2), (7, 3), (10, 4), (13, 5)])
 def test_nizk_prove_bytes_match_oracle(P, ctx, orc, s, seed):
     N = 1 << s
     ni = 10 if N > 16 else 1
@@ -48,7 +48,7 @@ def test_nizk_prove_bytes_match_oracle(P, ctx, orc, s, seed):
     gens.free(); inst.free()
 
 
-@pytest.mark.parametrize("s,seed", [(1, 0), (3, 1), (5, 2), (8, 3), (11, 4)])
+@pytest.mark.parametrize("s,seed", [(1, 0), (3, 1), (5, 2), (8, 3), (11, 4), (14, 5)])
 def test_snark_encode_and_prove_bytes_match_oracle(P, ctx, orc, s, seed):
     N = 1 << s
     ni = 10 if N > 16 else 1
