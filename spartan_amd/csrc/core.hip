@@ -1,5 +1,7 @@
 // spartan_amd: context, generators (window tables), fixed-base MSM, device tables.
 #include "internal.hpp"
+#include <list>
+#include <mutex>
 
 const char* kProfNames[PF_COUNT] = {"gens_table_build", "msm_rows_fixed", "msm_windows_fixed", "msm_reduce_pass", "msm_reduce_compress", "eq_expand", "sumcheck_eval",
                                     "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "misc"};
@@ -491,41 +493,71 @@ int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* 
 }
 
 
+// Window tables are public parameters (MultiCommitGens is immutable, commitments.rs:8-13) and large (4.1 MiB per point):
+// they are built once per (device, generator bytes) and shared by every context of the process — concurrent proving
+// contexts on one GPU hold one copy, and re-creating a SNARKGens is free. Reference-counted; freed with the last handle.
+struct GensCacheEntry {
+  int dev, mode;
+  size_t n, refs;
+  std::vector<uint8_t> in, comp;
+  Niels* table;
+};
+static std::mutex g_gens_mu;
+static std::list<GensCacheEntry> g_gens_cache;
+
 static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint8_t* comp_out, sp_gens** out) {
   if (!c || !in || !out || n == 0) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   size_t in_bytes = (mode == 0 ? 32 : 64) * n;
-  // scratch layout: [in bytes][pad][Pt n][comp 32n][bad int]
-  size_t off_pts = (in_bytes + 255) & ~(size_t)255;
-  size_t off_comp = off_pts + n * sizeof(Pt);
-  size_t off_bad = off_comp + ((32 * n + 255) & ~(size_t)255);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  SPCHK(ensure(&c->scratch, &c->scratch_cap, off_bad + 256));
-  uint8_t* base = (uint8_t*)c->scratch;
-  HIPCHK(hipMemcpyAsync(base, in, in_bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemsetAsync(base + off_bad, 0, 4, c->stream));
-  Niels* table = nullptr;
-  HIPCHK(hipMalloc((void**)&table, n * MSM_PT_ENTRIES * sizeof(Niels)));
-  {
-    ProfScope ps(c, PF_GENS_TABLE, (double)n * MSM_PT_ENTRIES * sizeof(Niels));
-    hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
-                       (mode == 1 && comp_out) ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
-    size_t nt = n * MSM_NWIN * TB_NCHUNK;
-    hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table);
-  }
-  int bad = 0;
-  int32_t rc = fetch_out(c, base + off_bad, &bad, 4);
-  if (rc == SP_OK && mode == 1 && comp_out) rc = fetch_out(c, base + off_comp, comp_out, 32 * n);
-  if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = SP_EHIP;
-  if (rc != SP_OK || bad) {
-    (void)hipFree(table);
-    return rc != SP_OK ? rc : SP_EPOINT;
+  std::lock_guard<std::mutex> lk(g_gens_mu);  // also serialises concurrent builds of the same table
+  GensCacheEntry* hit = nullptr;
+  for (auto& e : g_gens_cache)
+    if (e.dev == c->dev && e.mode == mode && e.n == n && memcmp(e.in.data(), in, in_bytes) == 0) { hit = &e; break; }
+  if (!hit) {
+    // scratch layout: [in bytes][pad][Pt n][comp 32n][bad int]
+    size_t off_pts = (in_bytes + 255) & ~(size_t)255;
+    size_t off_comp = off_pts + n * sizeof(Pt);
+    size_t off_bad = off_comp + ((32 * n + 255) & ~(size_t)255);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    SPCHK(ensure(&c->scratch, &c->scratch_cap, off_bad + 256));
+    uint8_t* base = (uint8_t*)c->scratch;
+    HIPCHK(hipMemcpyAsync(base, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(base + off_bad, 0, 4, c->stream));
+    Niels* table = nullptr;
+    HIPCHK(hipMalloc((void**)&table, n * MSM_PT_ENTRIES * sizeof(Niels)));
+    {
+      ProfScope ps(c, PF_GENS_TABLE, (double)n * MSM_PT_ENTRIES * sizeof(Niels));
+      hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
+                         mode == 1 ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
+      size_t nt = n * MSM_NWIN * TB_NCHUNK;
+      hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table);
+    }
+    int bad = 0;
+    std::vector<uint8_t> comp(mode == 1 ? 32 * n : 0);
+    int32_t rc = fetch_out(c, base + off_bad, &bad, 4);
+    if (rc == SP_OK && mode == 1) rc = fetch_out(c, base + off_comp, comp.data(), 32 * n);
+    if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = SP_EHIP;
+    if (rc != SP_OK || bad) {
+      (void)hipFree(table);
+      return rc != SP_OK ? rc : SP_EPOINT;
+    }
+    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table});
+    hit = &g_gens_cache.back();
   }
   sp_gens* g = new (std::nothrow) sp_gens();
-  if (!g) { (void)hipFree(table); return SP_ENOMEM; }
+  if (!g) {
+    if (hit->refs == 0) {  // just built for this call
+      (void)hipFree(hit->table);
+      g_gens_cache.pop_back();
+    }
+    return SP_ENOMEM;
+  }
+  hit->refs++;
+  if (mode == 1 && comp_out) memcpy(comp_out, hit->comp.data(), 32 * n);
   g->ctx = c;
   g->n = n;
-  g->table = table;
+  g->table = hit->table;
+  g->cache_entry = hit;
   *out = g;
   return SP_OK;
 }
@@ -539,7 +571,15 @@ void sp_gens_free(sp_gens* g) {
   (void)hipSetDevice(g->ctx->dev);
   (void)hipStreamSynchronize(g->ctx->stream);
   (void)hipStreamSynchronize(g->ctx->stream_bg);  // a background commit may still be reading the tables
-  (void)hipFree(g->table);
+  {
+    std::lock_guard<std::mutex> lk(g_gens_mu);
+    GensCacheEntry* e = (GensCacheEntry*)g->cache_entry;
+    if (--e->refs == 0) {
+      (void)hipFree(e->table);
+      for (auto it = g_gens_cache.begin(); it != g_gens_cache.end(); ++it)
+        if (&*it == e) { g_gens_cache.erase(it); break; }
+    }
+  }
   delete g;
 }
 

@@ -80,7 +80,8 @@ struct sp_ctx {
 struct sp_gens {
   sp_ctx* ctx;
   size_t n;
-  Niels* table;  // [n][32][128]
+  Niels* table;  // [n][MSM_NWIN][MSM_TENT]; owned by the process-wide table cache (core.hip), shared between contexts
+  void* cache_entry;
 };
 struct sp_table {
   sp_ctx* ctx;

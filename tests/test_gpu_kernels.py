@@ -34,6 +34,31 @@ def test_gens_from_uniform_matches_oracle(ctx, orc):
     g.free()
 
 
+def test_generator_tables_are_shared_between_contexts(orc):
+    """window tables are built once per (device, generator bytes) and reference-counted across contexts (core.hip gens_build)"""
+    import hashlib, time
+    from spartan_amd import capi
+    from tests.test_oracle_pins import BASEPOINT
+    n = 129
+    stream = hashlib.shake_256(b"gens_cache_test" + bytes.fromhex(BASEPOINT)).digest(64 * n)
+    a, b = capi.Ctx(0), capi.Ctx(0)
+    t0 = time.perf_counter(); ga = capi.Gens(a, uniform=stream); t_build = time.perf_counter() - t0
+    t0 = time.perf_counter(); gb = capi.Gens(b, uniform=stream); t_hit = time.perf_counter() - t0
+    assert ga.compressed == gb.compressed == gens_bytes(orc, n - 1, b"gens_cache_test")
+    assert t_hit < 0.5 * t_build, (t_build, t_hit)
+    rng = random.Random(77)
+    Z = rand_scalars(rng, 4 * 128)
+    want = (ctypes.c_uint8 * 128)()
+    g = ga.compressed
+    assert orc.orc_commit_rows(g[:32 * 128], sz(128), g[32 * 128:], mont_array(Z), sz(4), sz(128), None, want) == 0
+    ga.free()                                   # the table must survive its first owner
+    assert gb.commit_rows(mont_array(Z), 4, 128, None, g_off=0, h_idx=128) == bytes(want)
+    gb.free(); a.close()
+    gc = capi.Gens(b, uniform=stream)           # last handle gone: rebuilt from scratch, same bytes
+    assert gc.commit_rows(mont_array(Z), 4, 128, None, g_off=0, h_idx=128) == bytes(want)
+    gc.free(); b.close()
+
+
 def test_gens_upload_rejects_bad_point(ctx, orc):
     from spartan_amd import capi
     good = gens_bytes(orc, 3)
