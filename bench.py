@@ -142,8 +142,7 @@ def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
     for _ in range(2):
         e = P.SNARK.encode(ctx, inst, gens); e.free()
     dt = (time.perf_counter() - t0) / 2
-    # comb_ops: 16 * nnz scalars (row, col, val, 3 read timestamps per matrix padded), comb_mem: 4 * max(cons, vars+..) scalars
-    out["snark_encode"] = {"ms": dt * 1e3, "note": "SNARK::encode incl. AddrTimestamps::new on the host, upload, two multi_commits"}
+    out["snark_encode"] = {"ms": dt * 1e3, "note": "SNARK::encode: address lists laid out on the host, AddrTimestamps::new + two multi_commits on the device"}
     return out
 
 

@@ -159,6 +159,12 @@ void sp_ipa_free(sp_ipa* ipa);
 typedef struct sp_index sp_index; /* device-resident Vec<usize> (AddrTimestamps::ops_addr_usize, sparse_mlpoly.rs:213-219) */
 int32_t sp_index_upload(sp_ctx* ctx, const uint64_t* idx, size_t n, sp_index** out);
 void sp_index_free(sp_index* ix);
+/* AddrTimestamps::new (sparse_mlpoly.rs:221-254) for `nlists` address lists of equal length walked one after the other
+ * over ONE array of `cells` counters: read_ts of list k goes to ts_dst[ts_off[k] ..] and the final counters (audit_ts)
+ * to audit_dst[audit_off .. audit_off + cells), both as F_q tables. Addresses must be < cells. The sequential scan of
+ * the reference is computed as a stable sort by address plus rank-in-run. */
+int32_t sp_addr_timestamps(sp_ctx* ctx, sp_index* const* addr, size_t nlists, size_t cells, sp_table* ts_dst, const size_t* ts_off,
+                           sp_table* audit_dst, size_t audit_off);
 /* DensePolynomial::from_usize (dense_mlpoly.rs:274-280) written into dst[dst_off ..]. */
 int32_t sp_table_from_index(sp_ctx* ctx, const sp_index* ix, sp_table* dst, size_t dst_off);
 /* Non-owning view of elements [off, off+len) of a table (DensePolynomial::split, dense_mlpoly.rs:140-146). The

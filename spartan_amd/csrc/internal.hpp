@@ -83,6 +83,11 @@ struct sp_gens {
   Niels* table;  // [n][MSM_NWIN][MSM_TENT]; owned by the process-wide table cache (core.hip), shared between contexts
   void* cache_entry;
 };
+struct sp_index {  // a usize vector kept as u32 on the device (addresses of the SPARK memory checks)
+  sp_ctx* ctx;
+  uint32_t* d;
+  size_t n;
+};
 struct sp_table {
   sp_ctx* ctx;
   Fq* d;           // current contents

@@ -3,12 +3,6 @@
 // All of it is F_q streaming work (no group operations), HBM/ALU-bound.
 #include "internal.hpp"
 
-struct sp_index {
-  sp_ctx* ctx;
-  uint32_t* d;
-  size_t n;
-};
-
 __global__ void __launch_bounds__(256) k_from_index(const uint32_t* __restrict__ ix, size_t n, Fq* __restrict__ dst) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(dst + i, fq_from_u64(ix[i]));
 }

@@ -210,6 +210,45 @@ def test_vecmat_dot_evaluate_match_oracle(ctx, orc, v):
     t.free(); tb.free()
 
 
+@pytest.mark.parametrize("per,cells,nlists,dist", [(8, 4, 3, "uniform"), (256, 16, 3, "uniform"), (1000, 1 << 10, 2, "uniform"), (4096, 8192, 3, "uniform"),
+                                                   (4096, 64, 3, "one"), (1 << 16, 1 << 17, 3, "sorted")])
+def test_addr_timestamps_match_reference_scan(ctx, per, cells, nlists, dist):
+    """sp_addr_timestamps against the loop of AddrTimestamps::new (sparse_mlpoly.rs:221-254) restated in Python, with many
+    operations per cell (the synthetic R1CS has almost none), a single hot cell, and the increasing addresses of a real instance"""
+    from spartan_amd import capi
+    rng = random.Random(per * 31 + cells)
+    if dist == "uniform":
+        lists = [[rng.randrange(cells) for _ in range(per)] for _ in range(nlists)]
+    elif dist == "one":
+        lists = [[7 if rng.random() < 0.9 else rng.randrange(cells) for _ in range(per)] for _ in range(nlists)]
+    else:
+        lists = [[(i + k) % cells for i in range(per)] for k in range(nlists)]
+    audit = [0] * cells
+    want_ts = []
+    for ops in lists:            # one counter array across all lists, lists walked in order
+        ts = []
+        for a in ops:
+            ts.append(audit[a]); audit[a] += 1
+        want_ts.append(ts)
+    ix = []
+    for ops in lists:
+        h = vp()
+        assert capi.lib.sp_index_upload(ctx.h, (ctypes.c_uint64 * per)(*ops), sz(per), ctypes.byref(h)) == 0
+        ix.append(h)
+    dst = capi.Table.alloc(ctx, nlists * per + 5)
+    aud = capi.Table.alloc(ctx, cells + 3)
+    offs = (sz * nlists)(*[k * per + 5 for k in range(nlists)])
+    rc = capi.lib.sp_addr_timestamps(ctx.h, (vp * nlists)(*ix), sz(nlists), sz(cells), dst.h, offs, aud.h, sz(3))
+    assert rc == 0
+    got = from_mont_array(dst.download(), nlists * per + 5)
+    for k in range(nlists):
+        assert got[5 + k * per:5 + (k + 1) * per] == want_ts[k]
+    assert from_mont_array(aud.download(), cells + 3)[3:] == audit
+    for h in ix:
+        capi.lib.sp_index_free(h)
+    dst.free(); aud.free()
+
+
 def test_polynomial_evaluation_known_answer_on_device(ctx):
     """dense_mlpoly.rs:433-452 check_polynomial_evaluation: Z = [1,2,1,4], r = [4,3] -> 28, via sp_evaluate and via the
     L/R factorisation (sp_vecmat + host dot) the PolyEvalProof uses"""
