@@ -408,6 +408,7 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->pinned_cap = 0;
   c->hmap = nullptr;
   c->done_flag = nullptr;
+  c->device_encode = getenv("SPARTAN_DEVICE_ENCODE") != nullptr;  // diagnostic: keep every RFC 9496 encode on the GPU
   c->prof_on = 0;
   c->prof_mask = ~0ULL;
   c->pool_bytes = 0;
@@ -670,6 +671,8 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
   if (rows <= SP_HOST_ENCODE_ROWS) {  // latency path: the device sums, the host core runs the encode chain
+    // (SPARTAN_DEVICE_ENCODE: the sums stay in device memory and k_pt_encode runs the chain there — same bytes, ~100 us later)
+    uint8_t* sums_dst = c->device_encode ? (uint8_t*)c->scratch + m.part_bytes + m.part2_bytes + out_al : hres(c);
     if (m.windowed) {
       size_t nblk = (m.P + 255) / 256;
       Pt10* part = (Pt10*)c->scratch;  // nblk * rows * 160 B <= part_bytes
@@ -677,17 +680,26 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
         ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));
         if (nblk == 1)
           hipLaunchKernelGGL((k_msm_windows_tree<true>), dim3(1, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols, (const Niels*)g->table,
-                             g_off, didx, idx_row_stride, dblinds, h_idx, (void*)hres(c));
+                             g_off, didx, idx_row_stride, dblinds, h_idx, (void*)sums_dst);
         else
           hipLaunchKernelGGL((k_msm_windows_tree<false>), dim3((unsigned)nblk, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols,
                              (const Niels*)g->table, g_off, didx, idx_row_stride, dblinds, h_idx, (void*)part);
       }
       if (nblk > 1) {
         ProfScope ps(c, PF_MSM_REDUCE, 160.0 * (double)(rows * nblk) + 128.0 * (double)rows);
-        hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)part, nblk, hres(c));
+        hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)part, nblk, sums_dst);
       }
     } else {
-      msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, hres(c), false);
+      if (idx_row_stride) return SP_EINVAL;  // per-row index lists exist on the lookup+tree path only
+      msm_enqueue(c, c->stream, true, m, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, (uint8_t*)c->scratch, sums_dst, false);
+    }
+    if (c->device_encode) {
+      {
+        ProfScope ps(c, PF_MSM_REDUCE, 160.0 * (double)rows);
+        hipLaunchKernelGGL(k_pt_encode, dim3(1), dim3(64), 0, c->stream, (const Pt*)sums_dst, rows, hres(c));
+      }
+      SPCHK(fetch_small(c, out_host, 32 * rows));
+      return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
     }
     Pt sums[SP_HOST_ENCODE_ROWS];
     SPCHK(fetch_small(c, sums, sizeof(Pt) * rows));

@@ -47,6 +47,7 @@ struct sp_ctx {
   int dev;
   hipStream_t stream;
   hipStream_t stream_bg;  // lower-priority background stream: throughput MSMs overlapped with latency-bound rounds
+  bool device_encode;     // SPARTAN_DEVICE_ENCODE: small commitments are encoded by the device too (100 us instead of 3 us each)
   int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
   size_t bg_lds;          // dynamic LDS each of them claims (a whole CU's)
   // scratch

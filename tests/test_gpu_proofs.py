@@ -319,3 +319,28 @@ def test_tiny_r1cs_of_the_reference(P, ctx, orc):
     assert orc.orc_nizk_verify(onp, oi, ong, b"tiny", sz(4), b"nizk_example") == 1
     assert got == oracle_bytes(orc, onp)
     ngens.free(); enc.free(); gens.free(); inst.free()
+
+
+def test_host_and_device_point_encoding_give_the_same_proof(P, orc, monkeypatch):
+    """Commitments of up to 8 rows are summed on the GPU and encoded (RFC 9496 §4.3.2) by the calling host core, because one
+    serial inverse-square-root chain takes ~3 us there and ~100 us on a lone wavefront. SPARTAN_DEVICE_ENCODE
+    keeps that chain on the GPU: both contexts must produce the oracle's bytes."""
+    s, seed = 9, 21
+    N = 1 << s
+    proofs = []
+    for device_encode in (False, True):
+        if device_encode:
+            monkeypatch.setenv("SPARTAN_DEVICE_ENCODE", "1")
+        else:
+            monkeypatch.delenv("SPARTAN_DEVICE_ENCODE", raising=False)
+        c = P.Ctx(0)   # the knob is read when the context is created
+        inst = P.Instance.produce_synthetic_r1cs(c, N, N, 10, seed=seed)
+        gens = P.SNARKGens(c, N, N, 10, N)
+        enc = P.SNARK.encode(c, inst, gens)
+        proofs.append(P.SNARK.prove(c, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", P.seed_scalar(b"tape", seed)))
+        enc.free(); gens.free(); inst.free(); c.close()
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", P.seed_scalar(b"tape", seed), None))
+    assert proofs[0] == proofs[1] == oracle_bytes(orc, op)
