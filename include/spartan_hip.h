@@ -109,6 +109,12 @@ int32_t sp_sumcheck_eval(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t nt
 int32_t sp_table_bind_top(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, const uint64_t r[4]);
 /* Fused: bind all tables at r, then evaluate the next round on the bound tables in the same pass. */
 int32_t sp_sumcheck_bind_eval(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals);
+/* One round body of the zero-knowledge sum-checks (sumcheck.rs:471-583 / 661-772): sp_sumcheck_bind_eval at r and, at the
+ * same time on a second stream, the `rows` <= 8 small commitments of the round whose scalars are known as soon as r is
+ * (comm_eval and the DotProductProof's delta): out_points[k] = compress( sum_j S[k*cols+j] * P[idx[j]] ), cols <= 11.
+ * One completion wait instead of two, and the two kernels overlap. */
+int32_t sp_sumcheck_bind_eval_commit(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals,
+                                     const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out_points);
 /* DensePolynomial::bound (dense_mlpoly.rs:206-213): out[i] = sum_j L[j]*Z[j*R+i], Z viewed as Lsz x (len/Lsz). */
 int32_t sp_vecmat(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z, uint64_t* out);
 /* compute_dotproduct / inner_product (nizk/mod.rs:435-438, bullet.rs:233-243) over n elements. */

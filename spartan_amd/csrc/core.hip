@@ -400,8 +400,8 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
 }
 static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->dev = device_id;
-  c->stream = c->stream_bg = nullptr;
-  c->sync_ev = nullptr;
+  c->stream = c->stream_bg = c->stream_side = nullptr;
+  c->sync_ev = c->side_ev = nullptr;
   c->scratch = c->scratch2 = c->dstage = nullptr;
   c->scratch_cap = c->scratch2_cap = c->dstage_cap = 0;
   c->pinned = nullptr;
@@ -422,6 +422,8 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream_side, hipStreamNonBlocking, hi));
+    HIPCHK(hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithPriority(&c->stream_bg, hipStreamNonBlocking, lo));
     // background MSMs: one 1024-thread workgroup per CU on half of the CUs (k_msm_rows_bg). Measured at 2^20 with the
     // derefs row half in the background, share in eighths 2 / 3 / 4 / 5 / 6 / 8 -> 63.1 / 59.2 / 58.0 / 59.0 / 61.5 / 62.5 ms
@@ -455,6 +457,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
+  if (c->side_ev) (void)hipEventDestroy(c->side_ev);
+  if (c->stream_side) (void)hipStreamDestroy(c->stream_side);
   if (c->stream_bg) (void)hipStreamDestroy(c->stream_bg);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -803,6 +807,20 @@ int32_t sp_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, 
     dbl = (const Fq*)((uint8_t*)c->scratch2 + zb);
   }
   return msm_launch(c, g, (const Fq*)c->scratch2, cols, rows, cols, g_off, nullptr, dbl, h_idx, out);
+}
+int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows,
+                          uint8_t* sums_out) {
+  if (!c || !g || !idx || !S || !sums_out || rows == 0 || rows > SP_HOST_ENCODE_ROWS || cols == 0 || cols * MSM_NWIN > 256) return SP_EINVAL;
+  for (size_t j = 0; j < cols; j++)
+    if (idx[j] >= g->n) return SP_EINVAL;
+  size_t sb = 32 * rows * cols, ib = (4 * cols + 31) & ~(size_t)31;
+  if (sb + ib > HMAP_IN) return SP_EINVAL;
+  const Fq* ds = (const Fq*)stage_small(c, 0, S, sb);
+  const uint32_t* di = (const uint32_t*)stage_small(c, sb, idx, 4 * cols);
+  ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 128.0 * (double)rows, st);
+  hipLaunchKernelGGL((k_msm_windows_tree<true>), dim3(1, (unsigned)rows), dim3(256), 0, st, ds, cols, cols, (const Niels*)g->table, (size_t)0, di, (size_t)0,
+                     (const Fq*)nullptr, (size_t)0, (void*)sums_out);
+  return SP_OK;
 }
 int32_t sp_msm_indexed(sp_ctx* c, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out) {
   if (!c || !g || !idx || !S || !out || rows == 0 || cols == 0) return SP_EINVAL;

@@ -296,6 +296,49 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   if (kind != 0) memcpy(out_evals + 8, e + 8, 32);
   return SP_OK;
 }
+int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals,
+                                     const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out_points) {
+  if (kind < 0 || kind > 2 || !out_evals || !r || !out_points) return SP_EINVAL;
+  Tabs4 T;
+  size_t len;
+  SPCHK(tabs_check(c, tabs, ntabs, kind == 0 ? 2 : (kind == 1 ? 3 : 4), &T, &len));
+  if (len < 4) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  if (c->device_encode) {  // diagnostic mode (every encode on the GPU): the two halves one after the other
+    SPCHK(sp_sumcheck_bind_eval(c, kind, tabs, ntabs, r, out_evals));
+    return sp_msm_indexed(c, g, idx, cols, S, rows, out_points);
+  }
+  // the commitments do not depend on the tables: they run on the side stream while the main stream binds and evaluates
+  constexpr size_t SUMS_OFF = 1024;  // evaluations at hres[0, 96), row sums behind them
+  SPCHK(msm_small_enqueue(c, c->stream_side, g, idx, cols, S, rows, hres(c) + SUMS_OFF));
+  HIPCHK(hipEventRecord(c->side_ev, c->stream_side));
+  Fq rr;
+  memcpy(rr.l, r, 32);
+  size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
+  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
+    if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (kind == 2) hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+  }
+  for (size_t k = 0; k < ntabs; k++) tabs[k]->len = len / 2;
+  if (partials != (Fq*)hres(c)) {
+    ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * 3));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c));
+  }
+  HIPCHK(hipStreamWaitEvent(c->stream, c->side_ev, 0));  // one completion for both streams
+  SPCHK(sync_spin(c));
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  memcpy(out_evals, hres(c), 32);
+  memcpy(out_evals + 4, hres(c) + 32, 32);
+  if (kind != 0) memcpy(out_evals + 8, hres(c) + 64, 32);
+  Pt sums[8];
+  memcpy(sums, hres(c) + SUMS_OFF, sizeof(Pt) * rows);
+  for (size_t k = 0; k < rows; k++) pt_compress(sums[k], out_points + 32 * k);
+  return SP_OK;
+}
 int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, uint64_t* out) {
   if (!c || !L || !Z || !out || Lsz == 0 || Z->len % Lsz) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));

@@ -46,6 +46,8 @@ struct ProfRec {
 struct sp_ctx {
   int dev;
   hipStream_t stream;
+  hipStream_t stream_side;  // same priority as `stream`: small commitments that run NEXT TO a sum-check kernel of the same round
+  hipEvent_t side_ev;
   hipStream_t stream_bg;  // lower-priority background stream: throughput MSMs overlapped with latency-bound rounds
   bool device_encode;     // SPARTAN_DEVICE_ENCODE: small commitments are encoded by the device too (100 us instead of 3 us each)
   int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
@@ -158,6 +160,11 @@ void prof_drain(sp_ctx* c);
 int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes);   // host -> c->dstage (+off), async
 int32_t ensure_dstage(sp_ctx* c, size_t need);
 int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes);  // device -> host, synchronous
+// Enqueue (no wait) the lookups + tree of a commitment with <= 256 (column, window) pairs per row and rows <= 8 on `st`:
+// scalars S[rows][cols] and generator indices are staged in the host-mapped input page, the row sums (extended points)
+// land at sums_out (device-visible). core.hip.
+extern "C" int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows,
+                                     uint8_t* sums_out);
 // host-mapped page layout: [0, HMAP_IN) kernel inputs, [HMAP_IN, HMAP_SIZE) kernel results
 constexpr size_t HMAP_IN = 32768, HMAP_SIZE = 65536;
 void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes);  // returns the device-visible address; bytes+off <= HMAP_IN

@@ -521,18 +521,25 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     Fq r_j = t.challenge_scalar("challenge_nextround");
     // bind every table at r_j (sumcheck.rs:485-486 / 673-676); fused with the next round's evaluation
     bool more = j + 1 < num_rounds;
-    if (sp_table_len(tabs[0]) >= 4) SPX(sp_sumcheck_bind_eval(c, kind, tabs.data(), tabs.size(), U(r_j), ev));
-    else SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
     // ---- round tail (sumcheck.rs:491-583 / 681-772)
     Fq eval = poly.evaluate(r_j);
     FqVec d = tape.random_vector("d_vec", nn);  // DotProductProof randomness (nizk/mod.rs:330-332)
     Fq r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_beta");
-    // launch 1: comm_eval = eval*G1 + blinds_evals[j]*h ; delta = <d, Gn> + r_delta*hn
+    // launch 1: comm_eval = eval*G1 + blinds_evals[j]*h ; delta = <d, Gn> + r_delta*hn. Its scalars are known as soon as
+    // r_j is, like the bind: both go out together (sp_sumcheck_bind_eval_commit), one completion wait for the pair
     FqVec rows1(2 * W, fq_zero());
     rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
     for (size_t k = 0; k < nn; k++) rows1[W + k] = d[k];
     rows1[W + nn] = r_delta;
-    std::vector<CP> cm1 = msm_rows(c, gn.g, idx_u, rows1, 2);
+    std::vector<CP> cm1;
+    if (sp_table_len(tabs[0]) >= 4) {
+      uint8_t pts[64];
+      SPX(sp_sumcheck_bind_eval_commit(c, kind, tabs.data(), tabs.size(), U(r_j), ev, gn.g, idx_u.data(), W, U(rows1), 2, pts));
+      cm1 = {to_cp(pts), to_cp(pts + 32)};
+    } else {
+      SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
+      cm1 = msm_rows(c, gn.g, idx_u, rows1, 2);
+    }
     CP comm_eval = cm1[0], delta = cm1[1];
     t.append_point("comm_claim_per_round", comm_claim_per_round.data());
     t.append_point("comm_eval", comm_eval.data());
