@@ -88,10 +88,14 @@ int32_t sync_spin(sp_ctx* c) {
   uint32_t seq = ++c->done_seq;
   hipLaunchKernelGGL(k_done, dim3(1), dim3(1), 0, c->stream, c->done_flag, seq);
   for (uint64_t spins = 1;; spins++) {
-    if (*c->done_flag == seq) return SP_OK;
+    if (*c->done_flag == seq) { c->sync_epoch++; return SP_OK; }
     if ((spins & 0xFFFFF) == 0) {  // every ~ms: a faulted queue never delivers the flag
       hipError_t e = hipStreamQuery(c->stream);
-      if (e == hipSuccess) return *c->done_flag == seq ? SP_OK : SP_EHIP;
+      if (e == hipSuccess) {
+        if (*c->done_flag != seq) return SP_EHIP;
+        c->sync_epoch++;
+        return SP_OK;
+      }
       if (e != hipErrorNotReady) {
         fprintf(stderr, "spartan_hip: stream failed: %s\n", hipGetErrorString(e));
         return SP_EHIP;
@@ -408,6 +412,9 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->pinned_cap = 0;
   c->hmap = nullptr;
   c->done_flag = nullptr;
+  c->sync_epoch = 0;
+  c->eq_next = 0;
+  for (int k = 0; k < 8; k++) c->eq_slot_epoch[k] = 0;
   c->device_encode = getenv("SPARTAN_DEVICE_ENCODE") != nullptr;  // diagnostic: keep every RFC 9496 encode on the GPU
   c->prof_on = 0;
   c->prof_mask = ~0ULL;
@@ -814,7 +821,7 @@ int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const uin
   for (size_t j = 0; j < cols; j++)
     if (idx[j] >= g->n) return SP_EINVAL;
   size_t sb = 32 * rows * cols, ib = (4 * cols + 31) & ~(size_t)31;
-  if (sb + ib > HMAP_IN) return SP_EINVAL;
+  if (sb + ib > HMAP_GEN) return SP_EINVAL;
   const Fq* ds = (const Fq*)stage_small(c, 0, S, sb);
   const uint32_t* di = (const uint32_t*)stage_small(c, sb, idx, 4 * cols);
   ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 128.0 * (double)rows, st);
@@ -828,7 +835,7 @@ int32_t sp_msm_indexed(sp_ctx* c, const sp_gens* g, const uint32_t* idx, size_t 
     if (idx[j] >= g->n) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   size_t sb = 32 * rows * cols, ib = (4 * cols + 31) & ~(size_t)31;
-  if (sb + ib <= HMAP_IN) {  // Sigma-protocol sized: the kernel reads scalars and indices straight from the host-mapped page
+  if (sb + ib <= HMAP_GEN) {  // Sigma-protocol sized: the kernel reads scalars and indices straight from the host-mapped page
     const Fq* ds = (const Fq*)stage_small(c, 0, S, sb);
     const uint32_t* di = (const uint32_t*)stage_small(c, sb, idx, 4 * cols);
     return msm_launch(c, g, ds, cols, rows, cols, 0, di, nullptr, 0, out);

@@ -194,7 +194,14 @@ extern "C" {
 int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   if (!c || !r || !out || ell == 0 || ell > 40) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  const Fq* dr = (const Fq*)stage_small(c, 0, r, 32 * ell);
+  // the challenge vector goes into the next slot of a small ring and the call returns without waiting; a slot is reused
+  // only after a completed wait on the stream (sync_epoch moved on), which guarantees its kernel has read it
+  static_assert(EQ_SLOTS == 8 && 32 * 40 <= EQ_SLOT_BYTES, "eq ring layout");
+  unsigned slot = c->eq_next;
+  c->eq_next = (slot + 1) % EQ_SLOTS;
+  if (c->eq_slot_epoch[slot] == c->sync_epoch + 1) SPCHK(sync_spin(c));
+  const Fq* dr = (const Fq*)stage_small(c, HMAP_GEN + slot * EQ_SLOT_BYTES, r, 32 * ell);
+  c->eq_slot_epoch[slot] = c->sync_epoch + 1;
   size_t len = (size_t)1 << ell;
   SPCHK(table_new(c, len, false, out));
   int topb = ell < (size_t)EQ_TOPB ? (int)ell : EQ_TOPB;
@@ -209,7 +216,6 @@ int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
       default: hipLaunchKernelGGL(k_eq_expand<EQ_TOPB>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
     }
   }
-  SPCHK(sync_spin(c));  // the host-mapped input page is reusable
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
@@ -395,7 +401,7 @@ int32_t sp_evaluate(sp_ctx* c, const sp_table* Z, const uint64_t* r, size_t ell,
 }
 static int32_t gather_elems(sp_ctx* c, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out) {
   if (!c || !tabs || !out || ntabs == 0 || count == 0) return SP_EINVAL;
-  if (32 * ntabs * count > HMAP_SIZE - HMAP_IN || 8 * ntabs > HMAP_IN) return SP_EINVAL;
+  if (32 * ntabs * count > HMAP_SIZE - HMAP_IN || 8 * ntabs > HMAP_GEN) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   std::vector<const Fq*> ptrs(ntabs);
   for (size_t k = 0; k < ntabs; k++) {

@@ -64,6 +64,9 @@ struct sp_ctx {
   hipEvent_t sync_ev;
   // completion of the main stream is signalled by a one-thread kernel that stores a sequence number into host memory,
   // which the host polls: 6-9 us per round trip against 11-14 us for hipEventRecord + hipEventQuery (bench/flag_probe.hip)
+  uint64_t sync_epoch;              // completed waits on the main stream
+  uint64_t eq_slot_epoch[8];        // sync_epoch + 1 when the slot was last filled (0 = never)
+  unsigned eq_next;
   volatile uint32_t* done_flag;
   uint32_t done_seq;
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
@@ -165,8 +168,10 @@ int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes);  // de
 // land at sums_out (device-visible). core.hip.
 extern "C" int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows,
                                      uint8_t* sums_out);
-// host-mapped page layout: [0, HMAP_IN) kernel inputs, [HMAP_IN, HMAP_SIZE) kernel results
-constexpr size_t HMAP_IN = 32768, HMAP_SIZE = 65536;
+// host-mapped page layout: [0, HMAP_GEN) inputs of calls that wait for their kernels, [HMAP_GEN, HMAP_IN) a ring of
+// EQ_SLOTS slots for the challenge vectors of sp_eq_expand (which does not wait: the table is consumed by later launches
+// on the same stream), [HMAP_IN, HMAP_SIZE) kernel results
+constexpr size_t HMAP_IN = 32768, HMAP_SIZE = 65536, EQ_SLOTS = 8, EQ_SLOT_BYTES = 1280, HMAP_GEN = HMAP_IN - EQ_SLOTS * EQ_SLOT_BYTES;
 void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes);  // returns the device-visible address; bytes+off <= HMAP_IN
 static inline uint8_t* hres(sp_ctx* c) { return c->hmap + HMAP_IN; }
 int32_t fetch_small(sp_ctx* c, void* hdst, size_t bytes);
