@@ -39,16 +39,21 @@ struct HostSpan {
   const char* name; double t0, api0, child = 0; HostSpan* parent;
   static HostSpan*& top() { static HostSpan* t = nullptr; return t; }
   static std::map<std::string, std::pair<double, size_t>>& acc() { static std::map<std::string, std::pair<double, size_t>> m; return m; }
+  static std::map<std::string, double>& incl() { static std::map<std::string, double> m; return m; }
   explicit HostSpan(const char* n) : name(n), t0(now_s()), api0(g_api_t), parent(top()) { top() = this; }
   ~HostSpan() {
     double wall = now_s() - t0, api = g_api_t - api0;
     auto& e = acc()[name]; e.first += wall - api - child; e.second++;
+    incl()[name] += wall;
     if (parent) parent->child += wall - api;
     top() = parent;
   }
   static void dump() {
-    for (auto& kv : acc()) fprintf(stderr, "[hostprof] %-28s %6zu calls %9.3f ms host-exclusive\n", kv.first.c_str(), kv.second.second, kv.second.first * 1e3);
+    for (auto& kv : acc())
+      fprintf(stderr, "[hostprof] %-28s %6zu calls %9.3f ms host-exclusive %9.3f ms wall-inclusive\n", kv.first.c_str(), kv.second.second,
+              kv.second.first * 1e3, incl()[kv.first] * 1e3);
     acc().clear();
+    incl().clear();
   }
 };
 #define HSPAN(n) HostSpan hspan_(n)
