@@ -2,13 +2,17 @@
 // with device-resident a, b and generator-coefficient vector s. See include/spartan_hip.h for the algebra:
 // the folded generator vector is never built; every L/R is a fixed-base MSM over the uploaded generators.
 #include "internal.hpp"
+#include <utility>
 
 struct sp_ipa {
   sp_ctx* ctx;
   const sp_gens* g;
   size_t n0, n_cur, g_off, q_idx, h_idx;
   Fq q_scale;
-  Fq *a, *b, *s, *s2, *rows;  // device: a[n0], b[n0], s[n0], s2[n0], rows[2][n0+2] (round L/R use [2][n0/2+2] of it)
+  Fq *a, *b, *a2, *b2, *s, *s2, *rows;  // device: a, b, a2, b2, s, s2 [n0] each (ping-pong pairs), rows[2][n0+2] (round L/R use [2][n0/2+2])
+  uint8_t* base;                       // the one pool allocation behind all of the above (a and a2 swap roles, so `a` is not it)
+  bool fold_pending;                   // sp_ipa_round_fold only records (u, u^-1): the next launch that needs a, b, s applies it
+  Fq fu, fu_inv;
   uint32_t* idx;              // device: n0+2 generator indices (all generators, Q, H)
   uint32_t* idx_lr;           // device: [2][n0/2+2] per-row generator lists of the current round
   size_t bytes;
@@ -18,27 +22,52 @@ struct sp_ipa {
 // generator j = p*n_cur + i belongs to L when i >= h (scalar a[i-h]*s[p]) and to R when i < h (scalar a[h+i]*s[p]), so
 // each row has m = n0/2 + 2 columns with its own generator list: rows[r][q], idx_lr[r][q], q = p*h + (i mod h), then Q, H.
 // Blocks 0..nb-1 fill the generator columns; the extra last block computes c_L, c_R (LDS reduce) and the trailing columns.
+// When `fold` is set the vectors are those of the previous round and the fold of bullet.rs:105-109 by (u, u^-1) is applied
+// on the way: every block derives the folded entries it needs on the fly (2 multiplications each), and the extra block
+// materialises a', b', s' in the ping-pong buffers before it forms c_L, c_R from them — the fold needs no launch of its own.
+__device__ __forceinline__ Fq ipa_a(const Fq* __restrict__ a, size_t x, size_t n_cur, int fold, const Fq& u, const Fq& u_inv) {
+  Fq v = ld_fq(a + x);
+  return fold ? fq_add(fq_mul(v, u), fq_mul(u_inv, ld_fq(a + n_cur + x))) : v;  // a' = a_L u + u^-1 a_R
+}
+__device__ __forceinline__ Fq ipa_b(const Fq* __restrict__ b, size_t x, size_t n_cur, int fold, const Fq& u, const Fq& u_inv) {
+  Fq v = ld_fq(b + x);
+  return fold ? fq_add(fq_mul(v, u_inv), fq_mul(u, ld_fq(b + n_cur + x))) : v;  // b' = b_L u^-1 + u b_R
+}
+__device__ __forceinline__ Fq ipa_s(const Fq* __restrict__ s, size_t p, int fold, const Fq& u, const Fq& u_inv) {
+  return fold ? fq_mul(ld_fq(s + p / 2), (p & 1) ? u : u_inv) : ld_fq(s + p);  // s'[2p] = s[p] u^-1, s'[2p+1] = s[p] u
+}
 __global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
                                                      size_t n0, size_t g_off, uint32_t q_idx, uint32_t h_idx, Fq q_scale, Fq blind_L, Fq blind_R,
-                                                     Fq* __restrict__ rows, uint32_t* __restrict__ idx_lr) {
+                                                     Fq* __restrict__ rows, uint32_t* __restrict__ idx_lr, int fold, Fq u, Fq u_inv,
+                                                     Fq* __restrict__ a_new, Fq* __restrict__ b_new, Fq* __restrict__ s_new) {
   __shared__ Fq sm[256];
   size_t h = n_cur / 2, m = n0 / 2 + 2;
   if (blockIdx.x + 1 < gridDim.x) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n0) return;
     size_t p = j / n_cur, i = j % n_cur;
-    Fq sp_ = ld_fq(s + p);
+    Fq sp_ = ipa_s(s, p, fold, u, u_inv);
     bool is_l = i >= h;
     size_t q = p * h + (is_l ? i - h : i);
-    Fq v = fq_mul(ld_fq(a + (is_l ? i - h : h + i)), sp_);  // a_L[i-h] * G_R[i-h]  |  a_R[i] * G_L[i]
+    Fq v = fq_mul(ipa_a(a, is_l ? i - h : h + i, n_cur, fold, u, u_inv), sp_);  // a_L[i-h] * G_R[i-h]  |  a_R[i] * G_L[i]
     st_fq(rows + (is_l ? 0 : m) + q, v);
     idx_lr[(is_l ? 0 : m) + q] = (uint32_t)(g_off + j);
     return;
   }
+  const Fq *ac = a, *bc = b;
+  if (fold) {
+    for (size_t i = threadIdx.x; i < n_cur; i += 256) {
+      st_fq(a_new + i, ipa_a(a, i, n_cur, 1, u, u_inv));
+      st_fq(b_new + i, ipa_b(b, i, n_cur, 1, u, u_inv));
+    }
+    for (size_t p = threadIdx.x; p < n0 / n_cur; p += 256) st_fq(s_new + p, ipa_s(s, p, 1, u, u_inv));
+    __syncthreads();  // this block reads back what it has just written
+    ac = a_new; bc = b_new;
+  }
   Fq c[2] = {fq_zero(), fq_zero()};
   for (size_t i = threadIdx.x; i < h; i += 256) {
-    c[0] = fq_add(c[0], fq_mul(ld_fq(a + i), ld_fq(b + h + i)));  // c_L = <a_L, b_R>  (bullet.rs:80)
-    c[1] = fq_add(c[1], fq_mul(ld_fq(a + h + i), ld_fq(b + i)));  // c_R = <a_R, b_L>  (bullet.rs:81)
+    c[0] = fq_add(c[0], fq_mul(ld_fq(ac + i), ld_fq(bc + h + i)));  // c_L = <a_L, b_R>  (bullet.rs:80)
+    c[1] = fq_add(c[1], fq_mul(ld_fq(ac + h + i), ld_fq(bc + i)));  // c_R = <a_R, b_L>  (bullet.rs:81)
   }
   block_sum_fq<2>(c, sm);
   if (threadIdx.x == 0) {
@@ -85,7 +114,7 @@ extern "C" {
 
 void sp_ipa_free(sp_ipa* ipa) {
   if (!ipa) return;
-  pool_release(ipa->ctx, ipa->a, ipa->bytes);  // one allocation backs a, b, s, s2, rows, idx
+  pool_release(ipa->ctx, ipa->base, ipa->bytes);  // one allocation backs a, b, a2, b2, s, s2, rows, idx
   delete ipa;
 }
 int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
@@ -96,13 +125,17 @@ int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t
   if (!ipa) return SP_ENOMEM;
   ipa->ctx = c; ipa->g = g; ipa->n0 = ipa->n_cur = n; ipa->g_off = g_off; ipa->q_idx = q_idx; ipa->h_idx = h_idx;
   ipa->q_scale = limbs(q_scale);
-  size_t fq_count = 4 * n + 2 * (n + 2);
+  size_t fq_count = 6 * n + 2 * (n + 2);
   uint8_t* base = nullptr;
   ipa->bytes = 32 * fq_count + 4 * (n + 2) + 4 * (n + 4);
   ipa->a = nullptr;
+  ipa->base = nullptr;
   int32_t prc = pool_alloc(c, ipa->bytes, (void**)&base);
   if (prc != SP_OK) { delete ipa; return prc; }
-  ipa->a = (Fq*)base; ipa->b = ipa->a + n; ipa->s = ipa->b + n; ipa->s2 = ipa->s + n; ipa->rows = ipa->s2 + n;
+  ipa->base = base;
+  ipa->a = (Fq*)base; ipa->b = ipa->a + n; ipa->a2 = ipa->b + n; ipa->b2 = ipa->a2 + n; ipa->s = ipa->b2 + n; ipa->s2 = ipa->s + n;
+  ipa->rows = ipa->s2 + n;
+  ipa->fold_pending = false;
   ipa->idx = (uint32_t*)(ipa->rows + 2 * (n + 2));
   ipa->idx_lr = ipa->idx + (n + 2);
   std::vector<uint32_t> idx(n + 2);
@@ -129,7 +162,11 @@ int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t b
     ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);
     hipLaunchKernelGGL(k_ipa_prepare, dim3((unsigned)((ipa->n0 + 255) / 256 + 1)), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
                        ipa->n0, ipa->g_off, (uint32_t)ipa->q_idx, (uint32_t)ipa->h_idx, ipa->q_scale, limbs(blind_L), limbs(blind_R), ipa->rows,
-                       ipa->idx_lr);
+                       ipa->idx_lr, ipa->fold_pending ? 1 : 0, ipa->fu, ipa->fu_inv, ipa->a2, ipa->b2, ipa->s2);
+  }
+  if (ipa->fold_pending) {  // the kernel left the folded vectors in the ping-pong buffers
+    std::swap(ipa->a, ipa->a2); std::swap(ipa->b, ipa->b2); std::swap(ipa->s, ipa->s2);
+    ipa->fold_pending = false;
   }
   uint8_t lr[64];
   size_t m = ipa->n0 / 2 + 2;
@@ -138,23 +175,34 @@ int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t b
   memcpy(R_out, lr + 32, 32);
   return SP_OK;
 }
+// apply a recorded fold now (the vectors are needed by something other than the next round's prepare kernel)
+static int32_t ipa_flush_fold(sp_ipa* ipa) {
+  if (!ipa->fold_pending) return SP_OK;
+  sp_ctx* c = ipa->ctx;
+  {
+    ProfScope ps(c, PF_IPA, 32.0 * 6 * (double)ipa->n_cur);
+    hipLaunchKernelGGL(k_ipa_fold, dim3(1), dim3(256), 0, c->stream, ipa->a, ipa->b, (const Fq*)ipa->s, ipa->s2, 2 * ipa->n_cur, ipa->n0, ipa->fu,
+                       ipa->fu_inv);
+  }
+  std::swap(ipa->s, ipa->s2);
+  ipa->fold_pending = false;
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
 int32_t sp_ipa_round_fold(sp_ipa* ipa, const uint64_t u[4], const uint64_t u_inv[4]) {
   if (!ipa || !u || !u_inv || ipa->n_cur < 2) return SP_EINVAL;
-  sp_ctx* c = ipa->ctx;
-  HIPCHK(hipSetDevice(c->dev));
-  {
-    ProfScope ps(c, PF_IPA, 32.0 * 3 * (double)ipa->n_cur);
-    hipLaunchKernelGGL(k_ipa_fold, dim3(1), dim3(256), 0, c->stream, ipa->a, ipa->b, (const Fq*)ipa->s, ipa->s2, ipa->n_cur, ipa->n0, limbs(u),
-                       limbs(u_inv));
-  }
-  Fq* t = ipa->s; ipa->s = ipa->s2; ipa->s2 = t;
+  HIPCHK(hipSetDevice(ipa->ctx->dev));
+  SPCHK(ipa_flush_fold(ipa));  // at most one fold is deferred
+  ipa->fu = limbs(u);
+  ipa->fu_inv = limbs(u_inv);
+  ipa->fold_pending = true;
   ipa->n_cur /= 2;
-  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+  return SP_OK;
 }
 int32_t sp_ipa_finish(sp_ipa* ipa, uint64_t a_hat[4], uint64_t b_hat[4], uint8_t* g_hat) {
   if (!ipa || !a_hat || !b_hat || ipa->n_cur != 1) return SP_EINVAL;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ipa_flush_fold(ipa));
   SPCHK(fetch_out(c, ipa->a, a_hat, 32));
   SPCHK(fetch_out(c, ipa->b, b_hat, 32));
   if (g_hat) SPCHK(msm_launch(c, ipa->g, ipa->s, ipa->n0, 1, ipa->n0, ipa->g_off, nullptr, nullptr, 0, g_hat));
@@ -164,6 +212,7 @@ int32_t sp_ipa_commit_ghat(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4]
   if (!ipa || !d || !r || !out || ipa->n_cur != 1) return SP_EINVAL;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ipa_flush_fold(ipa));
   {
     ProfScope ps(c, PF_IPA, 64.0 * (double)ipa->n0);
     hipLaunchKernelGGL(k_ipa_ghat_row, dim3((unsigned)grid_for(ipa->n0, 64)), dim3(256), 0, c->stream, (const Fq*)ipa->s, ipa->n0, limbs(d),
