@@ -186,6 +186,8 @@ int32_t sp_hash_layer(sp_ctx* ctx, const sp_table* addr, const sp_table* val, co
 /* ProductCircuit::new (product_tree.rs:36-56). `store` has 2n elements with the n leaves in [0,n); layer k
  * (n/2^k elements, left half then right half) is written at offset 2n - 2n/2^k for k = 1..log2(n)-1. */
 int32_t sp_product_tree(sp_ctx* ctx, sp_table* store, size_t n);
+/* The same for `count` circuits of equal size n, one launch per layer for all of them. */
+int32_t sp_product_tree_many(sp_ctx* ctx, sp_table* const* stores, size_t count, size_t n);
 /* prove_cubic_batched evaluations (sumcheck.rs:287-357): for each instance k, the sums of A_k*B_k*C_k at
  * t = 0, 2, 3 over the current length -> out[4*(3k + {0,1,2})]. Tables may repeat across instances. */
 int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out);

@@ -24,6 +24,18 @@ __global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, s
     st_fq(out + i, fq_mul(ld_fq(in + i), ld_fq(in + half + i)));
 }
 
+// the same layer of several product circuits of equal size in one launch (grid.y = circuit): a 2^20-leaf tree has 19
+// layers of which 12 are shorter than a launch (a few us of fixed cost each)
+struct Stores16 {
+  Fq* p[16];
+};
+__global__ void __launch_bounds__(256) k_prod_layer_many(Stores16 st, size_t off, size_t half, size_t noff) {
+  const Fq* in = st.p[blockIdx.y] + off;
+  Fq* out = st.p[blockIdx.y] + noff;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+    st_fq(out + i, fq_mul(ld_fq(in + i), ld_fq(in + half + i)));
+}
+
 struct Triple {
   Fq *a, *b, *c;
   Fq* c_out;  // where this instance writes the bound C (non-null for exactly one instance per distinct C table)
@@ -231,6 +243,27 @@ int32_t sp_product_tree(sp_ctx* c, sp_table* store, size_t n) {
     hipLaunchKernelGGL(k_prod_layer, dim3((unsigned)grid_for(half)), dim3(256), 0, c->stream, (const Fq*)(store->d + off), half, store->d + noff);
     off = noff;
     len = half;
+  }
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+
+int32_t sp_product_tree_many(sp_ctx* c, sp_table* const* stores, size_t count, size_t n) {
+  if (!c || !stores || count == 0 || !is_pow2(n) || n < 2) return SP_EINVAL;
+  for (size_t k = 0; k < count; k++)
+    if (!stores[k] || stores[k]->cap < 2 * n) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  for (size_t k0 = 0; k0 < count; k0 += 16) {
+    size_t nk = count - k0 < 16 ? count - k0 : 16;
+    Stores16 st;
+    for (size_t k = 0; k < 16; k++) st.p[k] = k < nk ? stores[k0 + k]->d : nullptr;
+    size_t off = 0, len = n;
+    while (len > 2) {
+      size_t half = len / 2, noff = off + len;
+      ProfScope ps(c, PF_SPARK, 48.0 * (double)len * (double)nk);
+      hipLaunchKernelGGL(k_prod_layer_many, dim3((unsigned)grid_for(half, 1024), (unsigned)nk), dim3(256), 0, c->stream, st, off, half, noff);
+      off = noff;
+      len = half;
+    }
   }
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
