@@ -107,6 +107,9 @@ int32_t sp_eq_expand(sp_ctx* ctx, const uint64_t* r /*4*ell*/, size_t ell, sp_ta
 int32_t sp_sumcheck_eval(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t ntabs, uint64_t* out_evals);
 /* DensePolynomial::bound_poly_var_top (dense_mlpoly.rs:215-223) on every table: Z[i] += r*(Z[i+n]-Z[i]). */
 int32_t sp_table_bind_top(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, const uint64_t r[4]);
+/* The last round of a sum-check: tables of length 2 are bound at r (length 1) and their remaining entry is returned,
+ * out_heads[4k..4k+4) for table k — one launch and one wait for any number of tables (each listed once). */
+int32_t sp_table_bind_top_heads(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_heads);
 /* Fused: bind all tables at r, then evaluate the next round on the bound tables in the same pass. */
 int32_t sp_sumcheck_bind_eval(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals);
 /* One round body of the zero-knowledge sum-checks (sumcheck.rs:471-583 / 661-772): sp_sumcheck_bind_eval at r and, at the

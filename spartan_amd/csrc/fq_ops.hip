@@ -129,6 +129,18 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval(Tabs4 T, size_t quarter, F
     st_fq(partials + 3 * blockIdx.x + 2, e[2]);
   }
 }
+// the same for any number of tables of one length (pointer list in the host-mapped page); heads != nullptr with half == 1:
+// the bound value (the table's only remaining entry) also goes to the result area — bound_poly_var_top + [0] in one launch
+__global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ ptrs, size_t ntabs, size_t half, Fq r, Fq* __restrict__ heads) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ntabs * half; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t t = idx / half, i = idx % half;
+    Fq* p = ptrs[t];
+    Fq x0 = ld_fq(p + i), x1 = ld_fq(p + half + i);
+    Fq v = fq_add(x0, fq_mul(r, fq_sub(x1, x0)));
+    st_fq(p + i, v);
+    if (heads) st_fq(heads + t, v);
+  }
+}
 __global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t half, Fq r) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     for (int k = 0; k < ntabs; k++) {
@@ -275,6 +287,39 @@ int32_t sp_table_bind_top(sp_ctx* c, sp_table* const* tabs, size_t ntabs, const 
     for (size_t k = 0; k < nk; k++) tabs[k0 + k]->len = half;
   }
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+static Fq limbs4(const uint64_t* p) {
+  Fq x;
+  memcpy(x.l, p, 32);
+  return x;
+}
+static int32_t bind_top_list(sp_ctx* c, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_heads) {
+  if (!c || !tabs || !r || ntabs == 0 || 8 * ntabs > HMAP_GEN || 32 * ntabs > HMAP_SIZE - HMAP_IN) return SP_EINVAL;
+  size_t len = tabs[0] ? tabs[0]->len : 0;
+  if (len < 2 || !is_pow2(len) || (out_heads && len != 2)) return SP_EINVAL;
+  std::vector<Fq*> ptrs(ntabs);
+  for (size_t k = 0; k < ntabs; k++) {
+    if (!tabs[k] || tabs[k]->len != len) return SP_EINVAL;
+    for (size_t m = 0; m < k; m++)
+      if (tabs[m] == tabs[k]) return SP_EINVAL;  // a table listed twice would be bound twice
+    ptrs[k] = tabs[k]->d;
+  }
+  HIPCHK(hipSetDevice(c->dev));
+  Fq* const* dp = (Fq* const*)stage_small(c, 0, ptrs.data(), 8 * ntabs);
+  size_t half = len / 2;
+  {
+    ProfScope ps(c, PF_SC_BIND, 48.0 * (double)len * (double)ntabs);
+    hipLaunchKernelGGL(k_bind_top_list, dim3((unsigned)grid_for(ntabs * half)), dim3(256), 0, c->stream, dp, ntabs, half, limbs4(r),
+                       out_heads ? (Fq*)hres(c) : (Fq*)nullptr);
+  }
+  for (size_t k = 0; k < ntabs; k++) tabs[k]->len = half;
+  if (out_heads) SPCHK(fetch_small(c, out_heads, 32 * ntabs));
+  else SPCHK(sync_spin(c));  // the pointer list sits in the shared input page
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_table_bind_top_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_heads) {
+  if (!out_heads) return SP_EINVAL;
+  return bind_top_list(c, tabs, ntabs, r, out_heads);
 }
 int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals) {
   if (kind < 0 || kind > 2 || !out_evals || !r) return SP_EINVAL;
