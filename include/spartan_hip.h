@@ -90,6 +90,7 @@ int32_t sp_msm_indexed(sp_ctx* ctx, const sp_gens* g, const uint32_t* idx, size_
 
 /* ---- device tables (DensePolynomial.Z, src/dense_mlpoly.rs:14-18) ----------------------------------- */
 int32_t sp_table_alloc(sp_ctx* ctx, size_t len, sp_table** out);          /* zero-filled */
+int32_t sp_table_alloc_uninit(sp_ctx* ctx, size_t len, sp_table** out);   /* contents undefined: for tables the caller overwrites entirely */
 int32_t sp_table_upload(sp_ctx* ctx, const uint64_t* Z, size_t len, sp_table** out);
 int32_t sp_table_write(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* Z, size_t len);
 int32_t sp_table_download(sp_ctx* ctx, const sp_table* t, size_t off, size_t len, uint64_t* out);

@@ -866,6 +866,7 @@ int32_t table_new(sp_ctx* c, size_t len, bool zero, sp_table** out) {
   return SP_OK;
 }
 int32_t sp_table_alloc(sp_ctx* c, size_t len, sp_table** out) { return table_new(c, len, true, out); }
+int32_t sp_table_alloc_uninit(sp_ctx* c, size_t len, sp_table** out) { return table_new(c, len, false, out); }
 int32_t sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* Z, size_t len) {
   if (!c || !t || !Z || off + len > t->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));

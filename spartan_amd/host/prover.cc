@@ -144,6 +144,7 @@ GensStream& GensStream::operator=(GensStream&& o) noexcept {
 }
 
 static DevTable tab_alloc(sp_ctx* c, size_t len) { sp_table* t; SPX(sp_table_alloc(c, len, &t)); return DevTable(c, t); }
+static DevTable tab_alloc_uninit(sp_ctx* c, size_t len) { sp_table* t; SPX(sp_table_alloc_uninit(c, len, &t)); return DevTable(c, t); }
 static DevTable tab_upload(sp_ctx* c, const FqVec& v) { sp_table* t; SPX(sp_table_upload(c, U(v), v.size(), &t)); return DevTable(c, t); }
 static DevTable tab_view(sp_ctx* c, const DevTable& p, size_t off, size_t len) { sp_table* t; SPX(sp_table_view(c, p.h, off, len, &t)); return DevTable(c, t); }
 static DevTable tab_clone(sp_ctx* c, const DevTable& p) { sp_table* t; SPX(sp_table_clone(c, p.h, &t)); return DevTable(c, t); }
