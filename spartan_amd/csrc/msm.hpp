@@ -13,7 +13,8 @@
 namespace sp {
 
 #ifndef SP_MSM_WBITS
-#define SP_MSM_WBITS 12  // measured on MI355X at 2^20: c = 8 / 10 / 12 / 13 -> row commit 2.29 / 2.25 / 1.93 / 1.79 ms, proof 88.5 / 84.3 / 82.1 / 82.4 ms
+#define SP_MSM_WBITS 13  // measured on MI355X at 2^20, ms per proof: c = 8 / 10 / 12 / 13 -> 88.5 / 84.3 / 82.1 / 82.4 early in round 1; with the
+                         // final code 12 / 13 / 14 -> 50.4 / 49.5 / 48.9. 13 = 8.2 MiB per generator (42 GB at 2^20, 118 GB at 2^22); 14 would not fit 2^22
 #endif
 constexpr int MSM_WBITS = SP_MSM_WBITS;                        // signed window width c
 constexpr int MSM_NWIN = (254 + MSM_WBITS - 1) / MSM_WBITS;     // windows covering a 253-bit scalar plus the recoding carry
