@@ -31,8 +31,13 @@ __device__ __forceinline__ void eq_expand_top(Fq (&v)[1 << TOPB], const Fq* __re
     }
   }
 }
+// r arrives in the host-mapped page: it is copied to LDS once per block (one PCIe round trip for all of it) — read in
+// place, every step of the dependent product chain would wait ~2 us for its factor
 template <int TOPB>
-__global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r, size_t ell, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
+  __shared__ Fq r[40];
+  if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
+  __syncthreads();
   size_t nthreads = (size_t)1 << (ell - TOPB);
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nthreads) return;
@@ -41,10 +46,35 @@ __global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r, siz
 #pragma unroll
   for (int k = 0; k < (1 << TOPB); k++) st_fq(out + ((size_t)k << (ell - TOPB)) + t, v[k]);
 }
+// Short tables (ell <= EQ_SMALL_ELL) are pure latency, and there the SIZE of the code is what costs: the unrolled kernel
+// above is 59 KB of straight-line code that a lone wavefront fetches cold (~20 us measured, whatever ell is). Here one
+// thread per entry multiplies its ell factors in a rolled loop (2 KB of code).
+constexpr size_t EQ_SMALL_ELL = 13;
+__global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
+  __shared__ Fq r[40];
+  if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> ell) return;
+  Fq acc = fq_one();
+#pragma unroll 1
+  for (size_t k = 0; k < ell; k++) {
+    Fq rk = r[k];
+    bool bit = (i >> (ell - 1 - k)) & 1;  // r[0] <-> most significant index bit
+    Fq f = fq_sub(fq_one(), rk);
+#pragma unroll
+    for (int w = 0; w < 4; w++) f.l[w] = bit ? rk.l[w] : f.l[w];
+    acc = fq_mul(acc, f);
+  }
+  st_fq(out + i, acc);
+}
 // <Z, chi(r)> without materialising chi; per-block partials.
 template <int TOPB>
-__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r, size_t ell, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ partials) {
   __shared__ Fq sm[256];
+  __shared__ Fq r[40];
+  if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
+  __syncthreads();
   size_t nthreads = (size_t)1 << (ell - TOPB);
   Fq acc[1] = {fq_zero()};
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads; t += (size_t)gridDim.x * blockDim.x) {
@@ -221,6 +251,9 @@ int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   {
     ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
     dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
+    if (ell <= EQ_SMALL_ELL) {
+      hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), blk, 0, c->stream, dr, ell, (*out)->d);
+    } else
     switch (topb) {
       case 1: hipLaunchKernelGGL(k_eq_expand<1>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
       case 2: hipLaunchKernelGGL(k_eq_expand<2>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
