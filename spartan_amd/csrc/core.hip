@@ -246,6 +246,58 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
   }
   partial[row * (ncol * MSM_NWIN) + (size_t)w * ncol + j] = acc;
 }
+// In-place LDS tree sum of sm[0..n) into sm[0] for a 256-thread block, with every point addition spread over FOUR lanes.
+// A full extended addition is 9 dependent-ish field multiplications (~3.5 us for a lone lane); here lane `role` of a quad
+// computes one of A = (Y1-X1)(Y2-X2), B = (Y1+X1)(Y2+X2), C = T1*(2d*T2), D = (2*Z1)*Z2, the quad exchanges them through
+// LDS, and then one of X3 = E*F, Y3 = G*H, Z3 = F*G, T3 = E*H: three multiplications deep, same field elements (so the
+// same canonical bytes). All roles run ONE instruction stream — operands are chosen by LDS address and by selects, never
+// by branches — and the code is three multiplication bodies instead of nine (it is fetched cold by these few waves).
+__device__ __forceinline__ Fe10 fe10_pick(const Fe10& a, const Fe10& b, bool take_b) { return fe10_select(a, b, take_b); }
+__device__ __forceinline__ void pt10_tree_quad(Pt10* sm, Fe10* xch /*[256]*/, size_t n) {
+  const int t = threadIdx.x, role = t & 3;
+  const Fe10 zero = Fe10{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  const Fe10 k2d = fe10_pick(fe10_one(), fe10_load(fp_D2()), role == 2);  // the factor 2d belongs to C only
+  // field offsets inside Pt10, in units of Fe10: X 0, Y 1, Z 2, T 3
+  const int fsel = role <= 1 ? 1 : (role == 2 ? 3 : 2);  // first field:  Y, Y, T, Z
+  const int gsel = role <= 1 ? 0 : (role == 2 ? 3 : 2);  // second field: X, X, -, Z
+  int top = 128;
+  while (top > 1 && (size_t)top >= n) top >>= 1;  // no levels that would only add identities
+  for (int s = top; s > 0; s >>= 1) {
+    for (int base = 0; base < s; base += 64) {
+      const int q = base + (t >> 2);
+      const bool act = q < s && (size_t)(q + s) < n;
+      Fe10 res = zero;
+      if (act) {  // whole quads are active or not
+        const Fe10* P = reinterpret_cast<const Fe10*>(sm + q);
+        const Fe10* Q = reinterpret_cast<const Fe10*>(sm + q + s);
+        Fe10 f1 = P[fsel], g1 = P[gsel], f2 = Q[fsel], g2 = Q[gsel];
+        // role 0: f - g | role 1: f + g | role 2: f (T) | role 3: P: Z + Z, Q: Z
+        g1 = fe10_pick(g1, fe10_neg(g1), role == 0);
+        g1 = fe10_pick(g1, zero, role == 2);
+        g2 = fe10_pick(g2, fe10_neg(g2), role == 0);
+        g2 = fe10_pick(g2, zero, role >= 2);
+        Fe10 u = fe10_add(f1, g1), v = fe10_add(f2, g2);
+        res = fe10_mul(u, fe10_mul(v, k2d));
+      }
+      xch[t] = res;
+      __syncthreads();
+      Fe10 out = zero;
+      if (act) {
+        const int tb = t & ~3;
+        Fe10 A = xch[tb], B = xch[tb + 1], C = xch[tb + 2], D = xch[tb + 3];
+        Fe10 E = fe10_sub(B, A), F = fe10_sub(D, C), G = fe10_add(D, C), H = fe10_add(B, A);
+        // X3 = E*F, Y3 = G*H, Z3 = F*G, T3 = E*H
+        Fe10 m1 = fe10_pick(fe10_pick(E, G, role == 1), F, role == 2);
+        Fe10 m2 = fe10_pick(fe10_pick(F, H, (role & 1) != 0), G, role == 2);
+        out = fe10_mul(m1, m2);
+      }
+      __syncthreads();  // every read of sm and xch above is done
+      if (act) reinterpret_cast<Fe10*>(sm + q)[role == 0 ? 0 : (role == 1 ? 1 : (role == 2 ? 2 : 3))] = out;
+      __syncthreads();
+    }
+  }
+}
+
 // Latency path, fused form (rows <= SP_HOST_ENCODE_ROWS): grid (nblk, rows). Thread p of a row looks up the table entry
 // of its (column, window) pair and the block sums its 256 entries in an LDS tree, so a Sigma-protocol commitment is ONE
 // launch (nblk = 1, FINAL: the sum goes out as an extended point for the host to encode) and an inner-product round is two
@@ -257,6 +309,7 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
                                                           size_t idx_row_stride, const Fq* __restrict__ blinds, size_t h_idx,
                                                           void* __restrict__ out) {
   __shared__ Pt10 sm[256];
+  __shared__ Fe10 xch[256];
   size_t ncol = cols + (blinds ? 1 : 0), P = ncol * MSM_NWIN, row = blockIdx.y;
   int t = threadIdx.x;
   size_t p = (size_t)blockIdx.x * 256 + t;
@@ -280,12 +333,7 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
   sm[t] = acc;
   __syncthreads();
   size_t live = P - (size_t)blockIdx.x * 256;  // partial indices of this block that exist
-  int top = 128;
-  while (top > 1 && (size_t)top >= live) top >>= 1;
-  for (int s = top; s > 0; s >>= 1) {
-    if (t < s && (size_t)(t + s) < live) sm[t] = pt10_add(sm[t], sm[t + s]);
-    __syncthreads();
-  }
+  pt10_tree_quad(sm, xch, live);
   if (t == 0) {
     Pt10 r = sm[0];
     if (FINAL) ((Pt*)out)[row] = Pt{fe10_to_fp(r.X), fe10_to_fp(r.Y), fe10_to_fp(r.Z), fe10_to_fp(r.T)};
@@ -296,6 +344,7 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
 // Reductions run on the radix-2^25.5 serial-chain arithmetic (fe10.hpp): few waves, latency-bound.
 __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt10* __restrict__ out) {
   __shared__ Pt10 sm[256];
+  __shared__ Fe10 xch[256];
   size_t row = blockIdx.x, ck = blockIdx.y, nchunks = gridDim.y;
   int t = threadIdx.x;
   size_t lo = ck * chunk, hi = lo + chunk;
@@ -309,10 +358,7 @@ __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ i
   }
   sm[t] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (t < s) sm[t] = pt10_add(sm[t], sm[t + s]);
-    __syncthreads();
-  }
+  pt10_tree_quad(sm, xch, 256);
   if (t == 0) out[row * nchunks + ck] = sm[0];
 }
 // one block per row: sum the row's partials, RFC 9496 encode. IN10: partials already in Pt10 form (second pass).
@@ -324,6 +370,7 @@ __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ i
 template <bool IN10, bool ENCODE>
 __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ partial_, size_t nstrips, uint8_t* __restrict__ out) {
   __shared__ Pt10 sm[256];
+  __shared__ Fe10 xch[256];
   size_t row = blockIdx.x;
   int t = threadIdx.x;
   Pt10 acc = pt10_identity();
@@ -335,12 +382,7 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ par
   }
   sm[t] = acc;
   __syncthreads();
-  int top = 128;
-  while (top > 1 && (size_t)top >= nstrips) top >>= 1;  // no levels that would only add identities
-  for (int s = top; s > 0; s >>= 1) {
-    if (t < s && (size_t)(t + s) < nstrips) sm[t] = pt10_add(sm[t], sm[t + s]);
-    __syncthreads();
-  }
+  pt10_tree_quad(sm, xch, nstrips < 256 ? nstrips : 256);
   if (t == 0) {
     Pt10 r = sm[0];
     if (ENCODE) {
