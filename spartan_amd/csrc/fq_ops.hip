@@ -31,24 +31,10 @@ __device__ __forceinline__ void eq_expand_top(Fq (&v)[1 << TOPB], const Fq* __re
     }
   }
 }
-// r arrives in the host-mapped page: it is copied to LDS once per block (one PCIe round trip for all of it) — read in
-// place, every step of the dependent product chain would wait ~2 us for its factor
-template <int TOPB>
-__global__ void __launch_bounds__(256) k_eq_expand(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
-  __shared__ Fq r[40];
-  if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
-  __syncthreads();
-  size_t nthreads = (size_t)1 << (ell - TOPB);
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nthreads) return;
-  Fq v[1 << TOPB];
-  eq_expand_top<TOPB>(v, r, eq_suffix(r, ell, TOPB, t));
-#pragma unroll
-  for (int k = 0; k < (1 << TOPB); k++) st_fq(out + ((size_t)k << (ell - TOPB)) + t, v[k]);
-}
-// Short tables (ell <= EQ_SMALL_ELL) are pure latency, and there the SIZE of the code is what costs: the unrolled kernel
-// above is 59 KB of straight-line code that a lone wavefront fetches cold (~20 us measured, whatever ell is). Here one
-// thread per entry multiplies its ell factors in a rolled loop (2 KB of code).
+// Short tables (ell <= EQ_SMALL_ELL) are pure latency, and there the SIZE of the code is what costs: an earlier kernel
+// that expanded 16 entries per thread in registers was 59 KB of straight-line code, which a lone wavefront fetches cold
+// (~20 us measured, whatever ell is). Here one thread per entry multiplies its ell factors in a rolled loop (2 KB of code);
+// r arrives in the host-mapped page and is copied to LDS once per block.
 constexpr size_t EQ_SMALL_ELL = 13;
 __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
   __shared__ Fq r[40];
@@ -67,6 +53,15 @@ __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ 
     acc = fq_mul(acc, f);
   }
   st_fq(out + i, acc);
+}
+// Long tables: chi(r)[i] = chi(r_hi)[i >> lo] * chi(r_lo)[i & (2^lo - 1)] — two short tables (kernel above) and ONE
+// multiplication per entry in a streaming kernel with a few hundred bytes of code, instead of the 59 KB unrolled kernel
+// (whose first wave on every CU spends ~20 us fetching it). The product of the same factors in another order is the same
+// field element, hence the same canonical limbs.
+__global__ void __launch_bounds__(256) k_eq_outer(const Fq* __restrict__ hi, const Fq* __restrict__ lo, int lo_ell, size_t len, Fq* __restrict__ out) {
+  size_t mask = ((size_t)1 << lo_ell) - 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+    st_fq(out + i, fq_mul(ld_fq(hi + (i >> lo_ell)), ld_fq(lo + (i & mask))));
 }
 // <Z, chi(r)> without materialising chi; per-block partials.
 template <int TOPB>
@@ -246,19 +241,21 @@ int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   c->eq_slot_epoch[slot] = c->sync_epoch + 1;
   size_t len = (size_t)1 << ell;
   SPCHK(table_new(c, len, false, out));
-  int topb = ell < (size_t)EQ_TOPB ? (int)ell : EQ_TOPB;
-  size_t nthreads = len >> topb;
   {
     ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
-    dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
+    dim3 blk(256);
     if (ell <= EQ_SMALL_ELL) {
       hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), blk, 0, c->stream, dr, ell, (*out)->d);
-    } else
-    switch (topb) {
-      case 1: hipLaunchKernelGGL(k_eq_expand<1>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
-      case 2: hipLaunchKernelGGL(k_eq_expand<2>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
-      case 3: hipLaunchKernelGGL(k_eq_expand<3>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
-      default: hipLaunchKernelGGL(k_eq_expand<EQ_TOPB>, grid, blk, 0, c->stream, dr, ell, (*out)->d); break;
+    } else {
+      size_t hi_ell = ell - ell / 2, lo_ell = ell / 2, nhi = (size_t)1 << hi_ell, nlo = (size_t)1 << lo_ell;
+      Fq* tmp = nullptr;  // [chi(r_hi) | chi(r_lo)]; handed back to the pool right away: reuse is ordered by the stream
+      int32_t rc = pool_alloc(c, 32 * (nhi + nlo), (void**)&tmp);
+      if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; return rc; }
+      hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((nhi + 255) / 256)), blk, 0, c->stream, dr, hi_ell, tmp);
+      hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((nlo + 255) / 256)), blk, 0, c->stream, dr + hi_ell, lo_ell, tmp + nhi);
+      hipLaunchKernelGGL(k_eq_outer, dim3((unsigned)grid_for(len, 4096)), blk, 0, c->stream, (const Fq*)tmp, (const Fq*)(tmp + nhi), (int)lo_ell, len,
+                         (*out)->d);
+      pool_release(c, tmp, 32 * (nhi + nlo));
     }
   }
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
