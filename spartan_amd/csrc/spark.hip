@@ -291,13 +291,29 @@ static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, 
   *len_out = len;
   return SP_OK;
 }
+// Few partials per instance (the late rounds of every layer: most of the ~400 rounds of a proof): the blocks write them
+// straight into the host-mapped result page and the calling thread adds them — F_q additions are nanoseconds there,
+// while a second launch to add them costs ~10 us on the critical path.
+constexpr size_t HOST_SUM_BYTES = 24576;
+static bool host_sums(size_t nblk, size_t ninst) { return nblk == 1 || 96 * nblk * ninst <= HOST_SUM_BYTES; }
 static int32_t batched_finish(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out) {
   if (partials != (Fq*)hres(c)) {
     ProfScope ps(c, PF_REDUCE, 96.0 * (double)(nblk * ninst));
     hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c));
+    SPCHK(fetch_small(c, out, 96 * ninst));
+    return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
   }
-  SPCHK(fetch_small(c, out, 96 * ninst));
-  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+  SPCHK(sync_spin(c));
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  const Fq* p = (const Fq*)hres(c);  // [inst][blk][3]
+  Fq* o = (Fq*)out;
+  for (size_t i = 0; i < ninst; i++)
+    for (int k = 0; k < 3; k++) {
+      Fq acc = p[(i * nblk) * 3 + k];
+      for (size_t b = 1; b < nblk; b++) acc = fq_add(acc, p[(i * nblk + b) * 3 + k]);
+      o[3 * i + k] = acc;
+    }
+  return SP_OK;
 }
 int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out) {
   if (!out) return SP_EINVAL;
@@ -306,7 +322,7 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   SPCHK(batched_setup(c, A, B, C, ninst, &len, false));
   size_t half = len / 2, nblk = half <= 256 ? 1 : grid_for(half, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
-  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst);
     hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
@@ -327,7 +343,7 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   bool tiny = quarter <= 8192;  // one index per 8 lanes while the round is latency-bound (512 / 2048 / 8192 / 32768 measured: 45.3 / 45.0 / 44.8 / 45.6 ms per proof)
   size_t nblk = tiny ? (quarter + 31) / 32 : grid_for(quarter, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
-  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst);
     if (tiny)
