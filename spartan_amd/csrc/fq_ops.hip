@@ -217,13 +217,29 @@ __global__ void k_gather_elems(const Fq* const* __restrict__ ptrs, size_t n, siz
 }
 
 
-int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out) {
-  if (partials != (Fq*)hres(c)) {  // nblk == 1 kernels write their sums into the result area themselves
-    ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * K));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, (Fq*)hres(c));
+// partials[nblk][K] -> out[K]. A few hundred partials at most are written by the kernel straight into the host-mapped
+// result page and added by the calling thread (no second launch); longer lists are added by k_reduce_partials.
+static void host_sum(const Fq* p, size_t nblk, int K, uint64_t* out) {
+  Fq* o = (Fq*)out;
+  for (int k = 0; k < K; k++) {
+    Fq acc = p[k];
+    for (size_t b = 1; b < nblk; b++) acc = fq_add(acc, p[b * K + k]);
+    o[k] = acc;
   }
-  SPCHK(fetch_small(c, out, 32 * K));
-  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out) {
+  if (partials != (Fq*)hres(c)) {
+    {
+      ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * K));
+      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, (Fq*)hres(c));
+    }
+    SPCHK(fetch_small(c, out, 32 * K));
+    return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+  }
+  SPCHK(sync_spin(c));
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  host_sum((const Fq*)hres(c), nblk, K, out);
+  return SP_OK;
 }
 
 extern "C" {
@@ -281,7 +297,7 @@ int32_t sp_sumcheck_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntab
   HIPCHK(hipSetDevice(c->dev));
   size_t half = len / 2, nblk = half <= 256 ? 1 : grid_for(half, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
-  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_EVAL, 32.0 * (double)len * (double)ntabs);
     if (kind == 0) hipLaunchKernelGGL(k_sc_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
@@ -362,7 +378,7 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   memcpy(rr.l, r, 32);
   size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
-  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
     if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -390,14 +406,14 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
     return sp_msm_indexed(c, g, idx, cols, S, rows, out_points);
   }
   // the commitments do not depend on the tables: they run on the side stream while the main stream binds and evaluates
-  constexpr size_t SUMS_OFF = 1024;  // evaluations at hres[0, 96), row sums behind them
+  constexpr size_t SUMS_OFF = HMAP_SIZE - HMAP_IN - 1024;  // evaluations / partial sums at the head of the result area, row sums at its tail
   SPCHK(msm_small_enqueue(c, c->stream_side, g, idx, cols, S, rows, hres(c) + SUMS_OFF));
   HIPCHK(hipEventRecord(c->side_ev, c->stream_side));
   Fq rr;
   memcpy(rr.l, r, 32);
   size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
-  Fq* partials = nblk == 1 ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
     if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -412,9 +428,12 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
   HIPCHK(hipStreamWaitEvent(c->stream, c->side_ev, 0));  // one completion for both streams
   SPCHK(sync_spin(c));
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
-  memcpy(out_evals, hres(c), 32);
-  memcpy(out_evals + 4, hres(c) + 32, 32);
-  if (kind != 0) memcpy(out_evals + 8, hres(c) + 64, 32);
+  uint64_t e[12];
+  if (partials == (Fq*)hres(c)) host_sum((const Fq*)hres(c), nblk, 3, e);
+  else memcpy(e, hres(c), 96);
+  memcpy(out_evals, e, 32);
+  memcpy(out_evals + 4, e + 4, 32);
+  if (kind != 0) memcpy(out_evals + 8, e + 8, 32);
   Pt sums[8];
   memcpy(sums, hres(c) + SUMS_OFF, sizeof(Pt) * rows);
   for (size_t k = 0; k < rows; k++) pt_compress(sums[k], out_points + 32 * k);
@@ -446,7 +465,7 @@ int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, si
   HIPCHK(hipSetDevice(c->dev));
   size_t nblk = grid_for(n, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 1);
   {
     ProfScope ps(c, PF_DOT, 64.0 * (double)n);
     hipLaunchKernelGGL(k_dot, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)(a->d + a_off), (const Fq*)(b->d + b_off), n, partials);
@@ -460,7 +479,7 @@ int32_t sp_evaluate(sp_ctx* c, const sp_table* Z, const uint64_t* r, size_t ell,
   int topb = ell < (size_t)EQ_TOPB ? (int)ell : EQ_TOPB;
   size_t nthreads = Z->len >> topb, nblk = grid_for(nthreads, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 1);
   {
     ProfScope ps(c, PF_DOT, 32.0 * (double)Z->len);
     dim3 grid((unsigned)nblk), blk(256);

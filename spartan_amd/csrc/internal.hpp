@@ -174,6 +174,9 @@ extern "C" int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g
 constexpr size_t HMAP_IN = 32768, HMAP_SIZE = 65536, EQ_SLOTS = 8, EQ_SLOT_BYTES = 1280, HMAP_GEN = HMAP_IN - EQ_SLOTS * EQ_SLOT_BYTES;
 void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes);  // returns the device-visible address; bytes+off <= HMAP_IN
 static inline uint8_t* hres(sp_ctx* c) { return c->hmap + HMAP_IN; }
+// where a kernel should put its nblk x K partial sums: the host page when the calling thread can add them (reduce_and_fetch)
+constexpr size_t HOST_SUM_BYTES = 24576;
+static inline Fq* partials_dst(sp_ctx* c, size_t nblk, int K) { return 32 * nblk * (size_t)K <= HOST_SUM_BYTES ? (Fq*)hres(c) : (Fq*)c->scratch; }
 int32_t fetch_small(sp_ctx* c, void* hdst, size_t bytes);
 int32_t sync_spin(sp_ctx* c);  // wait for everything queued on the context stream                 // stream sync + copy out of the result area
 int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out);

@@ -294,7 +294,6 @@ static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, 
 // Few partials per instance (the late rounds of every layer: most of the ~400 rounds of a proof): the blocks write them
 // straight into the host-mapped result page and the calling thread adds them — F_q additions are nanoseconds there,
 // while a second launch to add them costs ~10 us on the critical path.
-constexpr size_t HOST_SUM_BYTES = 24576;
 static bool host_sums(size_t nblk, size_t ninst) { return nblk == 1 || 96 * nblk * ninst <= HOST_SUM_BYTES; }
 static int32_t batched_finish(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out) {
   if (partials != (Fq*)hres(c)) {
@@ -389,7 +388,7 @@ int32_t sp_dot3(sp_ctx* c, const sp_table* l, const sp_table* r, const sp_table*
   HIPCHK(hipSetDevice(c->dev));
   size_t nblk = grid_for(n, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 1);
   {
     ProfScope ps(c, PF_DOT, 96.0 * (double)n);
     hipLaunchKernelGGL(k_dot3, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)(l->d + off), (const Fq*)(r->d + off), (const Fq*)(w->d + off), n,

@@ -145,7 +145,7 @@ int32_t sp_sparse_evaluate(sp_ctx* c, const sp_sparse* m, const sp_table* tx, co
   HIPCHK(hipSetDevice(c->dev));
   size_t nblk = grid_for(m->nnz ? m->nnz : 1, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
-  Fq* partials = (Fq*)c->scratch;
+  Fq* partials = partials_dst(c, nblk, 1);
   {
     ProfScope ps(c, PF_SPARSE, (double)m->nnz * (8 + 96));
     hipLaunchKernelGGL(k_sparse_eval, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const uint32_t*)m->csr_row, (const uint32_t*)m->csr_col,
