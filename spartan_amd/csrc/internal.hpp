@@ -175,7 +175,7 @@ constexpr size_t HMAP_IN = 32768, HMAP_SIZE = 65536, EQ_SLOTS = 8, EQ_SLOT_BYTES
 void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes);  // returns the device-visible address; bytes+off <= HMAP_IN
 static inline uint8_t* hres(sp_ctx* c) { return c->hmap + HMAP_IN; }
 // where a kernel should put its nblk x K partial sums: the host page when the calling thread can add them (reduce_and_fetch)
-constexpr size_t HOST_SUM_BYTES = 24576;
+constexpr size_t HOST_SUM_BYTES = 30720;  // the last KiB of the 32 KiB result area is kept for row sums (sp_sumcheck_bind_eval_commit)
 static inline Fq* partials_dst(sp_ctx* c, size_t nblk, int K) { return 32 * nblk * (size_t)K <= HOST_SUM_BYTES ? (Fq*)hres(c) : (Fq*)c->scratch; }
 int32_t fetch_small(sp_ctx* c, void* hdst, size_t bytes);
 int32_t sync_spin(sp_ctx* c);  // wait for everything queued on the context stream                 // stream sync + copy out of the result area
