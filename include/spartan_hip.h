@@ -55,7 +55,7 @@ int32_t sp_prof_read(sp_ctx* ctx, const char** names, double* total_ms, uint64_t
  * A sp_gens is a list of n points P[0..n). A MultiCommitGens{G[0..m), h} made by
  * MultiCommitGens::new(m, label) is the list of its m+1 stream points with h = P[m]; gens that are prefixes
  * of one SHAKE stream (gens_3/gens_4/gens_pc of R1CSGens, src/r1csproof.rs:48-73) share one sp_gens.
- * Upload builds signed 12-bit fixed-base window tables (22 windows x 2048 affine entries per point, 4.1 MiB
+ * Upload builds signed 13-bit fixed-base window tables (20 windows x 4096 affine entries per point, 7.5 MiB
  * per point in HBM; 288 GB makes that cheap): generators are public parameters reused across proofs, so this
  * is setup cost (~85 ms per 1000 points). */
 int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n, sp_gens** out);

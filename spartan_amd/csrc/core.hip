@@ -547,7 +547,7 @@ int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* 
 }
 
 
-// Window tables are public parameters (MultiCommitGens is immutable, commitments.rs:8-13) and large (4.1 MiB per point):
+// Window tables are public parameters (MultiCommitGens is immutable, commitments.rs:8-13) and large (7.5 MiB per point):
 // they are built once per (device, generator bytes) and shared by every context of the process — concurrent proving
 // contexts on one GPU hold one copy, and re-creating a SNARKGens is free. Reference-counted; freed with the last handle.
 struct GensCacheEntry {
