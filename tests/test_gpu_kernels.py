@@ -249,6 +249,57 @@ def test_addr_timestamps_match_reference_scan(ctx, per, cells, nlists, dist):
     dst.free(); aud.free()
 
 
+def test_bind_top_heads_product_tree_many_and_round_body(ctx, orc, gens40):
+    """the calls that issue several pieces of one protocol step together: sp_table_bind_top_heads (last sum-check round),
+    sp_product_tree_many (ProductCircuit::new for circuits of one size), sp_sumcheck_bind_eval_commit (a ZK round body)"""
+    from spartan_amd import capi
+    rng = random.Random(2024)
+    # --- last round: 37 tables of length 2 bound at r, remaining entries returned (Python ground truth)
+    r = rng.randrange(Q)
+    vals = [[rng.randrange(Q), rng.randrange(Q)] for _ in range(37)]
+    tabs = [capi.Table.upload(ctx, mont_array(v), 2) for v in vals]
+    out = (ctypes.c_uint64 * (4 * 37))()
+    assert capi.lib.sp_table_bind_top_heads(ctx.h, (vp * 37)(*[t.h for t in tabs]), sz(37), mont_array([r]), out) == 0
+    want = [(a + r * (b - a)) % Q for a, b in vals]
+    assert from_mont_array(out, 37) == want
+    assert [from_mont_array(t.download(1), 1)[0] for t in tabs] == want and all(len(t) == 1 for t in tabs)
+    dup = (vp * 2)(tabs[0].h, tabs[0].h)   # a table listed twice would be bound twice: refused
+    assert capi.lib.sp_table_bind_top_heads(ctx.h, dup, sz(2), mont_array([r]), out) != 0
+    for t in tabs:
+        t.free()
+    # --- product trees of 5 circuits of 64 leaves in one go == one at a time (sp_product_tree is checked against the oracle by the proofs)
+    n = 64
+    leaves = [rand_scalars(rng, n) for _ in range(5)]
+    many = [capi.Table.upload(ctx, mont_array(l + [0] * n), 2 * n) for l in leaves]
+    assert capi.lib.sp_product_tree_many(ctx.h, (vp * 5)(*[t.h for t in many]), sz(5), sz(n)) == 0
+    for l, t in zip(leaves, many):
+        layer, off, got = l, 0, from_mont_array(t.download(), 2 * n)
+        while len(layer) > 2:   # layer k+1[i] = left[i] * right[i] (product_tree.rs:36-56), stored behind layer k
+            half = len(layer) // 2
+            nxt = [layer[i] * layer[half + i] % Q for i in range(half)]
+            off += len(layer)
+            assert got[off:off + half] == nxt
+            layer = nxt
+        t.free()
+    # --- ZK round body: bind+evaluate and two small commitments in one call == the two calls made separately
+    ell = 9
+    A = [rand_scalars(rng, 1 << ell) for _ in range(4)]
+    t1 = [capi.Table.upload(ctx, mont_array(a), 1 << ell) for a in A]
+    t2 = [capi.Table.upload(ctx, mont_array(a), 1 << ell) for a in A]
+    rr = mont_array([rng.randrange(Q)])
+    idx = [3, 4, 5, 6, 39, 0, 39]
+    S = rand_scalars(rng, 2 * len(idx))
+    want_ev = capi.sumcheck_bind_eval(ctx, 2, t1, rr)
+    want_pts = gens40.msm_indexed(idx, mont_array(S), rows=2)
+    ev = (ctypes.c_uint64 * 12)(); pts = (ctypes.c_uint8 * 64)()
+    rc = capi.lib.sp_sumcheck_bind_eval_commit(ctx.h, ctypes.c_int(2), (vp * 4)(*[t.h for t in t2]), sz(4), rr, ev, gens40.h,
+                                               (ctypes.c_uint32 * len(idx))(*idx), sz(len(idx)), mont_array(S), sz(2), pts)
+    assert rc == 0 and list(ev) == list(want_ev) and bytes(pts) == want_pts
+    assert all(list(a.download()) == list(b.download()) for a, b in zip(t1, t2))
+    for t in t1 + t2:
+        t.free()
+
+
 def test_polynomial_evaluation_known_answer_on_device(ctx):
     """dense_mlpoly.rs:433-452 check_polynomial_evaluation: Z = [1,2,1,4], r = [4,3] -> 28, via sp_evaluate and via the
     L/R factorisation (sp_vecmat + host dot) the PolyEvalProof uses"""
