@@ -166,6 +166,51 @@ __global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ p
     if (heads) st_fq(heads + t, v);
   }
 }
+// Latency form of k_sc_bind_eval for short tables (quarter <= 8192), kinds 0 (A*B) and 2 (A*(B*C-D)): as in
+// k_cubic_bind_eval_tiny (spark.hip) the multiplications of one index are spread over 8 lanes — lane 2k+h binds half h of
+// table k, then lanes 0..2 evaluate t = 0, 2, 3 with one instruction stream (operands chosen by selects). Block = 32
+// indices x 8 lanes; partials[blk][3].
+template <int KIND>
+__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+  constexpr int NT = KIND == 0 ? 2 : 4;
+  __shared__ Fq bound[32][8];  // [index][table*2 + half]
+  __shared__ Fq red[3][32];
+  int li = threadIdx.x >> 3, role = threadIdx.x & 7;
+  size_t i = (size_t)blockIdx.x * 32 + li;
+  bool live = i < quarter;
+  if (role < 2 * NT && live) {
+    int k = role >> 1, half = role & 1;
+    Fq* ptr = T.p[k];
+    Fq x0 = ld_fq(ptr + (size_t)half * quarter + i), x2 = ld_fq(ptr + (size_t)(2 + half) * quarter + i);
+    Fq v = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
+    bound[li][role] = v;
+    st_fq(ptr + (size_t)half * quarter + i, v);
+  }
+  __syncthreads();
+  if (role < 3) {
+    Fq e = fq_zero();
+    if (live && (KIND == 2 || role < 2)) {
+      // value of each table's line at this lane's point: t = 0 -> x0 ; t = 2 -> 2 x1 - x0 ; t = 3 -> 3 x1 - 2 x0
+      Fq pt[4];
+#pragma unroll
+      for (int k = 0; k < NT; k++) {
+        Fq x0 = bound[li][2 * k], x1 = bound[li][2 * k + 1];
+        Fq x2 = fq_sub(fq_dbl(x1), x0), x3 = fq_sub(fq_add(x2, x1), x0);
+#pragma unroll
+        for (int w = 0; w < 4; w++) pt[k].l[w] = role == 0 ? x0.l[w] : (role == 1 ? x2.l[w] : x3.l[w]);
+      }
+      if (KIND == 0) e = fq_mul(pt[0], pt[1]);
+      else e = fq_mul(pt[0], fq_sub(fq_mul(pt[1], pt[2]), pt[3]));
+    }
+    red[role][li] = e;
+  }
+  __syncthreads();
+  for (int s = 16; s > 0; s >>= 1) {
+    if (role < 3 && li < s) red[role][li] = fq_add(red[role][li], red[role][li + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) st_fq(partials + (size_t)blockIdx.x * 3 + threadIdx.x, red[threadIdx.x][0]);
+}
 __global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t half, Fq r) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     for (int k = 0; k < ntabs; k++) {
@@ -376,14 +421,18 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   HIPCHK(hipSetDevice(c->dev));
   Fq rr;
   memcpy(rr.l, r, 32);
-  size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 1024);
+  size_t quarter = len / 4;
+  bool tiny = kind != 1 && quarter <= 8192;  // latency-bound rounds: one index per 8 lanes
+  size_t nblk = tiny ? (quarter + 31) / 32 : grid_for(quarter, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
   Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
-    if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
-    if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
-    if (kind == 2) hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
   }
   for (size_t k = 0; k < ntabs; k++) tabs[k]->len = len / 2;
   uint64_t e[12];
@@ -411,14 +460,18 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
   HIPCHK(hipEventRecord(c->side_ev, c->stream_side));
   Fq rr;
   memcpy(rr.l, r, 32);
-  size_t quarter = len / 4, nblk = quarter <= 256 ? 1 : grid_for(quarter, 1024);
+  size_t quarter = len / 4;
+  bool tiny = kind != 1 && quarter <= 8192;  // latency-bound rounds: one index per 8 lanes
+  size_t nblk = tiny ? (quarter + 31) / 32 : grid_for(quarter, 1024);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
   Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
-    if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
-    if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
-    if (kind == 2) hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
   }
   for (size_t k = 0; k < ntabs; k++) tabs[k]->len = len / 2;
   if (partials != (Fq*)hres(c)) {
