@@ -134,6 +134,34 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __re
   }
   if (threadIdx.x < 3) st_fq(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x, red[threadIdx.x][0]);
 }
+// Latency form of k_cubic_eval_batched (the first round of a layer's sum-check, half <= 8192): four lanes per index, lanes
+// 0..2 evaluate t = 0, 2, 3 with one instruction stream; block = 64 indices; grid (nblk, ninst).
+__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, size_t half, Fq* __restrict__ partials) {
+  __shared__ Fq red[3][64];
+  Triple t = T[blockIdx.y];
+  int li = threadIdx.x >> 2, role = threadIdx.x & 3;
+  size_t i = (size_t)blockIdx.x * 64 + li;
+  Fq e = fq_zero();
+  if (role < 3 && i < half) {
+    Fq pt[3];
+    const Fq* ptr[3] = {t.a, t.b, t.c};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      Fq x0 = ld_fq(ptr[k] + i), x1 = ld_fq(ptr[k] + half + i);
+      Fq x2 = fq_sub(fq_dbl(x1), x0), x3 = fq_sub(fq_add(x2, x1), x0);
+#pragma unroll
+      for (int w = 0; w < 4; w++) pt[k].l[w] = role == 0 ? x0.l[w] : (role == 1 ? x2.l[w] : x3.l[w]);
+    }
+    e = fq_mul(fq_mul(pt[0], pt[1]), pt[2]);
+  }
+  if (role < 3) red[role][li] = e;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (role < 3 && li < s) red[role][li] = fq_add(red[role][li], red[role][li + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) st_fq(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x, red[threadIdx.x][0]);
+}
 // partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
 __global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
   __shared__ Fq sm[256];
@@ -319,12 +347,15 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   size_t len;
   HIPCHK(hipSetDevice(c ? c->dev : 0));
   SPCHK(batched_setup(c, A, B, C, ninst, &len, false));
-  size_t half = len / 2, nblk = half <= 256 ? 1 : grid_for(half, 256);
+  size_t half = len / 2;
+  bool tiny = half <= 8192;
+  size_t nblk = tiny ? (half + 63) / 64 : grid_for(half, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
   Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst);
-    hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
+    if (tiny) hipLaunchKernelGGL(k_cubic_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
+    else hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
   }
   return batched_finish(c, partials, nblk, ninst, out);
 }
