@@ -36,11 +36,12 @@ __device__ __forceinline__ Fq ipa_b(const Fq* __restrict__ b, size_t x, size_t n
 __device__ __forceinline__ Fq ipa_s(const Fq* __restrict__ s, size_t p, int fold, const Fq& u, const Fq& u_inv) {
   return fold ? fq_mul(ld_fq(s + p / 2), (p & 1) ? u : u_inv) : ld_fq(s + p);  // s'[2p] = s[p] u^-1, s'[2p+1] = s[p] u
 }
-__global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
+// 512-thread blocks: the extra block folds and multiplies up to 2048 entries, 4 + 2 per thread instead of 8 + 4 (1024 threads would spill).
+__global__ void __launch_bounds__(512) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
                                                      size_t n0, size_t g_off, uint32_t q_idx, uint32_t h_idx, Fq q_scale, Fq blind_L, Fq blind_R,
                                                      Fq* __restrict__ rows, uint32_t* __restrict__ idx_lr, int fold, Fq u, Fq u_inv,
                                                      Fq* __restrict__ a_new, Fq* __restrict__ b_new, Fq* __restrict__ s_new) {
-  __shared__ Fq sm[256];
+  __shared__ Fq sm[2][512];
   size_t h = n_cur / 2, m = n0 / 2 + 2;
   if (blockIdx.x + 1 < gridDim.x) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,20 +57,31 @@ __global__ void __launch_bounds__(256) k_ipa_prepare(const Fq* __restrict__ a, c
   }
   const Fq *ac = a, *bc = b;
   if (fold) {
-    for (size_t i = threadIdx.x; i < n_cur; i += 256) {
+    for (size_t i = threadIdx.x; i < n_cur; i += blockDim.x) {
       st_fq(a_new + i, ipa_a(a, i, n_cur, 1, u, u_inv));
       st_fq(b_new + i, ipa_b(b, i, n_cur, 1, u, u_inv));
     }
-    for (size_t p = threadIdx.x; p < n0 / n_cur; p += 256) st_fq(s_new + p, ipa_s(s, p, 1, u, u_inv));
+    for (size_t p = threadIdx.x; p < n0 / n_cur; p += blockDim.x) st_fq(s_new + p, ipa_s(s, p, 1, u, u_inv));
     __syncthreads();  // this block reads back what it has just written
     ac = a_new; bc = b_new;
   }
   Fq c[2] = {fq_zero(), fq_zero()};
-  for (size_t i = threadIdx.x; i < h; i += 256) {
+  for (size_t i = threadIdx.x; i < h; i += blockDim.x) {
     c[0] = fq_add(c[0], fq_mul(ld_fq(ac + i), ld_fq(bc + h + i)));  // c_L = <a_L, b_R>  (bullet.rs:80)
     c[1] = fq_add(c[1], fq_mul(ld_fq(ac + h + i), ld_fq(bc + i)));  // c_R = <a_R, b_L>  (bullet.rs:81)
   }
-  block_sum_fq<2>(c, sm);
+  sm[0][threadIdx.x] = c[0];
+  sm[1][threadIdx.x] = c[1];
+  __syncthreads();
+  for (unsigned st = blockDim.x / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      sm[0][threadIdx.x] = fq_add(sm[0][threadIdx.x], sm[0][threadIdx.x + st]);
+      sm[1][threadIdx.x] = fq_add(sm[1][threadIdx.x], sm[1][threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  c[0] = sm[0][0];
+  c[1] = sm[1][0];
   if (threadIdx.x == 0) {
     size_t t = n0 / 2;
     st_fq(rows + t, fq_mul(c[0], q_scale));
@@ -160,7 +172,7 @@ int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t b
   HIPCHK(hipSetDevice(c->dev));
   {
     ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);
-    hipLaunchKernelGGL(k_ipa_prepare, dim3((unsigned)((ipa->n0 + 255) / 256 + 1)), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
+    hipLaunchKernelGGL(k_ipa_prepare, dim3((unsigned)((ipa->n0 + 511) / 512 + 1)), dim3(512), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
                        ipa->n0, ipa->g_off, (uint32_t)ipa->q_idx, (uint32_t)ipa->h_idx, ipa->q_scale, limbs(blind_L), limbs(blind_R), ipa->rows,
                        ipa->idx_lr, ipa->fold_pending ? 1 : 0, ipa->fu, ipa->fu_inv, ipa->a2, ipa->b2, ipa->s2);
   }
