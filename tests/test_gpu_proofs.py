@@ -117,9 +117,9 @@ def test_instance_new_matches_synthetic_and_rejects_bad_input(P, ctx, orc):
     gens.free(); inst.free(); ref.free(); orc.orc_instance_free(oi)
 
 
-@pytest.mark.parametrize("s", [16, 20])
+@pytest.mark.parametrize("s", [16, 20, 22])
 def test_snark_full_size_properties(P, ctx, orc, s):
-    """BASELINE sizes (configs[1] 2^16, configs[2] 2^20), where the oracle prover is too slow to run in a test:
+    """BASELINE sizes (configs[1] 2^16, configs[2] 2^20, configs[4] 2^22), where the oracle prover is too slow to run in a test:
     size-independent properties — README proof lengths, determinism, and the oracle's restated VERIFIER accepts the
     GPU proof bytes against the GPU computation commitment (and rejects a corrupted proof)."""
     N = 1 << s
