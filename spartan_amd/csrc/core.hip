@@ -776,6 +776,7 @@ struct sp_job {
   uint8_t* scratch;
   size_t scratch_bytes, rows, out_off;
   hipEvent_t done;
+  hipStream_t stream;  // the stream the job runs on (background, or the main stream for sp_commit_rows_dev_start)
 };
 int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
                                  sp_job** out) {
@@ -784,7 +785,7 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
   MsmPlan m = msm_plan(rows, cols, false);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
-  j->ctx = c; j->rows = rows; j->scratch = nullptr;
+  j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream_bg;
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   j->out_off = m.part_bytes + m.part2_bytes;
   j->scratch_bytes = j->out_off + out_al + sizeof(Pt) * rows;
@@ -805,6 +806,38 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
   *out = j;
   return SP_OK;
 }
+// Foreground variant: the commit (with blinds) is queued on the MAIN stream at full width and the call returns; the caller
+// may do host work (it must not make another call on this context) until sp_job_wait. Used to hash the computation
+// commitment into the transcript (0.65 ms of Keccak at 2^20) while the witness commitment is being computed.
+int32_t sp_commit_rows_dev_start(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
+                                 const uint64_t* blinds, sp_job** out) {
+  if (!c || !g || !Z || !out || rows <= SP_HOST_ENCODE_ROWS || cols == 0 || g_off + cols > g->n || (blinds && h_idx >= g->n) ||
+      z_off + rows * cols > Z->cap)
+    return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  const Fq* dbl = nullptr;
+  if (blinds) {
+    SPCHK(ensure_dstage(c, 32 * rows));
+    SPCHK(stage_in(c, 0, blinds, 32 * rows));
+    dbl = (const Fq*)c->dstage;
+  }
+  MsmPlan m = msm_plan(rows, cols, blinds != nullptr);
+  sp_job* j = new (std::nothrow) sp_job();
+  if (!j) return SP_ENOMEM;
+  j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream;
+  size_t out_al = (32 * rows + 255) & ~(size_t)255;
+  j->out_off = m.part_bytes + m.part2_bytes;
+  j->scratch_bytes = j->out_off + out_al + sizeof(Pt) * rows;
+  int32_t rc = pool_alloc(c, j->scratch_bytes, (void**)&j->scratch);
+  if (rc != SP_OK) { delete j; return rc; }
+  if (hipEventCreateWithFlags(&j->done, hipEventDisableTiming) != hipSuccess) { pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  msm_enqueue(c, c->stream, true, m, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, dbl, h_idx, j->scratch, j->scratch + j->out_off, true,
+              j->scratch + j->out_off + out_al);
+  (void)hipEventRecord(j->done, c->stream);
+  if (hipGetLastError() != hipSuccess) { (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  *out = j;
+  return SP_OK;
+}
 int32_t sp_job_wait(sp_job* j, uint8_t* out) {
   if (!j || !out) return SP_EINVAL;
   sp_ctx* c = j->ctx;
@@ -816,8 +849,8 @@ int32_t sp_job_wait(sp_job* j, uint8_t* out) {
     if (e != hipErrorNotReady) { rc = SP_EHIP; break; }
   }
   if (rc == SP_OK) {
-    if (hipMemcpyAsync(out, j->scratch + j->out_off, 32 * j->rows, hipMemcpyDeviceToHost, c->stream_bg) != hipSuccess ||
-        hipStreamSynchronize(c->stream_bg) != hipSuccess)
+    if (hipMemcpyAsync(out, j->scratch + j->out_off, 32 * j->rows, hipMemcpyDeviceToHost, j->stream) != hipSuccess ||
+        hipStreamSynchronize(j->stream) != hipSuccess)
       rc = SP_EHIP;
   }
   // the scratch goes back to the pool, which hands it to main-stream work: make that work wait for the job

@@ -684,19 +684,42 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
 // on_rx: called as soon as the first sum-check has fixed rx (SNARK::prove starts work that only depends on rx there)
 static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& input, const R1CSGens& gens,
                             Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm,
-                            const std::function<void(const FqVec&)>* on_rx = nullptr) { HSPAN("r1cs_prove");
+                            const std::function<void(const FqVec&)>* on_rx = nullptr,
+                            const std::function<void()>* transcript_prefix = nullptr) { HSPAN("r1cs_prove");
   double t0 = now_s();
-  t.append_protocol_name("R1CS proof");
   // lib.rs:360-368 / 519-526: the assignment is zero-padded to the instance's (padded) num_vars — done in the device table
   REQUIRE(nvars_given <= inst.num_vars && input.size() < inst.num_vars && input.size() == inst.num_inputs);
-  t.append_scalars("input", input);
   R1CSProof P;
   size_t num_vars = inst.num_vars, lv = log_2(num_vars);
-  // polycommit (:160-171)
+  // polycommit (:160-171). The witness commitment does not depend on the transcript: it is started first, and everything
+  // the transcript has to absorb BEFORE it (the caller's prefix — for a SNARK the 6144 shares of the computation
+  // commitment — and the inputs) is hashed while the GPU computes; the order of the transcript operations is the reference's.
   DevTable poly_vars = tab_alloc(c, num_vars);  // zero-filled: implicit padding
   if (nvars_given) SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
   FqVec blinds_vars = tape.random_vector("poly_blinds", pow2(lv / 2));
-  P.comm_vars = poly_commit(c, poly_vars, lv, gens.gens_pc, &blinds_vars);
+  {
+    size_t Ls = pow2(lv / 2), Rs = pow2(lv - lv / 2);
+    const MultiCommitGens& g = gens.gens_pc.gens.gens_n;
+    sp_job* job = nullptr;
+    bool async = Ls > 8 && !commit_shard_active(c) && g.n() == Rs;
+    if (async) SPX(sp_commit_rows_dev_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, Ls, Rs, U(blinds_vars), &job));
+    try {
+      if (transcript_prefix) (*transcript_prefix)();
+      t.append_protocol_name("R1CS proof");
+      t.append_scalars("input", input);
+    } catch (...) {
+      if (job) { std::vector<uint8_t> sink(32 * Ls); (void)sp_job_wait(job, sink.data()); }
+      throw;
+    }
+    if (async) {
+      std::vector<uint8_t> out(32 * Ls);
+      SPX(sp_job_wait(job, out.data()));
+      P.comm_vars.C.resize(Ls);
+      for (size_t i = 0; i < Ls; i++) P.comm_vars.C[i] = to_cp(&out[32 * i]);
+    } else {
+      P.comm_vars = poly_commit(c, poly_vars, lv, gens.gens_pc, &blinds_vars);
+    }
+  }
   append_poly_commitment(t, "poly_commitment", P.comm_vars);
   if (tm) tm->polycommit = now_s() - t0;
 
@@ -786,10 +809,12 @@ NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_gi
                  const Fq& tape_seed, ProveTimes* tm) {  // lib.rs:501-546
   double t0 = now_s();
   RandomTape tape("proof", tape_seed);
-  t.append_protocol_name("Spartan NIZK proof");
-  t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());
+  std::function<void()> prefix = [&]() {
+    t.append_protocol_name("Spartan NIZK proof");
+    t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());
+  };
   NIZK P;
-  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, vars, nvars_given, inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm);
+  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, vars, nvars_given, inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm, nullptr, &prefix);
   if (tm) tm->total = now_s() - t0;
   return P;
 }
