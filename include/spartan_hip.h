@@ -125,6 +125,9 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* ctx, int kind, sp_table* const* tab
                                      const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out_points);
 /* DensePolynomial::bound (dense_mlpoly.rs:206-213): out[i] = sum_j L[j]*Z[j*R+i], Z viewed as Lsz x (len/Lsz). */
 int32_t sp_vecmat(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z, uint64_t* out);
+/* The same with the result left on the device as a new table (PolyEvalProof::prove only commits to it and feeds it to the
+ * inner-product argument: it never has to visit the host). */
+int32_t sp_vecmat_dev(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z, sp_table** out);
 /* compute_dotproduct / inner_product (nizk/mod.rs:435-438, bullet.rs:233-243) over n elements. */
 int32_t sp_dot(sp_ctx* ctx, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]);
 /* DensePolynomial::evaluate (dense_mlpoly.rs:236-242): <Z, chi(r)> with chi generated on the device. */
@@ -159,6 +162,12 @@ int32_t sp_sparse_evaluate(sp_ctx* ctx, const sp_sparse* m, const sp_table* tx, 
 typedef struct sp_ipa sp_ipa;
 int32_t sp_ipa_begin(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
                      const uint64_t* a /*4*n*/, const uint64_t* b /*4*n*/, sp_ipa** out);
+/* DotProductProofLog::prove (nizk/mod.rs:440-480) with x already on the device: a = the first n entries of a_dev, and
+ * commit_a = compress(<a, G> + blind_a * H) (its Cx) is computed from the same device copy. The scale of Q (= the
+ * challenge r drawn AFTER Cx is absorbed) is set afterwards with sp_ipa_set_scale, before the first round. */
+int32_t sp_ipa_begin_dev(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const sp_table* a_dev, const uint64_t* b,
+                         const uint64_t blind_a[4], uint8_t commit_a[32], sp_ipa** out);
+int32_t sp_ipa_set_scale(sp_ipa* ipa, const uint64_t q_scale[4]);
 /* bullet.rs:72-100: c_L, c_R, L = <a_L,G_R> + c_L Q + blind_L H, R = <a_R,G_L> + c_R Q + blind_R H, compressed. */
 int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]);
 /* bullet.rs:105-109: fold a, b (and the generator coefficients s) with the round challenge. */

@@ -513,6 +513,27 @@ int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, u
   SPCHK(fetch_out(c, dres, out, 32 * R));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
+int32_t sp_vecmat_dev(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, sp_table** out) {
+  if (!c || !L || !Z || !out || Lsz == 0 || Z->len % Lsz) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t R = Z->len / Lsz;
+  SPCHK(ensure_dstage(c, 32 * Lsz));
+  SPCHK(stage_in(c, 0, L, 32 * Lsz));
+  size_t nchunks = Lsz < 64 ? 1 : 64;
+  while (nchunks > 1 && (R / 256 + 1) * nchunks > 4096) nchunks /= 2;
+  size_t jchunk = (Lsz + nchunks - 1) / nchunks;
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nchunks * R + R)));
+  SPCHK(table_new(c, R, false, out));
+  Fq* partial = (Fq*)c->scratch;
+  {
+    ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R);
+    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 255) / 256), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
+                       (const Fq*)Z->d, R, jchunk, partial);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, (*out)->d);
+  }
+  SPCHK(sync_spin(c));  // the staging buffers behind L are reusable
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
 int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]) {
   if (!c || !a || !b || !out || n == 0 || a_off + n > a->cap || b_off + n > b->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));

@@ -129,14 +129,19 @@ void sp_ipa_free(sp_ipa* ipa) {
   pool_release(ipa->ctx, ipa->base, ipa->bytes);  // one allocation backs a, b, a2, b2, s, s2, rows, idx
   delete ipa;
 }
-int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
-                     const uint64_t* a, const uint64_t* b, sp_ipa** out) {
-  if (!c || !g || !q_scale || !a || !b || !out || !is_pow2(n) || g_off + n > g->n || q_idx >= g->n || h_idx >= g->n) return SP_EINVAL;
+// a: host vector, or (a_dev != nullptr) the first n entries of a device table. commit_a != nullptr: also returns
+// commit(a, blind_a) over the same generators (the Cx of DotProductProofLog::prove, nizk/mod.rs:469) computed from the
+// device copy — the vector is uploaded once for both uses.
+static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t* q_scale, const uint64_t* a,
+                         const sp_table* a_dev, const uint64_t* b, const uint64_t* blind_a, uint8_t* commit_a, sp_ipa** out) {
+  if (!c || !g || (!a && !a_dev) || !b || !out || !is_pow2(n) || g_off + n > g->n || q_idx >= g->n || h_idx >= g->n) return SP_EINVAL;
+  if (a_dev && a_dev->cap < n) return SP_EINVAL;
+  if (commit_a && !blind_a) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   sp_ipa* ipa = new (std::nothrow) sp_ipa();
   if (!ipa) return SP_ENOMEM;
   ipa->ctx = c; ipa->g = g; ipa->n0 = ipa->n_cur = n; ipa->g_off = g_off; ipa->q_idx = q_idx; ipa->h_idx = h_idx;
-  ipa->q_scale = limbs(q_scale);
+  ipa->q_scale = q_scale ? limbs(q_scale) : fq_one();
   size_t fq_count = 6 * n + 2 * (n + 2);
   uint8_t* base = nullptr;
   ipa->bytes = 32 * fq_count + 4 * (n + 2) + 4 * (n + 4);
@@ -155,15 +160,39 @@ int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t
   idx[n] = (uint32_t)q_idx;
   idx[n + 1] = (uint32_t)h_idx;
   Fq one = fq_one();
-  if (hipMemcpyAsync(ipa->a, a, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(ipa->b, b, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+  hipError_t e = a_dev ? hipMemcpyAsync(ipa->a, a_dev->d, 32 * n, hipMemcpyDeviceToDevice, c->stream)
+                       : hipMemcpyAsync(ipa->a, a, 32 * n, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess || hipMemcpyAsync(ipa->b, b, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
       hipMemcpyAsync(ipa->s, &one, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipStreamSynchronize(c->stream) != hipSuccess) {
+      hipMemcpyAsync(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
     sp_ipa_free(ipa);
     return SP_EHIP;
   }
+  int32_t rc = SP_OK;
+  if (commit_a) {  // waits for the stream: the host buffers above are released too
+    rc = ensure_dstage(c, 32);
+    if (rc == SP_OK) rc = stage_in(c, 0, blind_a, 32);
+    if (rc == SP_OK) rc = msm_launch(c, g, ipa->a, n, 1, n, g_off, nullptr, (const Fq*)c->dstage, h_idx, commit_a);
+  } else if (hipStreamSynchronize(c->stream) != hipSuccess) {
+    rc = SP_EHIP;
+  }
+  if (rc != SP_OK) { sp_ipa_free(ipa); return rc; }
   *out = ipa;
+  return SP_OK;
+}
+int32_t sp_ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const uint64_t q_scale[4],
+                     const uint64_t* a, const uint64_t* b, sp_ipa** out) {
+  if (!q_scale || !a) return SP_EINVAL;
+  return ipa_begin(c, g, g_off, n, q_idx, h_idx, q_scale, a, nullptr, b, nullptr, nullptr, out);
+}
+int32_t sp_ipa_begin_dev(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, size_t q_idx, size_t h_idx, const sp_table* a_dev, const uint64_t* b,
+                         const uint64_t blind_a[4], uint8_t commit_a[32], sp_ipa** out) {
+  if (!a_dev || !blind_a || !commit_a) return SP_EINVAL;
+  return ipa_begin(c, g, g_off, n, q_idx, h_idx, nullptr, nullptr, a_dev, b, blind_a, commit_a, out);
+}
+int32_t sp_ipa_set_scale(sp_ipa* ipa, const uint64_t q_scale[4]) {
+  if (!ipa || !q_scale) return SP_EINVAL;
+  ipa->q_scale = limbs(q_scale);
   return SP_OK;
 }
 int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {

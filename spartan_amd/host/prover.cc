@@ -330,21 +330,6 @@ static CP commit_scalar(sp_ctx* c, const Fq& x, const Fq& blind, const MultiComm
   REQUIRE(g1.n() == 1);
   return msm_rows(c, g1.g, {g1.G[0], g1.h}, {x, blind}, 1)[0];
 }
-static CP commit_vec(sp_ctx* c, const FqVec& v, const Fq& blind, const MultiCommitGens& gn) {  // [Scalar]::commit :80-92
-  REQUIRE(gn.n() == v.size());
-  bool contiguous = true;
-  for (size_t i = 0; i < gn.G.size(); i++) contiguous = contiguous && gn.G[i] == gn.G[0] + i;
-  if (contiguous && v.size() >= 64) {
-    uint8_t out[32];
-    SPX(sp_commit_rows(c, gn.g, gn.G[0], gn.h, U(v), 1, v.size(), U(blind), out));
-    return to_cp(out);
-  }
-  std::vector<uint32_t> idx = gn.G;
-  idx.push_back(gn.h);
-  FqVec s = v;
-  s.push_back(blind);
-  return msm_rows(c, gn.g, idx, s, 1)[0];
-}
 // DensePolynomial::commit (dense_mlpoly.rs:179-204): L row commitments of the R-wide rows of a device table
 static PolyCommitment poly_commit(sp_ctx* c, const DevTable& Z, size_t num_vars, const PolyCommitmentGens& gens, const FqVec* blinds) { HSPAN("poly_commit");
   size_t Ls = pow2(num_vars / 2), Rs = pow2(num_vars - num_vars / 2);
@@ -602,10 +587,12 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
 }
 
 // ------------------------------------------------------------------ DotProductProofLog (nizk/mod.rs:440-525) + bullet.rs:32-132
-static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGens& gens, Transcript& t, RandomTape& tape, const FqVec& x,
+// x lives on the device (it is the bound polynomial LZ of PolyEvalProof::prove): it is committed to and handed to the
+// inner-product argument from there
+static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGens& gens, Transcript& t, RandomTape& tape, const DevTable& x,
                                               const Fq& blind_x, const FqVec& a, const Fq& y, const Fq& blind_y, CP* Cy_out) { HSPAN("dotproductlog_prove");
   t.append_protocol_name("dot product proof (log)");
-  size_t n = x.size();
+  size_t n = x.len();
   REQUIRE(a.size() == n && gens.n == n);
   Fq d = tape.random_scalar("d");
   Fq r_delta = tape.random_scalar("r_delta");
@@ -613,19 +600,23 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
   size_t lg_n = log_2(n);
   FqVec v1 = tape.random_vector("blinds_vec_1", lg_n), v2 = tape.random_vector("blinds_vec_2", lg_n);
   const MultiCommitGens &gn = gens.gens_n, &g1 = gens.gens_1;
-  CP Cx = commit_vec(c, x, blind_x, gn);
-  t.append_point("Cx", Cx.data());
-  CP Cy = commit_scalar(c, y, blind_y, g1);
-  t.append_point("Cy", Cy.data());
-  t.append_scalars("a", a);
-  Fq r = t.challenge_scalar("r");
-  Fq blind_Gamma = blind_x + r * blind_y;
-  // BulletReductionProof::prove with Q = r*G1 (gens_1.scale(r), nizk/mod.rs:479-480), H = h
+  for (size_t i = 0; i < gn.G.size(); i++) REQUIRE(gn.G[i] == gn.G[0] + i);  // one contiguous run of the generator stream
+  // Cx = commit(x, blind_x) and the argument's device state from one copy of x; BulletReductionProof::prove runs with
+  // Q = r*G1 (gens_1.scale(r), nizk/mod.rs:479-480) and H = h, r being drawn below
   sp_ipa* ipa = nullptr;
-  SPX(sp_ipa_begin(c, gn.g, gn.G[0], n, g1.G[0], gn.h, U(r), U(x), U(a), &ipa));
+  CP Cx;
+  SPX(sp_ipa_begin_dev(c, gn.g, gn.G[0], n, g1.G[0], gn.h, x.h, U(a), U(blind_x), Cx.data(), &ipa));
   DotProductProofLog p;
-  Fq blind_hat = blind_Gamma;
+  Fq blind_hat, r;
+  CP Cy;
   try {
+    t.append_point("Cx", Cx.data());
+    Cy = commit_scalar(c, y, blind_y, g1);
+    t.append_point("Cy", Cy.data());
+    t.append_scalars("a", a);
+    r = t.challenge_scalar("r");
+    SPX(sp_ipa_set_scale(ipa, U(r)));
+    blind_hat = blind_x + r * blind_y;  // blind_Gamma
     for (size_t k = 0; k < lg_n; k++) {
       CP L, R;
       SPX(sp_ipa_round_lr(ipa, U(v1[k]), U(v2[k]), L.data(), R.data()));
@@ -667,8 +658,9 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
   REQUIRE(poly.len() == Ls * Rs);
   FqVec Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
   FqVec Rv = eq_evals_host(FqVec(r.begin() + r.size() / 2, r.end()));
-  FqVec LZ(Rs);
-  SPX(sp_vecmat(c, U(Lv), Ls, poly.h, U(LZ)));  // DensePolynomial::bound :349
+  sp_table* lz = nullptr;
+  SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device
+  DevTable LZ(c, lz);
   Fq LZ_blind = fq_zero();
   if (blinds_opt) {
     REQUIRE(blinds_opt->size() == Ls);
