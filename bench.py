@@ -41,7 +41,12 @@ def dist_setup(n_gpus):
 
 
 def dist_barrier(dist):
-    if dist is not None:
+    if dist is None:
+        return
+    if dist.get_backend() == "nccl":  # name the device: RCCL otherwise guesses it from the rank
+        import torch
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
         dist.barrier()
 
 
