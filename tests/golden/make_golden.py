@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from tests.helpers import load_oracle, sz, vp, u64x4, gens_bytes
 
-CASES = {"nizk": [(4, 2), (7, 3)], "snark": [(3, 1), (5, 2), (8, 3)]}  # (log2 size, seed)
+CASES = {"nizk": [(4, 2), (7, 3), (12, 5)], "snark": [(3, 1), (5, 2), (8, 3), (12, 4), (15, 5)]}  # (log2 size, seed)
 
 
 def proof_bytes(orc, p):
