@@ -5,7 +5,8 @@
 // Parity status: the reference's tests pin no commitment/challenge/proof byte; the oracle
 // is pinned on (i) the F_q known answers of scalar/ristretto255.rs tests, (ii) RFC 9496 / libsodium for the
 // group, (iii) the Merlin test vector + hashlib for the transcript, (iv) README.md:362,371,374 proof lengths,
-// (v) its restated verifier accepting its own proofs. Against real libspartan bytes it is "parity unpinned"
+// (v) the known answers of unipoly.rs:127-183 and dense_mlpoly.rs:433-452, (vi) its restated verifier accepting its own
+// proofs (and those of the HIP path up to 2^22 constraints). Against real libspartan bytes it is "parity unpinned"
 // (no Rust toolchain in this environment).
 #pragma once
 #include <array>
