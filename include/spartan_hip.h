@@ -213,6 +213,25 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* cons
  * once, out of place. Requires current length >= 4. */
 int32_t sp_sumcheck_bind_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst,
                                       const uint64_t r[4], uint64_t* out);
+/* Resident form of the two calls above for the latency-bound tail of a sum-check (tables of a few thousand entries and
+ * less: ~330 of the ~400 batched rounds of a 2^20 proof). ONE kernel stays on the device for all remaining rounds; each
+ * round is a mailbox exchange (the challenge goes in, the 3*ninst evaluations come out) instead of a launch plus a
+ * completion wait — the transcript stays with the caller. Same arithmetic, same table contents afterwards.
+ *   begin : tables as for sp_sumcheck_eval_batched (equal current length >= 2). first_eval != 0: also evaluates the
+ *           round on the tables as they are -> out_evals[12*ninst] (what sp_sumcheck_eval_batched returns).
+ *   round : sp_sumcheck_bind_eval_batched at r (current length >= 4).
+ *   finish: the last round, current length 2: binds every table at r and returns the remaining entries,
+ *           out_heads = A_0, B_0, A_1, B_1, ..., then each distinct C table in order of first appearance
+ *           (sp_table_bind_top_heads on that list). Ends the session and frees it, also on error.
+ *   abort : ends a session early (error paths); the tables hold the state after the last completed round.
+ * Between begin and finish/abort no other call may be made on the context. A session that hears nothing from its
+ * caller for 2 s ends by itself. */
+typedef struct sp_session sp_session;
+int32_t sp_sumcheck_session_begin(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int first_eval,
+                                  uint64_t* out_evals, sp_session** out);
+int32_t sp_sumcheck_session_round(sp_session* s, const uint64_t r[4], uint64_t* out_evals);
+int32_t sp_sumcheck_session_finish(sp_session* s, const uint64_t r[4], uint64_t* out_heads);
+void sp_sumcheck_session_abort(sp_session* s);
 /* out[k] = <chi, T_k> for k < nt (the ~23 DensePolynomial::evaluate calls of HashLayerProof::prove share chi). */
 int32_t sp_dot_many(sp_ctx* ctx, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out /*4*nt*/);
 /* DotProductCircuit::evaluate (product_tree.rs:84-88): sum l[i]*r[i]*w[i] over n elements from the given offsets. */

@@ -4,7 +4,7 @@
 #include <mutex>
 
 const char* kProfNames[PF_COUNT] = {"gens_table_build", "msm_rows_fixed", "msm_windows_fixed", "msm_reduce_pass", "msm_reduce_compress", "eq_expand", "sumcheck_eval",
-                                    "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "misc"};
+                                    "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "sumcheck_session", "misc"};
 
 int32_t ensure(void** p, size_t* cap, size_t need) {
   if (*cap >= need) return SP_OK;
@@ -453,6 +453,8 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->pinned = nullptr;
   c->pinned_cap = 0;
   c->hmap = nullptr;
+  c->sess_cmd = c->sess_slots = c->sess_dev = nullptr;
+  c->sess_seq = 0;
   c->done_flag = nullptr;
   c->sync_epoch = 0;
   c->eq_next = 0;
@@ -504,6 +506,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->dstage) (void)hipFree(c->dstage);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->hmap) (void)hipHostFree(c->hmap);
+  if (c->sess_cmd) (void)hipHostFree(c->sess_cmd);
+  if (c->sess_slots) (void)hipHostFree(c->sess_slots);
+  if (c->sess_dev) (void)hipFree(c->sess_dev);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
   if (c->side_ev) (void)hipEventDestroy(c->side_ev);

@@ -33,6 +33,7 @@ enum ProfFamily {
   PF_SPARSE,
   PF_IPA,
   PF_SPARK,
+  PF_SESSION,
   PF_MISC,
   PF_COUNT
 };
@@ -70,6 +71,13 @@ struct sp_ctx {
   volatile uint32_t* done_flag;
   uint32_t done_seq;
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
+
+  // resident sum-check sessions (session.hip): command mailbox + per-workgroup result slots in coherent host memory, the
+  // republished command in device memory; sess_seq numbers every command of the context's lifetime
+  void* sess_cmd;
+  void* sess_slots;
+  void* sess_dev;
+  uint64_t sess_seq;
 
   // size-class pool of device buffers: per-proof tables are recycled instead of hipMalloc/hipFree'd
   std::map<size_t, std::vector<void*>> pool;

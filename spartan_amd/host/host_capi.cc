@@ -51,11 +51,13 @@ void* spz_instance_new(void* ctx, size_t num_cons, size_t num_vars, size_t num_i
                        const uint64_t* cols, const uint8_t* vals) {
   return guard([&]() -> void* {
     std::vector<SparseEntry> m[3];
+    // lib.rs:164-186: an entry is checked for InvalidIndex first, then its scalar for InvalidScalar
     size_t off = 0;
     for (int k = 0; k < 3; k++)
       for (size_t i = 0; i < nnz[k]; i++, off++) {
         SparseEntry e;
         e.row = rows[off]; e.col = cols[off];
+        if (e.row >= num_cons || e.col >= num_vars + 1 + num_inputs) throw Error("InvalidIndex");
         sp::Fq raw;
         memcpy(raw.l, vals + 32 * off, 32);
         // Scalar::from_bytes (ristretto255.rs:390-416): reject encodings >= q
@@ -151,12 +153,12 @@ void* spz_snark_prove(void* ctx, void* inst, void* gens, void* enc, const uint64
                       const char* transcript_label, const uint64_t tape_seed[4], double* times10) {
   return guard([&]() -> void* {
     Transcript t(transcript_label);
-    Fq seed;
-    memcpy(seed.l, tape_seed, 32);
+    Fq seed;  // tape_seed == NULL: RandomTape::new, seeded from OS entropy (random.rs:13-15)
+    if (tape_seed) memcpy(seed.l, tape_seed, 32);
     ProveTimes tm;
     EncH* e = (EncH*)enc;
     SNARK p = SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(SNARKGens*)gens,
-                           t, seed, &tm);
+                           t, tape_seed ? &seed : nullptr, &tm);
     fill_times(tm, times10);
     ProofH* h = new ProofH;
     h->bytes = p.serialize();
@@ -168,9 +170,9 @@ void* spz_nizk_prove(void* ctx, void* inst, void* gens, const uint64_t* vars, si
   return guard([&]() -> void* {
     Transcript t(transcript_label);
     Fq seed;
-    memcpy(seed.l, tape_seed, 32);
+    if (tape_seed) memcpy(seed.l, tape_seed, 32);
     ProveTimes tm;
-    NIZK p = NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t, seed, &tm);
+    NIZK p = NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t, tape_seed ? &seed : nullptr, &tm);
     fill_times(tm, times10);
     ProofH* h = new ProofH;
     h->bytes = p.serialize();

@@ -109,7 +109,9 @@ struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the m
   size_t num_cons = 0, num_vars = 0, num_inputs = 0;
   std::vector<SparseEntry> A, B, C;
   sp_sparse *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  std::vector<uint8_t> digest;  // R1CSShapeDigest bytes (zlib(bincode(shape)) in the reference, r1cs.rs:154-158): opaque input
+  // R1CSShapeDigest bytes (zlib(bincode(shape)) in the reference, r1cs.rs:154-158): an opaque input the Rust side computes.
+  // NIZK::prove refuses to run without it (the transcript would not be bound to the shape, lib.rs:514).
+  std::vector<uint8_t> digest;
   // Instance::new (lib.rs:121-228): padding of num_cons / num_vars and the column shift are applied here.
   Instance(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const std::vector<SparseEntry>& A,
            const std::vector<SparseEntry>& B, const std::vector<SparseEntry>& C);
@@ -120,7 +122,8 @@ struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the m
   static std::unique_ptr<Instance> produce_synthetic_r1cs(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, uint64_t seed,
                                                           FqVec* vars, FqVec* inputs);
 };
-// from_bytes_wide(SHAKE256(domain || LE64(seed))[0..64]): the documented seed -> scalar map used for RandomTape seeds
+// TEST/BENCH ONLY: from_bytes_wide(SHAKE256(domain || LE64(seed))[0..64]), the documented seed -> scalar map behind the
+// reproducible RandomTape seeds of tests/ and bench.py. 64 bits of entropy: never a production tape seed.
 Fq seed_scalar(const char* domain, uint64_t seed);
 
 // ---- proof structs: field order == bincode order (same as the reference's serde derives) ----
@@ -213,27 +216,29 @@ struct SNARK {  // lib.rs:311-467
   SparseMatPolyEvalProof r1cs_eval_proof;
   // SNARK::encode (lib.rs:325-336)
   static void encode(Ctx& ctx, const Instance& inst, const SNARKGens& gens, ComputationCommitment* comm, ComputationDecommitment* decomm);
-  // SNARK::prove (lib.rs:339-420). `tape_seed` replaces the OsRng draw of RandomTape::new (random.rs:13-15).
+  // SNARK::prove (lib.rs:339-420). tape_seed == nullptr: the RandomTape is seeded from OS entropy like RandomTape::new
+  // (random.rs:13-15) — the production setting. A non-null seed is the `new_with_seed` test hook: it determines every blind,
+  // so it must be secret, >= 256 bits of entropy and single-use, or the proof is no longer zero-knowledge.
   static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
-                     const FqVec& vars, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript, const Fq& tape_seed,
+                     const FqVec& vars, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript, const Fq* tape_seed,
                      ProveTimes* times = nullptr) {
     return prove(ctx, inst, comm, decomm, vars.data(), vars.size(), inputs, gens, transcript, tape_seed, times);
   }
   // same, reading the assignment in place (a Rust `&[Scalar]` / a caller-owned buffer): no host-side copy
   static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
                      const Fq* vars, size_t num_vars_given, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript,
-                     const Fq& tape_seed, ProveTimes* times = nullptr);
+                     const Fq* tape_seed, ProveTimes* times = nullptr);
   std::vector<uint8_t> serialize() const;  // bincode 1.3 default encoding
 };
 struct NIZK {  // lib.rs:488-587
   R1CSProof r1cs_sat_proof;
   FqVec rx, ry;
   static NIZK prove(Ctx& ctx, const Instance& inst, const FqVec& vars, const FqVec& inputs, const NIZKGens& gens, Transcript& transcript,
-                    const Fq& tape_seed, ProveTimes* times = nullptr) {
+                    const Fq* tape_seed, ProveTimes* times = nullptr) {
     return prove(ctx, inst, vars.data(), vars.size(), inputs, gens, transcript, tape_seed, times);
   }
   static NIZK prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t num_vars_given, const FqVec& inputs, const NIZKGens& gens,
-                    Transcript& transcript, const Fq& tape_seed, ProveTimes* times = nullptr);
+                    Transcript& transcript, const Fq* tape_seed, ProveTimes* times = nullptr);
   std::vector<uint8_t> serialize() const;
 };
 

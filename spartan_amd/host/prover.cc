@@ -251,7 +251,12 @@ Instance::Instance(Ctx& ctx, size_t nc, size_t nv, size_t ni, const std::vector<
     for (size_t i = 0; i < m.size(); i++) { r[i] = m[i].row; cc[i] = m[i].col; v[i] = m[i].val; }
     SPX(sp_sparse_upload(c, r.data(), cc.data(), U(v), m.size(), num_cons, 2 * num_vars, d));
   };
-  up(A, &dA); up(B, &dB); up(C, &dC);
+  try {
+    up(A, &dA); up(B, &dB); up(C, &dC);
+  } catch (...) {  // a constructor that throws gets no destructor call: release what was uploaded
+    sp_sparse_free(dA); sp_sparse_free(dB); sp_sparse_free(dC);
+    throw;
+  }
 }
 Instance::~Instance() { sp_sparse_free(dA); sp_sparse_free(dB); sp_sparse_free(dC); }
 
@@ -798,9 +803,10 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
 }
 
 NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& inputs, const NIZKGens& gens, Transcript& t,
-                 const Fq& tape_seed, ProveTimes* tm) {  // lib.rs:501-546
+                 const Fq* tape_seed, ProveTimes* tm) {  // lib.rs:501-546
   double t0 = now_s();
-  RandomTape tape("proof", tape_seed);
+  REQUIRE(!inst.digest.empty());  // lib.rs:514 absorbs inst.digest: an empty one would leave the proof unbound to the shape
+  RandomTape tape = tape_seed ? RandomTape("proof", *tape_seed) : RandomTape("proof");  // random.rs:11-18
   std::function<void()> prefix = [&]() {
     t.append_protocol_name("Spartan NIZK proof");
     t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());

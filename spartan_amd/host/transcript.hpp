@@ -3,9 +3,13 @@
 // over Merlin 1.0 (STROBE-128 / Keccak-f[1600]); SHAKE256 for MultiCommitGens::new (src/commitments.rs:16-24).
 // The transcript stays on the host exactly as it stays in Rust in the drop-in design.
 #pragma once
+#include <sys/random.h>
+
+#include <cerrno>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -186,11 +190,30 @@ class Transcript {  // merlin::Transcript + libspartan's ProofTranscript trait
   Strobe128 s_;
 };
 
-// random.rs:10-28. The reference seeds from OsRng (random.rs:13-15); `new_with_seed` is the determinism hook
-// the parity contract needs on both sides.
+// random.rs:10-28. RandomTape::new seeds the tape with Scalar::random(&mut OsRng) (random.rs:13-15): the one-argument
+// constructor does the same (64 bytes from getrandom(2) -> from_bytes_wide), and is what the provers use when the caller
+// passes no seed. The seeded constructor is `new_with_seed`, the determinism hook the parity tests need on both sides
+// (SURVEY.md fact 1): a seed fixes every blind of the proof, so outside tests it must be secret, carry
+// >= 256 bits of entropy and never be used for two proofs — otherwise zero-knowledge is lost.
 class RandomTape {
  public:
+  explicit RandomTape(const char* name) : tape_(name) { tape_.append_scalar("init_randomness", os_random_scalar()); }
   RandomTape(const char* name, const Fq& seed) : tape_(name) { tape_.append_scalar("init_randomness", seed); }
+  static Fq os_random_scalar() {  // Scalar::random (ristretto255.rs:374-380) over the OS entropy source
+    uint8_t buf[64];
+    size_t got = 0;
+    while (got < sizeof buf) {
+      ssize_t n = getrandom(buf + got, sizeof buf - got, 0);
+      if (n < 0) {
+        if (errno == EINTR) continue;
+        throw std::runtime_error("getrandom failed: no OS entropy for the RandomTape");
+      }
+      got += (size_t)n;
+    }
+    uint64_t w[8];
+    memcpy(w, buf, 64);
+    return sp::fq_from_u512(w);
+  }
   Fq random_scalar(const char* label) { return tape_.challenge_scalar(label); }
   std::vector<Fq> random_vector(const char* label, size_t len) { return tape_.challenge_vector(label, len); }
 

@@ -106,6 +106,9 @@ class NIZKGens:
 
 
 def seed_scalar(domain, seed):
+    """TEST/BENCH ONLY: the reproducible 64-bit-seed -> scalar map behind the RandomTape seeds of tests/ and bench.py. A real
+    proof passes tape_seed=None (the tape is then seeded from OS entropy, like RandomTape::new, random.rs:13-15): a known or
+    reused seed fixes every blind of the proof and gives up zero-knowledge."""
     out = (ctypes.c_uint64 * 4)()
     H.spz_seed_scalar(domain, ctypes.c_uint64(seed), out)
     return out
@@ -163,23 +166,3 @@ class Encoded:
     def free(self):
         if self.h:
             H.spz_encode_free(self.h); self.h = None
-
-
-def smoke_check(orc):
-    """used by __graft_entry__.smoke(): SNARK::prove at 2^6 constraints on cuda:0, bytes compared with the oracle's."""
-    from tests import helpers as Hh
-    s = 6; N = 1 << s
-    ctx = Ctx(0)
-    inst = Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=3)
-    gens = SNARKGens(ctx, N, N, 10, N)
-    enc = SNARK.encode(ctx, inst, gens)
-    seed = seed_scalar(b"tape", 5)
-    got = SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", seed)
-    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(3)))
-    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
-    oe = vp(orc.orc_snark_encode(oi, og))
-    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", seed, None))
-    n = orc.orc_proof_bytes(op, None, sz(0)); b = (ctypes.c_uint8 * n)(); orc.orc_proof_bytes(op, b, sz(n))
-    assert got == bytes(b), "SNARK proof bytes differ from the oracle"
-    assert orc.orc_snark_verify(op, oi, og, oe, b"snark_example") == 1
-    enc.free(); gens.free(); inst.free(); ctx.close()

@@ -86,3 +86,25 @@ def gens_bytes(orc, n, label=b"gens_r1cs_sat"):
     buf = (ctypes.c_uint8 * (32 * (n + 1)))()
     orc.orc_multi_commit_gens(sz(n), label, buf)
     return bytes(buf)
+
+
+# ---- bulk conversions for the large-shape tests (2^17..2^20 scalars): one mul-mod + to_bytes per element
+def mont_bulk(vals):
+    """python ints -> ctypes uint64 array of Montgomery limbs (same layout as mont_array, ~10x faster)"""
+    raw = b"".join(((x % Q) * R % Q).to_bytes(32, "little") for x in vals)
+    return (ctypes.c_uint64 * (4 * len(vals))).from_buffer_copy(raw)
+
+
+def from_mont_bulk(arr, n):
+    raw = bytes(arr)[:32 * n]
+    out = []
+    for k in range(n):
+        m = int.from_bytes(raw[32 * k:32 * k + 32], "little")
+        assert m < Q
+        out.append(m * RINV % Q)
+    return out
+
+
+def fast_scalars(rng, n):
+    """n uniform scalars from one getrandbits call per element"""
+    return [rng.getrandbits(300) % Q for _ in range(n)]

@@ -61,10 +61,12 @@ def test_generator_tables_are_shared_between_contexts(orc):
 
 def test_gens_upload_rejects_bad_point(ctx, orc):
     from spartan_amd import capi
+    from tests.test_oracle_pins import RFC_BAD
     good = gens_bytes(orc, 3)
-    bad = good[:32] + bytes.fromhex("00ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff") + good[64:]
-    with pytest.raises(capi.SpartanHipError, match="-4"):
-        capi.Gens(ctx, compressed=bad)
+    for enc in RFC_BAD:   # every class of RFC 9496 A.2 invalid encodings is refused by the device decoder (k_points_load)
+        bad = good[:32] + bytes.fromhex(enc) + good[64:]
+        with pytest.raises(capi.SpartanHipError, match="-4"):
+            capi.Gens(ctx, compressed=bad)
 
 
 @pytest.mark.parametrize("rows,cols,kind,blind", [(1, 1, "uniform", False), (1, 5, "edge", True), (4, 8, "uniform", True), (32, 32, "uniform", True),

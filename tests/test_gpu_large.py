@@ -1,0 +1,409 @@
+"""Direct parity tests of the C-ABI entry points at the sizes where the THROUGHPUT launch plans are selected (the
+small-shape tests in test_gpu_kernels.py reach only the latency forms): >= 2^17 elements for the F_q streaming kernels
+(k_eq_outer, k_cubic_*_batched, k_sc_bind_eval, k_dot_many, k_dot3, k_spmv, k_eval_table, k_sparse_eval, k_hash_layer),
+n = 4096 for the inner-product argument, and the full 1024 x 1024 witness-sized commit on every row (k_msm_rows with the
+XCD tile order, and the persistent half-chip k_msm_rows_bg).
+
+Ground truth: the oracle where it exports the operation (orc_eq_evals, orc_sumcheck_eval, orc_bound_top, orc_commit_rows,
+orc_pt_msm), Python big integers restating the reference line by line elsewhere (each function cites it). Bit-exact."""
+import ctypes, random
+import pytest
+from tests.helpers import *
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from spartan_amd import capi
+    c = capi.Ctx(0)
+    yield c
+    c.close()
+
+
+def up(ctx, vals):
+    from spartan_amd import capi
+    return capi.Table.upload(ctx, mont_bulk(vals), len(vals))
+
+
+def fq1(x):
+    return mont_bulk([x])
+
+
+def test_eq_expand_long_table_matches_oracle(ctx, orc):
+    """EqPolynomial::evals (dense_mlpoly.rs:68-84) at ell = 17 and 18: the outer-product path (k_eq_outer)."""
+    from spartan_amd import capi
+    for ell in (14, 17, 18):
+        rng = random.Random(ell)
+        r = fast_scalars(rng, ell)
+        t = capi.Table.eq(ctx, mont_bulk(r), ell)
+        want = (ctypes.c_uint64 * (4 << ell))()
+        orc.orc_eq_evals(mont_bulk(r), sz(ell), want)
+        assert bytes(t.download()) == bytes(want)
+        t.free()
+
+
+@pytest.mark.parametrize("kind,ntabs", [(0, 2), (2, 4)])
+def test_zk_sumcheck_rounds_large_match_oracle(ctx, orc, kind, ntabs):
+    """sumcheck.rs:460-469 / 624-652 + bound_poly_var_top at 2^17: the streaming k_sc_eval / k_sc_bind_eval (quarter > 8192)
+    and the hand-over to the lane-parallel form as the tables shrink."""
+    from spartan_amd import capi
+    ell = 17
+    n = 1 << ell
+    rng = random.Random(900 + kind)
+    vals = [fast_scalars(rng, n) for _ in range(ntabs)]
+    tabs = [up(ctx, v) for v in vals]
+    host = [mont_bulk(v) for v in vals] + [None] * (4 - ntabs)
+    nv = 8 if kind == 0 else 12
+    want = (ctypes.c_uint64 * 12)()
+    orc.orc_sumcheck_eval(ctypes.c_int(kind), host[0], host[1], host[2], host[3], sz(n), want)
+    got = capi.sumcheck_eval(ctx, kind, tabs)
+    assert list(got)[:nv] == list(want)[:nv]
+    length = n
+    for _ in range(6):   # quarters 2^15 .. 2^10: three streaming rounds, three lane-parallel ones
+        r = fq1(rng.getrandbits(250))
+        for k in range(ntabs):
+            orc.orc_bound_top(host[k], sz(length), r)
+        length //= 2
+        orc.orc_sumcheck_eval(ctypes.c_int(kind), host[0], host[1], host[2], host[3], sz(length), want)
+        got = capi.sumcheck_bind_eval(ctx, kind, tabs, r)
+        assert list(got)[:nv] == list(want)[:nv], length
+    for k in range(ntabs):
+        assert bytes(tabs[k].download(length)) == bytes(host[k])[:32 * length]
+    for t in tabs:
+        t.free()
+
+
+def cubic_evals(A, B, C):
+    """sumcheck.rs:290-357: evaluations of sum_i A(t) B(t) C(t) at t = 0, 2, 3 over the top-variable pairs"""
+    h = len(A) // 2
+    e0 = e2 = e3 = 0
+    for i in range(h):
+        a0, a1, b0, b1, c0, c1 = A[i], A[h + i], B[i], B[h + i], C[i], C[h + i]
+        e0 += a0 * b0 * c0
+        a2, b2, c2 = 2 * a1 - a0, 2 * b1 - b0, 2 * c1 - c0
+        e2 += a2 * b2 * c2
+        e3 += (a2 + a1 - a0) * (b2 + b1 - b0) * (c2 + c1 - c0)
+    return [e0 % Q, e2 % Q, e3 % Q]
+
+
+def bind(T, r):
+    h = len(T) // 2
+    return [(T[i] + r * (T[h + i] - T[i])) % Q for i in range(h)]
+
+
+def test_batched_cubic_sumcheck_large_matches_reference_arithmetic(ctx):
+    """prove_cubic_batched's round body (sumcheck.rs:287-393) at 2^17: 3 'par' instances sharing poly_C_par (bound once, out
+    of place) and 2 'seq' instances with their own C; k_cubic_eval_batched, then k_cubic_bind_eval_batched for the rounds
+    with quarter > 8192, then the lane-parallel form."""
+    from spartan_amd import capi
+    n = 1 << 17
+    rng = random.Random(4242)
+    npar, nseq = 3, 2
+    A = [fast_scalars(rng, n) for _ in range(npar + nseq)]
+    B = [fast_scalars(rng, n) for _ in range(npar + nseq)]
+    Cpar = fast_scalars(rng, n)
+    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
+    tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
+    tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
+    ni = npar + nseq
+    hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
+    hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
+    C = [Cpar] * npar + Cseq
+    out = (ctypes.c_uint64 * (12 * ni))()
+    assert capi.lib.sp_sumcheck_eval_batched(ctx.h, hA, hB, hC, sz(ni), out) == 0
+    got = from_mont_bulk(out, 3 * ni)
+    for k in range(ni):
+        assert got[3 * k:3 * k + 3] == cubic_evals(A[k], B[k], C[k]), k
+    for rnd in range(4):  # lengths 2^17 -> 2^13: quarters 2^15, 2^14 streaming; 2^13, 2^12 lane-parallel
+        r = rng.getrandbits(251)
+        A = [bind(a, r) for a in A]; B = [bind(b, r) for b in B]
+        Cpar = bind(Cpar, r); Cseq = [bind(c, r) for c in Cseq]
+        C = [Cpar] * npar + Cseq
+        assert capi.lib.sp_sumcheck_bind_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(r), out) == 0
+        got = from_mont_bulk(out, 3 * ni)
+        for k in range(ni):
+            assert got[3 * k:3 * k + 3] == cubic_evals(A[k], B[k], C[k]), (rnd, k)
+    ln = len(Cpar)
+    assert from_mont_bulk(tCpar.download(ln), ln) == Cpar and len(tCpar) == ln
+    assert from_mont_bulk(tA[4].download(ln), ln) == A[4] and from_mont_bulk(tCseq[1].download(ln), ln) == Cseq[1]
+    for t in tA + tB + tCseq + [tCpar]:
+        t.free()
+
+
+def test_dot_many_dot3_hash_layer_gather_large(ctx):
+    """HashLayerProof::prove's shared-chi evaluations (sparse_mlpoly.rs:722-835 -> k_dot_many), DotProductCircuit::evaluate
+    (product_tree.rs:84-88 -> k_dot3), Layers::build_hash_layer (sparse_mlpoly.rs:529-604 -> k_hash_layer) and
+    AddrTimestamps::deref_mem (:256-265 -> k_gather) at 2^17 elements."""
+    from spartan_amd import capi
+    n = 1 << 17
+    rng = random.Random(1717)
+    chi = fast_scalars(rng, n)
+    T = [fast_scalars(rng, n) for _ in range(5)]
+    tchi, tT = up(ctx, chi), [up(ctx, t) for t in T]
+    out = (ctypes.c_uint64 * 20)()
+    assert capi.lib.sp_dot_many(ctx.h, tchi.h, (vp * 5)(*[t.h for t in tT]), sz(5), out) == 0
+    assert from_mont_bulk(out, 5) == [sum(a * b for a, b in zip(chi, t)) % Q for t in T]
+    o4 = (ctypes.c_uint64 * 4)()
+    off = 1 << 16   # the right half of a split DotProductCircuit (product_tree.rs:90-109)
+    assert capi.lib.sp_dot3(ctx.h, tT[0].h, tT[1].h, tT[2].h, sz(off), sz(n - off), o4) == 0
+    assert from_mont_bulk(o4, 1)[0] == sum(T[0][i] * T[1][i] * T[2][i] for i in range(off, n)) % Q
+    # hash layers: (ts + inc) * r^2 + val * r + addr - r_multiset, with addr = identity / ts = 0 variants (init, audit, read, write)
+    rh, rm = rng.getrandbits(250), rng.getrandbits(249)
+    dst = capi.Table.alloc(ctx, n + 7)
+    for addr, ts, inc in ((None, None, 0), (None, 3, 0), (4, 3, 0), (4, 3, 1)):
+        rc = capi.lib.sp_hash_layer(ctx.h, tT[addr].h if addr is not None else None, tT[1].h, tT[ts].h if ts is not None else None, ctypes.c_int(inc),
+                                    sz(n), fq1(rh), fq1(rm), dst.h, sz(7))
+        assert rc == 0
+        want = [(((T[ts][i] if ts is not None else 0) + inc) * rh * rh + T[1][i] * rh + (T[addr][i] if addr is not None else i) - rm) % Q for i in range(n)]
+        assert from_mont_bulk(dst.download(n, 7), n) == want, (addr, ts, inc)
+    # deref_mem: dst[off + i] = mem[addr[i]]
+    addrs = [rng.randrange(n) for _ in range(n)]
+    ix = vp()
+    assert capi.lib.sp_index_upload(ctx.h, (ctypes.c_uint64 * n)(*addrs), sz(n), ctypes.byref(ix)) == 0
+    g = capi.Table.alloc(ctx, n + 3)
+    assert capi.lib.sp_gather(ctx.h, tT[2].h, ix, g.h, sz(3)) == 0
+    assert from_mont_bulk(g.download(n, 3), n) == [T[2][a] for a in addrs]
+    f = capi.Table.alloc(ctx, n)   # DensePolynomial::from_usize (dense_mlpoly.rs:274-280)
+    assert capi.lib.sp_table_from_index(ctx.h, ix, f.h, sz(0)) == 0
+    assert from_mont_bulk(f.download(), n) == addrs
+    capi.lib.sp_index_free(ix)
+    for t in tT + [tchi, dst, g, f]:
+        t.free()
+
+
+def test_sparse_matrix_products_large(ctx):
+    """SparseMatPolynomial::multiply_vec (sparse_mlpoly.rs:454-464), compute_eval_table_sparse x3 combined as
+    r1csproof.rs:275-283, evaluate_with_tables (:429-438) on matrices with 2^17 rows/columns, several entries per row and
+    per column, empty rows, and duplicate (row, col) pairs (the synthetic instances have exactly one entry per row)."""
+    from spartan_amd import capi
+    nr = nc = 1 << 17
+    rng = random.Random(31337)
+    mats = []
+    for k in range(3):
+        nnz = (1 << 17) + 1000 * k
+        rows = [rng.randrange(nr) if rng.random() < 0.7 else rng.randrange(64) for _ in range(nnz)]   # a few crowded rows
+        cols = [rng.randrange(nc) if rng.random() < 0.7 else nc - 1 - rng.randrange(32) for _ in range(nnz)]
+        vals = fast_scalars(rng, nnz)
+        rows[5], cols[5] = rows[4], cols[4]   # duplicate coordinate: both entries count
+        mats.append((rows, cols, vals))
+    hs = []
+    for rows, cols, vals in mats:
+        h = vp()
+        n = len(rows)
+        rc = capi.lib.sp_sparse_upload(ctx.h, (ctypes.c_uint64 * n)(*rows), (ctypes.c_uint64 * n)(*cols), mont_bulk(vals), sz(n), sz(nr), sz(nc), ctypes.byref(h))
+        assert rc == 0
+        hs.append(h)
+    z = fast_scalars(rng, nc)
+    tz = up(ctx, z)
+    for (rows, cols, vals), h in zip(mats, hs):
+        o = vp()
+        assert capi.lib.sp_sparse_mulvec(ctx.h, h, tz.h, ctypes.byref(o)) == 0
+        t = capi.Table(ctx, o)
+        want = [0] * nr
+        for r_, c_, v_ in zip(rows, cols, vals):
+            want[r_] += v_ * z[c_]
+        assert from_mont_bulk(t.download(), nr) == [w % Q for w in want]
+        t.free()
+    rx = fast_scalars(rng, nr)
+    trx = up(ctx, rx)
+    w = fast_scalars(rng, 3)
+    o = vp()
+    assert capi.lib.sp_sparse_eval_table(ctx.h, (vp * 3)(*hs), mont_bulk(w), sz(3), trx.h, ctypes.byref(o)) == 0
+    t = capi.Table(ctx, o)
+    want = [0] * nc
+    for k, (rows, cols, vals) in enumerate(mats):
+        for r_, c_, v_ in zip(rows, cols, vals):
+            want[c_] += w[k] * rx[r_] * v_
+    assert from_mont_bulk(t.download(), nc) == [x % Q for x in want]
+    t.free()
+    ty = up(ctx, z)
+    for (rows, cols, vals), h in zip(mats, hs):
+        o4 = (ctypes.c_uint64 * 4)()
+        assert capi.lib.sp_sparse_evaluate(ctx.h, h, trx.h, ty.h, o4) == 0
+        assert from_mont_bulk(o4, 1)[0] == sum(rx[r_] * z[c_] * v_ for r_, c_, v_ in zip(rows, cols, vals)) % Q
+    for h in hs:
+        capi.lib.sp_sparse_free(h)
+    for t in (tz, trx, ty):
+        t.free()
+
+
+def test_vecmat_and_evaluate_large_match_oracle(ctx, orc):
+    """DensePolynomial::bound (dense_mlpoly.rs:206-213) and ::evaluate (:236-242) at 2^18 (512 x 512 view)."""
+    from spartan_amd import capi
+    v = 18
+    n = 1 << v
+    rng = random.Random(1818)
+    Z = fast_scalars(rng, n)
+    Ls = 1 << (v // 2)
+    Lv = fast_scalars(rng, Ls)
+    t = up(ctx, Z)
+    got = capi.vecmat(ctx, mont_bulk(Lv), Ls, t)
+    want = (ctypes.c_uint64 * (4 * (n // Ls)))()
+    orc.orc_bound_vecmat(mont_bulk(Z), sz(v), mont_bulk(Lv), want)
+    assert bytes(got) == bytes(want)
+    r = fast_scalars(rng, v)
+    e = capi.evaluate(ctx, t, mont_bulk(r), v)
+    chi = (ctypes.c_uint64 * (4 * n))()
+    orc.orc_eq_evals(mont_bulk(r), sz(v), chi)
+    w = u64x4()
+    orc.orc_dot(mont_bulk(Z), chi, sz(n), w)
+    assert list(e) == list(w)
+    t.free()
+
+
+def test_inner_product_argument_n4096_matches_folded_generators(ctx, orc):
+    """BulletReductionProof::prove (nizk/bullet.rs:32-132) at n = 4096 as the reference computes it — G folded every round,
+    L = <a_L, G_R> + c_L Q + blind_L H over the FOLDED generators — through the oracle's point arithmetic only
+    (orc_pt_msm), against sp_ipa_*, which never folds G (fixed-base rows over the original generators)."""
+    from spartan_amd import capi
+    n = 4096
+    rng = random.Random(4096)
+    comp = gens_bytes(orc, n + 1, b"gens_ipa_test")   # G[0..n), Q = P[n], H = P[n+1]
+    g = capi.Gens(ctx, compressed=comp)
+    P = [comp[32 * i:32 * i + 32] for i in range(n + 2)]
+    a, b = fast_scalars(rng, n), fast_scalars(rng, n)
+    qs = rng.getrandbits(250)
+    ipa = vp()
+    assert capi.lib.sp_ipa_begin(ctx.h, g.h, sz(0), sz(n), sz(n), sz(n + 1), fq1(qs), mont_bulk(a), mont_bulk(b), ctypes.byref(ipa)) == 0
+    out = (ctypes.c_uint8 * 32)()
+
+    def msm(scalars, points):
+        assert orc.orc_pt_msm(mont_bulk(scalars), b"".join(points), sz(len(points)), out) == 1
+        return bytes(out)
+    Qp = msm([qs], [P[n]])   # gens_1.scale(r) (nizk/mod.rs:479-480)
+    G = P[:n]
+    cur = n
+    while cur > 1:
+        h = cur // 2
+        bl, br = rng.getrandbits(250), rng.getrandbits(249)
+        cL = sum(a[i] * b[h + i] for i in range(h)) % Q
+        cR = sum(a[h + i] * b[i] for i in range(h)) % Q
+        wantL = msm(a[:h] + [cL, bl], G[h:] + [Qp, P[n + 1]])     # bullet.rs:83-89
+        wantR = msm(a[h:] + [cR, br], G[:h] + [Qp, P[n + 1]])     # :91-97
+        L = (ctypes.c_uint8 * 32)(); Rr = (ctypes.c_uint8 * 32)()
+        assert capi.lib.sp_ipa_round_lr(ipa, fq1(bl), fq1(br), L, Rr) == 0
+        assert bytes(L) == wantL and bytes(Rr) == wantR, cur
+        u = rng.getrandbits(251) | 1
+        ui = pow(u, Q - 2, Q)
+        assert capi.lib.sp_ipa_round_fold(ipa, fq1(u), fq1(ui)) == 0
+        a = [(a[i] * u + ui * a[h + i]) % Q for i in range(h)]     # :105-106
+        b = [(b[i] * ui + u * b[h + i]) % Q for i in range(h)]
+        G = [msm([ui, u], [G[i], G[h + i]]) for i in range(h)]     # :108
+        cur = h
+    ah = (ctypes.c_uint64 * 4)(); bh = (ctypes.c_uint64 * 4)(); gh = (ctypes.c_uint8 * 32)()
+    assert capi.lib.sp_ipa_finish(ipa, ah, bh, gh) == 0
+    assert from_mont_bulk(ah, 1) == a and from_mont_bulk(bh, 1) == b and bytes(gh) == G[0]
+    d, r = rng.getrandbits(250), rng.getrandbits(250)
+    assert capi.lib.sp_ipa_commit_ghat(ipa, fq1(d), fq1(r), out) == 0
+    assert bytes(out) == msm([d, r], [G[0], P[n + 1]])             # nizk/mod.rs:496-501
+    capi.lib.sp_ipa_free(ipa)
+    g.free()
+
+
+def test_witness_sized_commit_every_row_matches_oracle(ctx, orc):
+    """DensePolynomial::commit_inner (dense_mlpoly.rs:164-177) at the 2^20 headline shape, 1024 rows x 1024 columns with
+    blinds: every one of the 1024 commitments of k_msm_rows (XCD tile order, two-pass reduce, one-lane-per-row encode) against
+    orc_commit_rows; then the same rows through the persistent half-chip background kernel (k_msm_rows_bg, no blinds)."""
+    from spartan_amd import capi
+    rows = cols = 1024
+    rng = random.Random(20)
+    comp = gens_bytes(orc, cols, b"gens_r1cs_sat")
+    g = capi.Gens(ctx, compressed=comp)
+    Z = fast_scalars(rng, rows * cols)
+    bl = fast_scalars(rng, rows)
+    Zm, blm = mont_bulk(Z), mont_bulk(bl)
+    t = capi.Table.upload(ctx, Zm, rows * cols)
+    got = g.commit_rows(t, rows, cols, blm, g_off=0, h_idx=cols)
+    orc.orc_set_threads(ctypes.c_int(min(32, __import__("os").cpu_count() or 1)))
+    want = (ctypes.c_uint8 * (32 * rows))()
+    assert orc.orc_commit_rows(comp[:32 * cols], sz(cols), comp[32 * cols:], Zm, sz(rows), sz(cols), blm, want) == 0
+    assert got == bytes(want)
+    job = g.commit_rows_begin(t, rows, cols, g_off=0)
+    got_bg = g.commit_rows_wait(job)
+    assert orc.orc_commit_rows(comp[:32 * cols], sz(cols), comp[32 * cols:], Zm, sz(rows), sz(cols), None, want) == 0
+    assert got_bg == bytes(want)
+    orc.orc_set_threads(ctypes.c_int(1))
+    t.free(); g.free()
+
+
+@pytest.mark.parametrize("ell,first_eval", [(13, True), (13, False), (6, True), (1, True), (2, False)])
+def test_resident_sumcheck_session_matches_reference_arithmetic(ctx, ell, first_eval):
+    """sp_sumcheck_session_* (session.hip): all remaining rounds of prove_cubic_batched (sumcheck.rs:287-419) inside one
+    resident kernel, the challenge and the evaluations travelling through mailboxes. Every round's evaluations, the table
+    contents after an early abort, and the final claims are compared with the reference arithmetic in Python; 3 'par'
+    instances share their C table, 2 'seq' instances own theirs. 2^13 = the largest session (16 workgroups per instance)."""
+    from spartan_amd import capi
+    n = 1 << ell
+    rng = random.Random(7000 + ell)
+    npar, nseq = 3, 2
+    ni = npar + nseq
+    A = [fast_scalars(rng, n) for _ in range(ni)]
+    B = [fast_scalars(rng, n) for _ in range(ni)]
+    Cpar = fast_scalars(rng, n)
+    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
+
+    def tables():
+        tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
+        tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
+        hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
+        return tA, tB, tCpar, tCseq, (vp * ni)(*[t.h for t in tA]), (vp * ni)(*[t.h for t in tB]), hC
+    tA, tB, tCpar, tCseq, hA, hB, hC = tables()
+    out = (ctypes.c_uint64 * (12 * ni))()
+    sess = vp()
+    cA, cB, cCpar, cCseq = [list(a) for a in A], [list(b) for b in B], list(Cpar), [list(c) for c in Cseq]
+    cC = lambda: [cCpar] * npar + cCseq
+    if first_eval:
+        assert capi.lib.sp_sumcheck_session_begin(ctx.h, hA, hB, hC, sz(ni), ctypes.c_int(1), out, ctypes.byref(sess)) == 0
+        got = from_mont_bulk(out, 3 * ni)
+        for k in range(ni):
+            assert got[3 * k:3 * k + 3] == cubic_evals(cA[k], cB[k], cC()[k]), k
+    else:
+        assert capi.lib.sp_sumcheck_session_begin(ctx.h, hA, hB, hC, sz(ni), ctypes.c_int(0), None, ctypes.byref(sess)) == 0
+    length = n
+    while length >= 4:
+        r = rng.getrandbits(251)
+        cA = [bind(a, r) for a in cA]; cB = [bind(b, r) for b in cB]; cCpar = bind(cCpar, r); cCseq = [bind(c, r) for c in cCseq]
+        assert capi.lib.sp_sumcheck_session_round(sess, fq1(r), out) == 0
+        length //= 2
+        got = from_mont_bulk(out, 3 * ni)
+        for k in range(ni):
+            assert got[3 * k:3 * k + 3] == cubic_evals(cA[k], cB[k], cC()[k]), (length, k)
+        assert len(tA[0]) == length and len(tCpar) == length
+    r = rng.getrandbits(250)
+    heads = (ctypes.c_uint64 * (4 * (2 * ni + 1 + nseq)))()
+    assert capi.lib.sp_sumcheck_session_finish(sess, fq1(r), heads) == 0
+    got = from_mont_bulk(heads, 2 * ni + 1 + nseq)
+    fin = lambda T: (T[0] + r * (T[1] - T[0])) % Q
+    want = []
+    for k in range(ni):
+        want += [fin(cA[k]), fin(cB[k])]
+    want += [fin(cCpar)] + [fin(c) for c in cCseq]
+    assert got == want
+    # the table objects describe the bound tables (length 1, current buffer) — what the next protocol step reads
+    assert all(len(t) == 1 for t in tA + tB + tCseq + [tCpar])
+    assert from_mont_bulk(tCpar.download(1), 1) == [fin(cCpar)] and from_mont_bulk(tA[3].download(1), 1) == [fin(cA[3])]
+    assert from_mont_bulk(tCseq[1].download(1), 1) == [fin(cCseq[1])]
+    for t in tA + tB + tCseq + [tCpar]:
+        t.free()
+    if ell < 6:
+        return
+    # abort after two rounds: the tables hold the state after the last completed round, and the context keeps working
+    tA, tB, tCpar, tCseq, hA, hB, hC = tables()
+    assert capi.lib.sp_sumcheck_session_begin(ctx.h, hA, hB, hC, sz(ni), ctypes.c_int(0), None, ctypes.byref(sess)) == 0
+    cA, cCpar, cCseq = [list(a) for a in A], list(Cpar), [list(c) for c in Cseq]
+    for _ in range(3):
+        r = rng.getrandbits(251)
+        cA = [bind(a, r) for a in cA]; cCpar = bind(cCpar, r); cCseq = [bind(c, r) for c in cCseq]
+        assert capi.lib.sp_sumcheck_session_round(sess, fq1(r), out) == 0
+    capi.lib.sp_sumcheck_session_abort(sess)
+    ln = n // 8
+    assert len(tCpar) == ln and from_mont_bulk(tCpar.download(ln), ln) == cCpar
+    assert from_mont_bulk(tA[1].download(ln), ln) == cA[1] and from_mont_bulk(tCseq[0].download(ln), ln) == cCseq[0]
+    # and the launch-per-round path continues from there with the same result as the session would have given
+    r = rng.getrandbits(251)
+    assert capi.lib.sp_sumcheck_bind_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(r), out) == 0
+    cA = [bind(a, r) for a in cA]
+    assert from_mont_bulk(tA[2].download(ln // 2), ln // 2) == cA[2]
+    for t in tA + tB + tCseq + [tCpar]:
+        t.free()

@@ -72,7 +72,7 @@ def test_points_match_oracle(hc, orc):
         assert hc.hc_pt_add(a, a, o1) == 1 and hc.hc_pt_dbl(a, o2) == 1 and bytes(o1) == bytes(o2)
         orc.orc_pt_dbl(a, o1); assert bytes(o1) == bytes(o2)
     from tests.test_oracle_pins import RFC_BAD
-    for bad in RFC_BAD[:7]:
+    for bad in RFC_BAD:
         assert hc.hc_pt_recompress(bytes.fromhex(bad), o1) == 0
 
 

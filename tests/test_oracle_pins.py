@@ -102,17 +102,42 @@ RFC_MULTIPLES = [  # RFC 9496 A.1: k*B for k = 0..15
     "46376b80f409b29dc2b5f6f0c52591990896e5716f41477cd30085ab7f10301e",
     "e0c418f7c8d9c4cdd7395b93ea124f3ad99021bb681dfc3302a9d99a2e53e64e",
 ]
-RFC_BAD = [  # RFC 9496 A.2 (a selection of each class)
+RFC_BAD = [  # RFC 9496 A.2 "Invalid Encodings", all five classes (curve25519-dalek's `bad_encodings` holds the same list).
+    # Every entry is also required to be rejected by libsodium below, so a mistyped vector cannot pass unnoticed.
+    # non-canonical field encodings
     "00ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff",
     "ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
     "f3ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
     "edffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
+    # negative field elements
     "0100000000000000000000000000000000000000000000000000000000000000",
     "01ffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
     "ed57ffd8c914fb201471d1c3d245ce3c746fcbe63a3679d51b6a516ebebe0e20",
-    "c3aea9c1e6c1e4ed0f4f4f4b4c4a7c6e5c3a5f6e7d8c9b0a1f2e3d4c5b6a7988" if False else "26948d35ca62e643e26a83177332e6b6afeb9d08e4268b650f1f5bbd8d81d371",
+    "c34c4e1826e5d403b78e246e88aa051c36ccf0aafebffe137d148a2bf9104562",
+    "c940e5a4404157cfb1628b108db051a8d439e1a421394ec4ebccb9ec92a8ac78",
+    "47cfc5497c53dc8e61c91d17fd626ffb1c49e2bca94eed052281b510b1117a24",
+    "f1c6165d33367351b0da8f6e4511010c68174a03b6581212c71c0e1d026c3c72",
+    "87260f7a2f12495118360f02c26a470f450dadf34a413d21042b43b9d93e1309",
+    # non-square x^2
+    "26948d35ca62e643e26a83177332e6b6afeb9d08e4268b650f1f5bbd8d81d371",
     "4eac077a713c57b4f4397629a4145982c661f48044dd3f96427d40b147d9742f",
-    "de6a7b00deadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbe0f" if False else "7a0a0a8a8a4a3a2a1a0a9a8a7a6a5a4a3a2a1a0a9a8a7a6a5a4a3a2a1a0a9a8f",
+    "de6a7b00deadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbeefdeadbeef",
+    "bcab477be20861e01e4a0e295284146a510150d9817763caf1a6f4b422d67042",
+    "2a292df7e32cababbd9de088d1d1abec9fc0440f637ed2fba145094dc14bea08",
+    "f4a9e534fc0d216c44b218fa0c42d99635a0127ee2e53c712f70609649fdff22",
+    "8268436f8c4126196cf64b3c7ddbda90746a378625f9813dd9b8457077256731",
+    "2810e5cbc2cc4d4eece54f61c6f69758e289aa7ab440b3cbeaa21995c2f4232b",
+    # negative x*y
+    "3eb858e78f5a7254d8c9731174a94f76755fd3941c0ac93735c07ba14579630e",
+    "a45fdc55c76448c049a1ab33f17023edfb2be3581e9c7aade8a6125215e04220",
+    "d483fe813c6ba647ebbfd3ec41adca1c6130c2beeee9d9bf065c8d151c5f396e",
+    "8a2e1d30050198c65a54483123960ccc38aef6848e1ec8f5f780e8523769ba32",
+    "32888462f8b486c68ad7dd9610be5192bbeaf3b443951ac1a8118419d9fa097b",
+    "227142501b9d4355ccba290404bde41575b037693cef1f438c47f8fbf35d1165",
+    "5c37cc491da847cfeb9281d407efc41e15144c876e0170b499a96a22ed31e01e",
+    "445425117cb8c90edcbc7c1cc0e74f747f2c1efa5630a967c64f287792a48a4b",
+    # s = -1 (y = 0)
+    "ecffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
 ]
 RFC_MAP_IN = "5d1be09e3d0c82fc538112490e35701979d99e06ca3e2b5b54bffe8b4dc772c14d98b696a1bbfb5ca32c436cc61c16563790306c79eaca7705668b47dffe5bb6"
 RFC_MAP_OUT = "3066f82a1a747d45120d1740f14358531a8f04bbffe6a819f86dfe50f44a0a46"
@@ -130,8 +155,11 @@ def test_group_rfc9496_vectors(orc):
         assert orc.orc_pt_mul_bytes(k.to_bytes(32, "little"), B, out) == 1 and bytes(out).hex() == RFC_MULTIPLES[k]
         assert orc.orc_pt_add(acc, B, out) == 1
         acc = bytes(out)
-    for bad in RFC_BAD[:7]:
+    sod = _sodium()
+    for bad in RFC_BAD:
         assert orc.orc_pt_recompress(bytes.fromhex(bad), out) == 0, bad
+        if sod is not None:
+            assert sod.crypto_core_ristretto255_is_valid_point(bytes.fromhex(bad)) == 0, bad
     # one-way map: RFC 9496 A.3 first vector (input = SHA-512("Ristretto is traditionally a short shot of espresso coffee"))
     h = hashlib.sha512(b"Ristretto is traditionally a short shot of espresso coffee").digest()
     assert h.hex() == RFC_MAP_IN
