@@ -18,6 +18,7 @@
 // mailbox that the other workgroups poll. Every wait carries a wall-clock timeout: a session whose host went away exits
 // by itself and flags the error; it cannot hang the GPU.
 #include "internal.hpp"
+#include <time.h>
 
 namespace {
 
@@ -67,7 +68,7 @@ SP_HD size_t sess_active(uint32_t type, size_t len, size_t gx) {
 // grid (gx, ninst), 256 threads: 32 indices x 8 lanes per pass, as k_cubic_bind_eval_tiny (spark.hip): lane 2k+h of an
 // index handles half h of table k (load, bind), then lanes 0..2 evaluate t = 0, 2, 3 with one instruction stream.
 __global__ void __launch_bounds__(256) k_cubic_session(const SessInst* __restrict__ insts, size_t len, uint64_t seq, const SessCmd* cmd, SessSlot* slots,
-                                                       SessDev* dev) {
+                                                       SessDev* dev, uint32_t flags, uint64_t* trace) {
   __shared__ Fq bound[32][6];
   __shared__ Fq red[3][32];
   __shared__ Fq sh_r;
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(256) k_cubic_session(const SessInst* __restric
           if (ld_sys(&cmd->seq) == seq) { ok = true; break; }
           __builtin_amdgcn_s_sleep(2);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the command body is read after its sequence number
         if (ok) {
           type = (uint32_t)ld_sys((const uint64_t*)&cmd->type);
           r = ld_fq_sys(&cmd->r);
@@ -100,23 +102,35 @@ __global__ void __launch_bounds__(256) k_cubic_session(const SessInst* __restric
         dev->r = r;
         dev->type = type;
         __hip_atomic_store(&dev->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        while (wall_clock64() - t0 < SESS_TIMEOUT_TICKS) {
-          if (__hip_atomic_load(&dev->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) { ok = true; break; }
-          __builtin_amdgcn_s_sleep(1);
+        // one copy per instance (256 B apart), so that a copy is polled by that instance's workgroups only
+        for (size_t k = 1; k < gridDim.y; k++) {
+          SessDev* d = (SessDev*)((uint8_t*)dev + 256 * k);
+          d->r = r;
+          d->type = type;
+          __hip_atomic_store(&d->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+      } else {
+        const SessDev* d = (const SessDev*)((const uint8_t*)dev + 256 * inst);
+        while (wall_clock64() - t0 < SESS_TIMEOUT_TICKS) {
+          if (__hip_atomic_load(&d->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) { ok = true; break; }  // no cache invalidate per poll
+          __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (ok) {
-          type = __hip_atomic_load(&dev->type, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t* rp = dev->r.l;
+          type = __hip_atomic_load(&d->type, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t* rp = d->r.l;
 #pragma unroll
           for (int k = 0; k < 4; k++) r.l[k] = __hip_atomic_load(rp + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       sh_type = type;
       sh_r = r;
+      if (trace && bx == 0 && inst == 0) trace[0] = wall_clock64();
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' table writes of the previous round
+    const bool tr = trace && bx == 0 && inst == 0 && threadIdx.x == 0;
+    if (tr) trace[1] = wall_clock64();
     const uint32_t type = sh_type;
     const Fq r = sh_r;
     if (type != SC_EVAL && type != SC_ROUND && type != SC_FINISH) return;
@@ -166,22 +180,31 @@ __global__ void __launch_bounds__(256) k_cubic_session(const SessInst* __restric
         }
         __syncthreads();
       }
+      if (tr) trace[2] = wall_clock64();
       if (role < 3) red[role][li] = e;
       __syncthreads();
       for (int s = 16; s > 0; s >>= 1) {
         if (role < 3 && li < s) red[role][li] = fq_add(red[role][li], red[role][li + s]);
         __syncthreads();
       }
-      if (threadIdx.x < 3) st_fq_sys(&slot->v[threadIdx.x], red[threadIdx.x][0]);
+      if (tr) trace[3] = wall_clock64();
+      // the 96 bytes of the slot in ONE store instruction (one limb per lane): one PCIe write, not twelve
+      if (threadIdx.x < 12)
+        __hip_atomic_store(&((uint64_t*)slot->v)[threadIdx.x], red[threadIdx.x >> 2][0].l[threadIdx.x & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (do_bind) {
         len /= 2;
         Fq* t = cc; cc = cn; cn = t;
       }
     }
-    // ---- post: table writes and the slot payload first, then the slot's sequence number
-    __threadfence_system();
+    // ---- post: table writes and the slot payload first, then the slot's sequence number. The barrier orders every thread's
+    // stores before thread 0's system-scope release (one L2 write-back per workgroup, not one per wave).
+    if (flags & 1) __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+      if (tr) trace[4] = wall_clock64();
+      __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tr) { trace[5] = wall_clock64(); trace += 6; }
+    }
     if (type == SC_FINISH) return;
     seq++;
     // the next command is a ROUND while len >= 4, else the FINISH; a workgroup with nothing left to do leaves
@@ -190,7 +213,23 @@ __global__ void __launch_bounds__(256) k_cubic_session(const SessInst* __restric
   }
 }
 
+static uint32_t sess_flags() {
+  static const uint32_t v = [] { const char* e = getenv("SPARTAN_SESSION_FLAGS"); return e ? (uint32_t)atoi(e) : 0u; }();
+  return v;
+}
+static bool sess_trace_on() {
+  static const bool v = getenv("SPARTAN_SESSION_TRACE") != nullptr;
+  return v;
+}
+static double sess_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+struct SessTrace { double post_us = 0, done_us = 0; };
 struct sp_session {
+  std::vector<SessTrace> tr;
+  double t_begin = 0;
   sp_ctx* ctx;
   size_t ninst, gx, len, ncs;
   uint64_t seq;            // sequence number of the last command issued
@@ -221,10 +260,12 @@ static int32_t sess_wait(sp_session* s, uint32_t type, size_t len_before) {
         }
       }
     }
+  if (sess_trace_on() && !s->tr.empty()) s->tr.back().done_us = sess_now();
   return SP_OK;
 }
 static void sess_post(sp_session* s, uint32_t type, const uint64_t* r) {
   SessCmd* cmd = (SessCmd*)s->ctx->sess_cmd;
+  if (sess_trace_on()) { s->tr.emplace_back(); s->tr.back().post_us = sess_now(); }
   cmd->type = type;
   if (r) memcpy(cmd->r.l, r, 32);
   s->seq = ++s->ctx->sess_seq;
@@ -265,15 +306,16 @@ int32_t sp_sumcheck_session_begin(sp_ctx* c, sp_table* const* A, sp_table* const
   if (!c->sess_cmd) {  // mailboxes of this context: allocated on first use, reused by every session
     HIPCHK(hipHostMalloc((void**)&c->sess_cmd, 4096, hipHostMallocCoherent | hipHostMallocMapped));
     HIPCHK(hipHostMalloc((void**)&c->sess_slots, sizeof(SessSlot) * SESS_GX_MAX * SESS_MAX_INST, hipHostMallocCoherent | hipHostMallocMapped));
-    HIPCHK(hipMalloc((void**)&c->sess_dev, 4096));
+    HIPCHK(hipMalloc((void**)&c->sess_dev, 32768));  // 64 command copies of 256 B, then the trace area
     memset(c->sess_cmd, 0, 4096);
     memset(c->sess_slots, 0, sizeof(SessSlot) * SESS_GX_MAX * SESS_MAX_INST);
-    HIPCHK(hipMemsetAsync(c->sess_dev, 0, 4096, c->stream));
+    HIPCHK(hipMemsetAsync(c->sess_dev, 0, 32768, c->stream));
     c->sess_seq = 0;
   }
   sp_session* s = new (std::nothrow) sp_session();
   if (!s) return SP_ENOMEM;
   s->ctx = c; s->ninst = ninst; s->len = len; s->dead = false; s->cur = 0;
+  s->t_begin = sess_trace_on() ? sess_now() : 0;
   s->A.assign(A, A + ninst); s->B.assign(B, B + ninst); s->C.assign(C, C + ninst);
   s->c_of_inst.resize(ninst);
   for (size_t k = 0; k < ninst; k++) {
@@ -308,7 +350,7 @@ int32_t sp_sumcheck_session_begin(sp_ctx* c, sp_table* const* A, sp_table* const
   {
     ProfScope ps(c, PF_SESSION, 0.0);
     hipLaunchKernelGGL(k_cubic_session, dim3((unsigned)s->gx, (unsigned)ninst), dim3(256), 0, c->stream, (const SessInst*)dinst, len, seq0,
-                       (const SessCmd*)c->sess_cmd, (SessSlot*)c->sess_slots, (SessDev*)c->sess_dev);
+                       (const SessCmd*)c->sess_cmd, (SessSlot*)c->sess_slots, (SessDev*)c->sess_dev, sess_flags(), sess_trace_on() ? (uint64_t*)((uint8_t*)c->sess_dev + 16384) : (uint64_t*)nullptr);
   }
   if (hipGetLastError() != hipSuccess) { delete s; return SP_EHIP; }
   if (first_eval) {
@@ -335,6 +377,26 @@ int32_t sp_sumcheck_session_round(sp_session* s, const uint64_t r[4], uint64_t* 
 }
 
 static void sess_release(sp_session* s) {
+  if (sess_trace_on() && !s->tr.empty()) {  // diagnostic: where a round's time goes (host clock in us, device wall clock at 100 MHz)
+    sp_ctx* c = s->ctx;
+    (void)hipStreamSynchronize(c->stream);
+    std::vector<uint64_t> dt(6 * s->tr.size());
+    (void)hipMemcpy(dt.data(), (uint8_t*)c->sess_dev + 16384, 8 * dt.size(), hipMemcpyDeviceToHost);
+    double host_rt = 0, host_gap = 0, d[6] = {0, 0, 0, 0, 0, 0};
+    size_t n = s->tr.size(), nr = 0;
+    for (size_t k = 0; k < n; k++) {
+      host_rt += s->tr[k].done_us - s->tr[k].post_us;
+      if (k) host_gap += s->tr[k].post_us - s->tr[k - 1].done_us;
+      if (k + 1 == n && s->len == 1) continue;  // the FINISH command takes a different path through the kernel
+      nr++;
+      for (int j = 0; j < 5; j++) d[j] += (double)(dt[6 * k + j + 1] - dt[6 * k + j]) * 0.01;
+      if (k) d[5] += (double)(dt[6 * k] - dt[6 * k - 1]) * 0.01;
+    }
+    if (!nr) nr = 1;
+    fprintf(stderr, "[session] ninst %zu gx %zu cmds %zu | host us/cmd: post->all slots %.1f, think %.1f (begin->first post %.1f) | wg(0,0) us/cmd: seen->acquired %.1f, ->rounds done %.1f, ->tree %.1f, ->slot stored+barrier %.1f, ->seq released %.1f, ->next cmd seen %.1f\n",
+            s->ninst, s->gx, n, host_rt / n, n > 1 ? host_gap / (n - 1) : 0.0, s->tr[0].post_us - s->t_begin, d[0] / nr, d[1] / nr, d[2] / nr, d[3] / nr, d[4] / nr,
+            d[5] / (nr > 1 ? nr - 1 : 1));
+  }
   sess_sync_tables(s);
   delete s;
 }
