@@ -213,19 +213,21 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* cons
  * once, out of place. Requires current length >= 4. */
 int32_t sp_sumcheck_bind_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst,
                                       const uint64_t r[4], uint64_t* out);
-/* Resident form of the two calls above for the latency-bound tail of a sum-check (tables of a few thousand entries and
- * less: ~330 of the ~400 batched rounds of a 2^20 proof). ONE kernel stays on the device for all remaining rounds; each
- * round is a mailbox exchange (the challenge goes in, the 3*ninst evaluations come out) instead of a launch plus a
+/* Resident form of the two calls above for the latency-bound tail of a sum-check: tables of at most
+ * sp_sumcheck_session_max_len() (512) entries, ~270 of the ~400 batched rounds of a 2^20 proof. ONE kernel stays on the
+ * device for all remaining rounds, one workgroup per instance with that instance's tables held in LDS; each round is a
+ * mailbox exchange (the challenge goes in, the 3*ninst evaluations come out) instead of a launch, a pass over HBM and a
  * completion wait — the transcript stays with the caller. Same arithmetic, same table contents afterwards.
- *   begin : tables as for sp_sumcheck_eval_batched (equal current length >= 2). first_eval != 0: also evaluates the
- *           round on the tables as they are -> out_evals[12*ninst] (what sp_sumcheck_eval_batched returns).
+ *   begin : tables as for sp_sumcheck_eval_batched (equal current length, 2 <= length <= max_len). first_eval != 0: also
+ *           evaluates the round on the tables as they are -> out_evals[12*ninst] (what sp_sumcheck_eval_batched returns).
  *   round : sp_sumcheck_bind_eval_batched at r (current length >= 4).
  *   finish: the last round, current length 2: binds every table at r and returns the remaining entries,
  *           out_heads = A_0, B_0, A_1, B_1, ..., then each distinct C table in order of first appearance
  *           (sp_table_bind_top_heads on that list). Ends the session and frees it, also on error.
  *   abort : ends a session early (error paths); the tables hold the state after the last completed round.
- * Between begin and finish/abort no other call may be made on the context. A session that hears nothing from its
- * caller for 2 s ends by itself. */
+ * Between begin and finish/abort no other call may be made on the context, and the tables' device contents are undefined
+ * (the current values live in LDS). A session that hears nothing from its caller for 2 s writes its tables back and ends. */
+size_t sp_sumcheck_session_max_len(void);
 typedef struct sp_session sp_session;
 int32_t sp_sumcheck_session_begin(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int first_eval,
                                   uint64_t* out_evals, sp_session** out);

@@ -128,7 +128,111 @@ SP_HD Fq fq_mont_reduce(const uint64_t tin[8]) {
   Fq t = {{r[4], r[5], r[6], r[7]}};
   return fq_csub(t);
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FQ_MUL_GENERIC)
+// Device form of fq_mul: product-scanning (Comba) Montgomery multiplication on 8 x 32-bit words with a 96-bit column
+// accumulator, written around the one instruction the hardware has for this — v_mad_u64_u32 (32 x 32 + 64 -> 64, carry-out
+// into an SGPR pair). A term of a column is mad + add-with-carry; the compiler's own code for the u128 formulation below
+// never uses the carry-out and spends 350 of its 517 instructions (100 of them multiplies) shuffling 32-bit halves so that
+// no addition can overflow. Here: 64 + 40 terms (q = 2^252 + c has three zero words, and its top word is a single bit),
+// 8 word inverses, 15 column shifts — ~330 issue slots. Two wait states separate a VALU write of VCC from a VALU read of it
+// on gfx9: the s_nop sits inside the asm statement, where the hazard recognizer does not look.
+// Same value as the generic form (both return the canonical residue), checked by every parity test.
+// lo:hi (64 + 32 bits) += x*y, for 1, 2 or 4 terms per statement. In the 4-term form the carries travel through three SGPR
+// pairs (VCC and two the compiler picks) and every add-with-carry sits at least two instructions behind the mad whose
+// carry it consumes, so no wait-state padding is needed: two instructions per term.
+__device__ __forceinline__ void fq_term1(uint64_t& lo, uint32_t& hi, uint32_t x, uint32_t y) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void fq_term2(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+  uint64_t c1;
+  asm("v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+      "v_mad_u64_u32 %0, %2, %5, %6, %0\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_addc_co_u32_e64 %1, %2, 0, %1, %2"
+      : "+v"(lo), "+v"(hi), "=&s"(c1)
+      : "v"(x0), "v"(y0), "v"(x1), "v"(y1)
+      : "vcc");
+}
+__device__ __forceinline__ void fq_term4(uint64_t& lo, uint32_t& hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2,
+                                         uint32_t x3, uint32_t y3) {
+  uint64_t c1, c2;
+  asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+      "v_mad_u64_u32 %0, %2, %6, %7, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %8, %9, %0\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+      "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+      "v_addc_co_u32_e64 %1, %2, 0, %1, %2\n\t"
+      "v_addc_co_u32_e64 %1, %3, 0, %1, %3\n\t"
+      "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+      : "+v"(lo), "+v"(hi), "=&s"(c1), "=&s"(c2)
+      : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3)
+      : "vcc");
+}
+template <int N>
+__device__ __forceinline__ void fq_terms(uint64_t& lo, uint32_t& hi, const uint32_t (&x)[16], const uint32_t (&y)[16]) {
+  static_assert(N >= 0 && N <= 16, "terms per column");
+  constexpr int n4 = N / 4 * 4;
+#pragma unroll
+  for (int t = 0; t < n4; t += 4) fq_term4(lo, hi, x[t], y[t], x[t + 1], y[t + 1], x[t + 2], y[t + 2], x[t + 3], y[t + 3]);
+  if (N - n4 >= 2) fq_term2(lo, hi, x[n4], y[n4], x[n4 + 1], y[n4 + 1]);
+  if ((N - n4) & 1) fq_term1(lo, hi, x[N - 1], y[N - 1]);
+}
+// column k of the product-scanning Montgomery multiplication: sum of a_i b_(k-i) and of m_i q_(k-i) over the words that exist
+template <int K>
+__device__ __forceinline__ void fq_column(uint64_t& lo, uint32_t& hi, const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t (&m)[8],
+                                          const uint32_t (&q)[8], uint32_t (&r)[8]) {
+  constexpr int i0 = K < 8 ? 0 : K - 7, i1 = K < 8 ? K : 7;  // a_i b_(K-i) for i0 <= i <= i1
+  // reduction terms m_i q_(K-i): i < K for the low columns (m_K is made below), q has words 0..3 and 7 only
+  constexpr bool has7 = K >= 7;               // m_(K-7) q_7
+  constexpr int j0 = K < 8 ? (K >= 3 ? K - 3 : 0) : (K - 3 > K - 7 ? K - 3 : K - 7);  // m_i q_(K-i) with K-i in 1..3 (and 0 for high columns)
+  uint32_t x[16], y[16];
+  int n = 0;
+#pragma unroll
+  for (int i = i0; i <= i1; i++) { x[n] = a[i]; y[n] = b[K - i]; n++; }
+  if (has7) { x[n] = m[K - 7]; y[n] = q[7]; n++; }
+#pragma unroll
+  for (int i = j0; i <= 7; i++) {
+    const int w = K - i;  // word of q
+    if (w >= (K < 8 ? 1 : 0) && w <= 3) { x[n] = m[i]; y[n] = q[w]; n++; }
+  }
+  constexpr int nprod = i1 - i0 + 1;
+  constexpr int nred = (has7 ? 1 : 0) + (K < 8 ? (K < 3 ? K : 3) : (K <= 10 ? 11 - K : 0));
+  fq_terms<nprod + nred>(lo, hi, x, y);
+  if (K < 8) {
+    uint64_t t;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"((uint32_t)lo), "v"((uint32_t)SP_QINV) : "vcc");  // low word of lo * (-q^-1)
+    m[K] = (uint32_t)t;
+    fq_term1(lo, hi, m[K], q[0]);  // clears the column's low word
+  } else {
+    r[K - 8] = (uint32_t)lo;
+  }
+  lo = (lo >> 32) | ((uint64_t)hi << 32);
+  hi = 0;
+}
+__device__ __forceinline__ Fq fq_mul(const Fq& A, const Fq& B) {  // ristretto255.rs:690-714
+  uint32_t a[8], b[8], m[8], r[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a[2 * i] = (uint32_t)A.l[i]; a[2 * i + 1] = (uint32_t)(A.l[i] >> 32);
+    b[2 * i] = (uint32_t)B.l[i]; b[2 * i + 1] = (uint32_t)(B.l[i] >> 32);
+  }
+  const uint32_t q[8] = {(uint32_t)SP_Q0, (uint32_t)(SP_Q0 >> 32), (uint32_t)SP_Q1, (uint32_t)(SP_Q1 >> 32), 0, 0, 0, (uint32_t)(SP_Q3 >> 32)};
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  fq_column<0>(lo, hi, a, b, m, q, r); fq_column<1>(lo, hi, a, b, m, q, r); fq_column<2>(lo, hi, a, b, m, q, r); fq_column<3>(lo, hi, a, b, m, q, r);
+  fq_column<4>(lo, hi, a, b, m, q, r); fq_column<5>(lo, hi, a, b, m, q, r); fq_column<6>(lo, hi, a, b, m, q, r); fq_column<7>(lo, hi, a, b, m, q, r);
+  fq_column<8>(lo, hi, a, b, m, q, r); fq_column<9>(lo, hi, a, b, m, q, r); fq_column<10>(lo, hi, a, b, m, q, r); fq_column<11>(lo, hi, a, b, m, q, r);
+  fq_column<12>(lo, hi, a, b, m, q, r); fq_column<13>(lo, hi, a, b, m, q, r); fq_column<14>(lo, hi, a, b, m, q, r);
+  r[7] = (uint32_t)lo;
+  Fq t = {{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32), (uint64_t)r[4] | ((uint64_t)r[5] << 32),
+           (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
+  return fq_csub(t);
+}
+__host__ inline Fq fq_mul(const Fq& a, const Fq& b) {
+#else
 SP_HD Fq fq_mul(const Fq& a, const Fq& b) {  // ristretto255.rs:690-714
+#endif
   uint64_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -257,7 +361,59 @@ SP_HD Fp fp_reduce512(const uint64_t t[8]) {
   r.v[0] += cc * 38u;  // a second wrap leaves r < 2^64: cannot carry
   return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FP_MUL_GENERIC)
+// Device form of fp_mul, same construction as fq_mul above (32-bit words, 96-bit column accumulator, v_mad_u64_u32 with its
+// carry-out, two instructions per term): the seven high columns of the 8 x 8 product first (words h[0..7], exact: they carry
+// no carries of the low half), then the eight low columns with the extra term 38 * h[k] (2^256 = 38 mod p), then the
+// carry word of the low half folded in the same way. 72 terms, ~210 instructions against 317 (+89 s_nop) compiled from the
+// u128 form; a mixed point addition is seven of these. The result is a weakly reduced representative (< 2^256) of the same
+// residue; every consumer reduces before it compares or encodes.
+template <int K>
+__device__ __forceinline__ void fp_column(uint64_t& lo, uint32_t& hi, const uint32_t (&a)[8], const uint32_t (&b)[8], const uint32_t (&h)[8]) {
+  constexpr int i0 = K < 8 ? 0 : K - 7, i1 = K < 8 ? K : 7;
+  uint32_t x[16], y[16];
+  int n = 0;
+#pragma unroll
+  for (int i = i0; i <= i1; i++) { x[n] = a[i]; y[n] = b[K - i]; n++; }
+  if (K < 8) { x[n] = h[K]; y[n] = 38u; n++; }
+  fq_terms<(i1 - i0 + 1) + (K < 8 ? 1 : 0)>(lo, hi, x, y);
+}
+__device__ __forceinline__ Fp fp_mul(const Fp& A, const Fp& B) {
+  uint32_t a[8], b[8], h[8], r[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a[2 * i] = (uint32_t)A.v[i]; a[2 * i + 1] = (uint32_t)(A.v[i] >> 32);
+    b[2 * i] = (uint32_t)B.v[i]; b[2 * i + 1] = (uint32_t)(B.v[i] >> 32);
+  }
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+#define SP_FP_HI(K)                              \
+  fp_column<K>(lo, hi, a, b, h);                 \
+  h[K - 8] = (uint32_t)lo;                       \
+  lo = (lo >> 32) | ((uint64_t)hi << 32);        \
+  hi = 0;
+  SP_FP_HI(8) SP_FP_HI(9) SP_FP_HI(10) SP_FP_HI(11) SP_FP_HI(12) SP_FP_HI(13) SP_FP_HI(14)
+#undef SP_FP_HI
+  h[7] = (uint32_t)lo;
+  lo = 0;
+#define SP_FP_LO(K)                              \
+  fp_column<K>(lo, hi, a, b, h);                 \
+  r[K] = (uint32_t)lo;                           \
+  lo = (lo >> 32) | ((uint64_t)hi << 32);        \
+  hi = 0;
+  SP_FP_LO(0) SP_FP_LO(1) SP_FP_LO(2) SP_FP_LO(3) SP_FP_LO(4) SP_FP_LO(5) SP_FP_LO(6) SP_FP_LO(7)
+#undef SP_FP_LO
+  Fp o = {{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32), (uint64_t)r[4] | ((uint64_t)r[5] << 32),
+           (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
+  // the low half overflowed 2^256 by lo (< 2^40): fold 38 * lo back in; a second wrap leaves o < 2^64, so it cannot carry again
+  uint64_t c2 = fp_add_small(o, 38 * lo);
+  o.v[0] += 38 * c2;
+  return o;
+}
+__host__ inline Fp fp_mul(const Fp& a, const Fp& b) {
+#else
 SP_HD Fp fp_mul(const Fp& a, const Fp& b) {
+#endif
   uint64_t t[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) t[i] = 0;
@@ -276,7 +432,12 @@ SP_HD Fp fp_mul(const Fp& a, const Fp& b) {
 }
 // dedicated squaring: 6 doubled cross products + 4 squares (10 wide multiplies instead of 16). The ~254-squaring
 // inverse-square-root chain of the ristretto encode is latency-critical on the commit path.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FP_MUL_GENERIC)
+__device__ __forceinline__ Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }  // ~210 instructions; the u128 squaring below compiles to 251 (+61 s_nop)
+__host__ inline Fp fp_sqr(const Fp& a) {
+#else
 SP_HD Fp fp_sqr(const Fp& a) {
+#endif
   uint64_t t[8];
   u128 c;
   c = (u128)a.v[0] * a.v[1];

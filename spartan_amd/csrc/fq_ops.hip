@@ -33,10 +33,54 @@ __device__ __forceinline__ void eq_expand_top(Fq (&v)[1 << TOPB], const Fq* __re
 }
 // Short tables (ell <= EQ_SMALL_ELL) are pure latency, and there the SIZE of the code is what costs: an earlier kernel
 // that expanded 16 entries per thread in registers was 59 KB of straight-line code, which a lone wavefront fetches cold
-// (~20 us measured, whatever ell is). Here one thread per entry multiplies its ell factors in a rolled loop (2 KB of code);
-// r arrives in the host-mapped page and is copied to LDS once per block.
+// (~20 us measured, whatever ell is). The kernel below is a few KB of rolled code; r arrives in the host-mapped page and is
+// copied to LDS once per block.
 constexpr size_t EQ_SMALL_ELL = 13;
+// One thread per entry, but not one chain of ell multiplications per thread (a lone wavefront needs 1-2 us per dependent
+// F_q multiplication: 13 of them were ~19 us per table, on the critical path of every product-circuit layer). The factors
+// are grouped: the low 8 index bits split 4 + 4 into two 16-entry tables built by 32 threads (3 multiplications deep),
+// the block's high bits (<= 5) are multiplied out by one more thread, then hi*ta (16 threads) and one multiplication per
+// entry: at most 6 deep. The product of the same factors in another order is the same field element.
 __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
+  __shared__ Fq r[16];
+  __shared__ Fq ta[16], tb[16];
+  __shared__ Fq hi;
+  const int t = threadIdx.x;
+  if (t < (int)ell) r[t] = ld_fq(r_host + t);
+  __syncthreads();
+  const int nlo = ell < 8 ? (int)ell : 8, nb = nlo / 2, na = nlo - nb, nhi = (int)ell - nlo;
+  auto factor = [&](int k, bool bit) {  // chi factor of variable k: r[k] or 1 - r[k]
+    Fq rk = r[k], f = fq_sub(fq_one(), rk);
+#pragma unroll
+    for (int w = 0; w < 4; w++) f.l[w] = bit ? rk.l[w] : f.l[w];
+    return f;
+  };
+  if (t < 16) {
+    Fq acc = fq_one();
+    if (t < (1 << na))
+      for (int k = 0; k < na; k++) { Fq f = factor(nhi + k, (t >> (na - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
+    ta[t] = acc;
+  } else if (t < 32) {
+    int u = t - 16;
+    Fq acc = fq_one();
+    if (u < (1 << nb))
+      for (int k = 0; k < nb; k++) { Fq f = factor(nhi + na + k, (u >> (nb - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
+    tb[u] = acc;
+  } else if (t == 32) {
+    Fq acc = fq_one();
+    for (int k = 0; k < nhi; k++) { Fq f = factor(k, (blockIdx.x >> (nhi - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
+    hi = acc;
+  }
+  __syncthreads();
+  if (nhi > 0 && t < (1 << na)) ta[t] = fq_mul(ta[t], hi);
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * 256 + t;
+  if (i >> ell) return;
+  Fq v = ta[(t >> nb) & ((1 << na) - 1)];
+  if (nb > 0) v = fq_mul(v, tb[t & ((1 << nb) - 1)]);
+  st_fq(out + i, v);
+}
+__global__ void __launch_bounds__(256) k_eq_expand_serial(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
   __shared__ Fq r[40];
   if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
   __syncthreads();
@@ -54,6 +98,7 @@ __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ 
   }
   st_fq(out + i, acc);
 }
+
 // Long tables: chi(r)[i] = chi(r_hi)[i >> lo] * chi(r_lo)[i & (2^lo - 1)] — two short tables (kernel above) and ONE
 // multiplication per entry in a streaming kernel with a few hundred bytes of code, instead of the 59 KB unrolled kernel
 // (whose first wave on every CU spends ~20 us fetching it). The product of the same factors in another order is the same
@@ -229,24 +274,42 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ 
     if (threadIdx.x == 0) st_fq(out + k, acc[0]);
   }
 }
-// out[i] (+)= sum_{j in chunk} L[j] * Z[j*R + i] ; grid (R/256, nchunks) ; partial[chunk][i]
+// DensePolynomial::bound (dense_mlpoly.rs:206-213): out[i] = sum_j L[j] * Z[j*R + i], in two stages.
+// Stage 1, grid (ceil(R/64), nchunks): a block covers 64 columns x one chunk of rows; its 256 threads are 64 columns x 4 row
+// lanes (a wave reads 2 KiB of one row: coalesced), each thread multiplies its few rows (the row chunks are sized so that a
+// thread has 4..8 rows and the launch has thousands of blocks, also for the 1024 x 1024 witness), then the 4 row lanes are
+// added in LDS -> partial[chunk][col]. Stage 2, grid ceil(R/32): 32 columns x 8 chunk lanes per block add the chunks.
 __global__ void __launch_bounds__(256) k_vecmat(const Fq* __restrict__ L, size_t Lsz, const Fq* __restrict__ Z, size_t R, size_t jchunk,
                                                 Fq* __restrict__ partial) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
+  __shared__ Fq sm[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  size_t i = (size_t)blockIdx.x * 64 + cl;
   size_t j0 = (size_t)blockIdx.y * jchunk, j1 = j0 + jchunk;
   if (j1 > Lsz) j1 = Lsz;
   Fq acc = fq_zero();
-  for (size_t j = j0; j < j1; j++) acc = fq_add(acc, fq_mul(ld_fq(L + j), ld_fq(Z + j * R + i)));
-  st_fq(partial + (size_t)blockIdx.y * R + i, acc);
+  if (i < R)
+    for (size_t j = j0 + g; j < j1; j += 4) acc = fq_add(acc, fq_mul(ld_fq(L + j), ld_fq(Z + j * R + i)));
+  sm[g][cl] = acc;
+  __syncthreads();
+  if (g == 0 && i < R) st_fq(partial + (size_t)blockIdx.y * R + i, fq_add(fq_add(sm[0][cl], sm[1][cl]), fq_add(sm[2][cl], sm[3][cl])));
 }
 __global__ void __launch_bounds__(256) k_colsum(const Fq* __restrict__ partial, size_t nchunks, size_t R, Fq* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R) return;
+  __shared__ Fq sm[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  size_t i = (size_t)blockIdx.x * 32 + cl;
   Fq acc = fq_zero();
-  for (size_t c = 0; c < nchunks; c++) acc = fq_add(acc, ld_fq(partial + c * R + i));
-  st_fq(out + i, acc);
+  if (i < R)
+    for (size_t c = g; c < nchunks; c += 8) acc = fq_add(acc, ld_fq(partial + c * R + i));
+  sm[g][cl] = acc;
+  __syncthreads();
+  for (int s = 4; s > 0; s >>= 1) {
+    if (g < s) sm[g][cl] = fq_add(sm[g][cl], sm[g + s][cl]);
+    __syncthreads();
+  }
+  if (g == 0 && i < R) st_fq(out + i, sm[0][cl]);
 }
+// rows per chunk of stage 1: 4 row lanes x (4 rows for small matrices, 8 for large ones)
+static size_t vecmat_jchunk(size_t Lsz, size_t R) { return Lsz * R <= ((size_t)1 << 22) ? 16 : 32; }
 __global__ void __launch_bounds__(256) k_dot(const Fq* __restrict__ a, const Fq* __restrict__ b, size_t n, Fq* __restrict__ partials) {
   __shared__ Fq sm[256];
   Fq acc[1] = {fq_zero()};
@@ -289,6 +352,12 @@ int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* 
 
 extern "C" {
 
+static void launch_eq_small(sp_ctx* c, const Fq* dr, size_t ell, Fq* out) {
+  static const bool serial = getenv("SPARTAN_EQ_SERIAL") != nullptr;  // A/B switch: the one-chain-per-entry kernel
+  size_t len = (size_t)1 << ell;
+  if (serial) hipLaunchKernelGGL(k_eq_expand_serial, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, dr, ell, out);
+  else hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, dr, ell, out);
+}
 int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   if (!c || !r || !out || ell == 0 || ell > 40) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
@@ -306,14 +375,14 @@ int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
     ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
     dim3 blk(256);
     if (ell <= EQ_SMALL_ELL) {
-      hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), blk, 0, c->stream, dr, ell, (*out)->d);
+      launch_eq_small(c, dr, ell, (*out)->d);
     } else {
       size_t hi_ell = ell - ell / 2, lo_ell = ell / 2, nhi = (size_t)1 << hi_ell, nlo = (size_t)1 << lo_ell;
       Fq* tmp = nullptr;  // [chi(r_hi) | chi(r_lo)]; handed back to the pool right away: reuse is ordered by the stream
       int32_t rc = pool_alloc(c, 32 * (nhi + nlo), (void**)&tmp);
       if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; return rc; }
-      hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((nhi + 255) / 256)), blk, 0, c->stream, dr, hi_ell, tmp);
-      hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((nlo + 255) / 256)), blk, 0, c->stream, dr + hi_ell, lo_ell, tmp + nhi);
+      launch_eq_small(c, dr, hi_ell, tmp);
+      launch_eq_small(c, dr + hi_ell, lo_ell, tmp + nhi);
       hipLaunchKernelGGL(k_eq_outer, dim3((unsigned)grid_for(len, 4096)), blk, 0, c->stream, (const Fq*)tmp, (const Fq*)(tmp + nhi), (int)lo_ell, len,
                          (*out)->d);
       pool_release(c, tmp, 32 * (nhi + nlo));
@@ -498,17 +567,15 @@ int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, u
   size_t R = Z->len / Lsz;
   SPCHK(ensure_dstage(c, 32 * Lsz));
   SPCHK(stage_in(c, 0, L, 32 * Lsz));
-  size_t nchunks = Lsz < 64 ? 1 : 64;
-  while (nchunks > 1 && (R / 256 + 1) * nchunks > 4096) nchunks /= 2;
-  size_t jchunk = (Lsz + nchunks - 1) / nchunks;
+  size_t jchunk = vecmat_jchunk(Lsz, R), nchunks = (Lsz + jchunk - 1) / jchunk;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nchunks * R + R)));
   Fq* partial = (Fq*)c->scratch;
   Fq* dres = partial + nchunks * R;
   {
     ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R);
-    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 255) / 256), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
+    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
                        (const Fq*)Z->d, R, jchunk, partial);
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, dres);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, dres);
   }
   SPCHK(fetch_out(c, dres, out, 32 * R));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
@@ -519,17 +586,15 @@ int32_t sp_vecmat_dev(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* 
   size_t R = Z->len / Lsz;
   SPCHK(ensure_dstage(c, 32 * Lsz));
   SPCHK(stage_in(c, 0, L, 32 * Lsz));
-  size_t nchunks = Lsz < 64 ? 1 : 64;
-  while (nchunks > 1 && (R / 256 + 1) * nchunks > 4096) nchunks /= 2;
-  size_t jchunk = (Lsz + nchunks - 1) / nchunks;
+  size_t jchunk = vecmat_jchunk(Lsz, R), nchunks = (Lsz + jchunk - 1) / jchunk;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nchunks * R + R)));
   SPCHK(table_new(c, R, false, out));
   Fq* partial = (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R);
-    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 255) / 256), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
+    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
                        (const Fq*)Z->d, R, jchunk, partial);
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, (*out)->d);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, (*out)->d);
   }
   SPCHK(sync_spin(c));  // the staging buffers behind L are reusable
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;

@@ -327,12 +327,12 @@ def test_witness_sized_commit_every_row_matches_oracle(ctx, orc):
     t.free(); g.free()
 
 
-@pytest.mark.parametrize("ell,first_eval", [(13, True), (13, False), (6, True), (1, True), (2, False)])
+@pytest.mark.parametrize("ell,first_eval", [(9, True), (9, False), (6, True), (1, True), (2, False)])
 def test_resident_sumcheck_session_matches_reference_arithmetic(ctx, ell, first_eval):
     """sp_sumcheck_session_* (session.hip): all remaining rounds of prove_cubic_batched (sumcheck.rs:287-419) inside one
     resident kernel, the challenge and the evaluations travelling through mailboxes. Every round's evaluations, the table
     contents after an early abort, and the final claims are compared with the reference arithmetic in Python; 3 'par'
-    instances share their C table, 2 'seq' instances own theirs. 2^13 = the largest session (16 workgroups per instance)."""
+    instances share their C table, 2 'seq' instances own theirs. 2^9 = the largest session (tables held in LDS)."""
     from spartan_amd import capi
     n = 1 << ell
     rng = random.Random(7000 + ell)
@@ -351,6 +351,7 @@ def test_resident_sumcheck_session_matches_reference_arithmetic(ctx, ell, first_
     tA, tB, tCpar, tCseq, hA, hB, hC = tables()
     out = (ctypes.c_uint64 * (12 * ni))()
     sess = vp()
+    assert capi.lib.sp_sumcheck_session_max_len() == 512
     cA, cB, cCpar, cCseq = [list(a) for a in A], [list(b) for b in B], list(Cpar), [list(c) for c in Cseq]
     cC = lambda: [cCpar] * npar + cCseq
     if first_eval:
