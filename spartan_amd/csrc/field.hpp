@@ -54,6 +54,109 @@ SP_HD bool fq_eq(const Fq& a, const Fq& b) {
   return ((a.l[0] ^ b.l[0]) | (a.l[1] ^ b.l[1]) | (a.l[2] ^ b.l[2]) | (a.l[3] ^ b.l[3])) == 0;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FIELD_ADD_GENERIC)
+// ---- device add/sub: two interleaved 8-word carry chains + one select, in inline asm.
+// The u128 formulations below compile to 48-66 VALU instructions plus ~28 wait-state s_nops per field addition (on gfx9 two
+// wait states separate a VALU write of a carry mask from the VALU read of it, and the compiler serialises every chain): a
+// quarter of the cubic sum-check kernels and of a mixed point addition. Here chain 1 is (a op b) word by word, chain 2
+// applies the correction to chain 1's words one step behind it (t - q, d + q, s + 38, d - 38), each chain carrying through
+// its own SGPR pair, so the other chain's instruction and one s_nop 0 are all the padding a carry needs; the final carry
+// of one of the chains selects, per lane, which of the two results is the reduced one. 8 + 8 + 8 instructions.
+template <int OP>  // OP 0: a + b then - k (fq_add) | 1: a - b then + k (fq_sub) | 2: a + b then + k (fp_add) | 3: a - b then - k (fp_sub)
+__device__ __forceinline__ void sp_chain2(const uint32_t (&a)[8], const uint32_t (&b)[8], const uint32_t (&k)[8], uint32_t (&s)[8], uint32_t (&d)[8],
+                                          uint64_t& cA, uint64_t& cB) {
+  // low four words: the chains start (no carry-in)
+  if (OP == 0)
+    asm("v_add_co_u32_e64 %0, %8, %10, %14\n\tv_sub_co_u32_e64 %4, %9, %0, %18\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %8, %11, %15, %8\n\tv_subb_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %2, %8, %12, %16, %8\n\tv_subb_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %3, %8, %13, %17, %8\n\tv_subb_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&s"(cA), "=&s"(cB)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+  else if (OP == 1)
+    asm("v_sub_co_u32_e64 %0, %8, %10, %14\n\tv_add_co_u32_e64 %4, %9, %0, %18\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %1, %8, %11, %15, %8\n\tv_addc_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, %8, %12, %16, %8\n\tv_addc_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %3, %8, %13, %17, %8\n\tv_addc_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&s"(cA), "=&s"(cB)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+  else if (OP == 2)
+    asm("v_add_co_u32_e64 %0, %8, %10, %14\n\tv_add_co_u32_e64 %4, %9, %0, %18\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %8, %11, %15, %8\n\tv_addc_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %2, %8, %12, %16, %8\n\tv_addc_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %3, %8, %13, %17, %8\n\tv_addc_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&s"(cA), "=&s"(cB)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+  else
+    asm("v_sub_co_u32_e64 %0, %8, %10, %14\n\tv_sub_co_u32_e64 %4, %9, %0, %18\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %1, %8, %11, %15, %8\n\tv_subb_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, %8, %12, %16, %8\n\tv_subb_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %3, %8, %13, %17, %8\n\tv_subb_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&s"(cA), "=&s"(cB)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+  // high four words: both chains continue from their carries
+  if (OP == 0)
+    asm("v_addc_co_u32_e64 %0, %8, %10, %14, %8\n\tv_subb_co_u32_e64 %4, %9, %0, %18, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %8, %11, %15, %8\n\tv_subb_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %2, %8, %12, %16, %8\n\tv_subb_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %3, %8, %13, %17, %8\n\tv_subb_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "+s"(cA), "+s"(cB)
+        : "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+  else if (OP == 1)
+    asm("v_subb_co_u32_e64 %0, %8, %10, %14, %8\n\tv_addc_co_u32_e64 %4, %9, %0, %18, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %1, %8, %11, %15, %8\n\tv_addc_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, %8, %12, %16, %8\n\tv_addc_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %3, %8, %13, %17, %8\n\tv_addc_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "+s"(cA), "+s"(cB)
+        : "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+  else if (OP == 2)
+    asm("v_addc_co_u32_e64 %0, %8, %10, %14, %8\n\tv_addc_co_u32_e64 %4, %9, %0, %18, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %1, %8, %11, %15, %8\n\tv_addc_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %2, %8, %12, %16, %8\n\tv_addc_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_addc_co_u32_e64 %3, %8, %13, %17, %8\n\tv_addc_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "+s"(cA), "+s"(cB)
+        : "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+  else
+    asm("v_subb_co_u32_e64 %0, %8, %10, %14, %8\n\tv_subb_co_u32_e64 %4, %9, %0, %18, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %1, %8, %11, %15, %8\n\tv_subb_co_u32_e64 %5, %9, %1, %19, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, %8, %12, %16, %8\n\tv_subb_co_u32_e64 %6, %9, %2, %20, %9\n\ts_nop 0\n\t"
+        "v_subb_co_u32_e64 %3, %8, %13, %17, %8\n\tv_subb_co_u32_e64 %7, %9, %3, %21, %9\n\ts_nop 0"
+        : "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "+s"(cA), "+s"(cB)
+        : "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]));
+}
+// r[i] = sel ? x[i] : y[i] per lane; `both` = 1 where selA and selB are both set (the rare second wrap of the Fp forms)
+__device__ __forceinline__ void sp_select8(uint32_t (&r)[8], const uint32_t (&x)[8], const uint32_t (&y)[8], uint64_t sel) {
+  asm("s_nop 1\n\t"
+      "v_cndmask_b32_e64 %0, %16, %8, %24\n\tv_cndmask_b32_e64 %1, %17, %9, %24\n\tv_cndmask_b32_e64 %2, %18, %10, %24\n\t"
+      "v_cndmask_b32_e64 %3, %19, %11, %24\n\tv_cndmask_b32_e64 %4, %20, %12, %24\n\tv_cndmask_b32_e64 %5, %21, %13, %24\n\t"
+      "v_cndmask_b32_e64 %6, %22, %14, %24\n\tv_cndmask_b32_e64 %7, %23, %15, %24"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]),
+        "v"(y[5]), "v"(y[6]), "v"(y[7]), "s"(sel));
+}
+__device__ __forceinline__ uint32_t sp_both(uint64_t selA, uint64_t selB) {
+  uint32_t f;
+  uint64_t t;
+  asm("s_and_b64 %1, %2, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(f), "=&s"(t) : "s"(selA), "s"(selB) : "scc");
+  return f;
+}
+template <typename F>
+__device__ __forceinline__ void sp_split8(const F& v, uint32_t (&w)[8]) {
+  const uint64_t* p = reinterpret_cast<const uint64_t*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)p[i]; w[2 * i + 1] = (uint32_t)(p[i] >> 32); }
+}
+template <typename F>
+__device__ __forceinline__ F sp_join8(const uint32_t (&w)[8]) {
+  F r;
+  uint64_t* p = reinterpret_cast<uint64_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < 4; i++) p[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  return r;
+}
+#define SP_Q_WORDS {(uint32_t)SP_Q0, (uint32_t)(SP_Q0 >> 32), (uint32_t)SP_Q1, (uint32_t)(SP_Q1 >> 32), 0u, 0u, 0u, (uint32_t)(SP_Q3 >> 32)}
+#endif
+
 // t - q if t >= q else t   (t < 2q)
 SP_HD Fq fq_csub(const Fq& t) {
   const uint64_t Q[4] = {SP_Q0, SP_Q1, SP_Q2, SP_Q3};
@@ -70,7 +173,29 @@ SP_HD Fq fq_csub(const Fq& t) {
   for (int i = 0; i < 4; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
   return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FIELD_ADD_GENERIC)
+__device__ __forceinline__ Fq fq_add(const Fq& a, const Fq& b) {  // ristretto255.rs:736-745: s = a + b, then s - q unless that borrows
+  uint32_t aw[8], bw[8], s[8], d[8], r[8];
+  const uint32_t q[8] = SP_Q_WORDS;
+  sp_split8(a, aw); sp_split8(b, bw);
+  uint64_t cA, cB;
+  sp_chain2<0>(aw, bw, q, s, d, cA, cB);
+  sp_select8(r, s, d, cB);  // borrow: s < q, keep s
+  return sp_join8<Fq>(r);
+}
+__device__ __forceinline__ Fq fq_sub(const Fq& a, const Fq& b) {  // ristretto255.rs:718-733: d = a - b, plus q if that borrowed
+  uint32_t aw[8], bw[8], d[8], e[8], r[8];
+  const uint32_t q[8] = SP_Q_WORDS;
+  sp_split8(a, aw); sp_split8(b, bw);
+  uint64_t cA, cB;
+  sp_chain2<1>(aw, bw, q, d, e, cA, cB);
+  sp_select8(r, e, d, cA);
+  return sp_join8<Fq>(r);
+}
+__host__ inline Fq fq_add(const Fq& a, const Fq& b) {
+#else
 SP_HD Fq fq_add(const Fq& a, const Fq& b) {  // ristretto255.rs:736-745
+#endif
   Fq s;
   u128 c = 0;
 #pragma unroll
@@ -81,7 +206,11 @@ SP_HD Fq fq_add(const Fq& a, const Fq& b) {  // ristretto255.rs:736-745
   }
   return fq_csub(s);  // a,b < q < 2^253: no carry out
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FIELD_ADD_GENERIC)
+__host__ inline Fq fq_sub(const Fq& a, const Fq& b) {
+#else
 SP_HD Fq fq_sub(const Fq& a, const Fq& b) {  // ristretto255.rs:718-733
+#endif
   const uint64_t Q[4] = {SP_Q0, SP_Q1, SP_Q2, SP_Q3};
   Fq d;
   uint64_t borrow = 0;
@@ -304,7 +433,33 @@ SP_HD uint64_t fp_add_small(Fp& r, uint64_t x) {
   }
   return (uint64_t)c;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FIELD_ADD_GENERIC)
+__device__ __forceinline__ Fp fp_add(const Fp& a, const Fp& b) {  // s = a + b; if it left 2^256: s + 38 (2^256 = 38 mod p); a second wrap adds 38 once more
+  uint32_t aw[8], bw[8], s[8], t[8], r[8];
+  const uint32_t k[8] = {38u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  sp_split8(a, aw); sp_split8(b, bw);
+  uint64_t cA, cB;
+  sp_chain2<2>(aw, bw, k, s, t, cA, cB);
+  sp_select8(r, t, s, cA);
+  Fp o = sp_join8<Fp>(r);
+  o.v[0] += 38 * (uint64_t)sp_both(cA, cB);  // after a second wrap o < 38: cannot carry
+  return o;
+}
+__device__ __forceinline__ Fp fp_sub(const Fp& a, const Fp& b) {  // d = a - b; if it borrowed: d - 38; a second borrow takes 38 once more
+  uint32_t aw[8], bw[8], d[8], e[8], r[8];
+  const uint32_t k[8] = {38u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  sp_split8(a, aw); sp_split8(b, bw);
+  uint64_t cA, cB;
+  sp_chain2<3>(aw, bw, k, d, e, cA, cB);
+  sp_select8(r, e, d, cA);
+  Fp o = sp_join8<Fp>(r);
+  o.v[0] -= 38 * (uint64_t)sp_both(cA, cB);  // after a second wrap o >= 2^256 - 38: cannot borrow
+  return o;
+}
+__host__ inline Fp fp_add(const Fp& a, const Fp& b) {
+#else
 SP_HD Fp fp_add(const Fp& a, const Fp& b) {
+#endif
   Fp r;
   u128 c = 0;
 #pragma unroll
@@ -317,7 +472,11 @@ SP_HD Fp fp_add(const Fp& a, const Fp& b) {
   r.v[0] += 38 * c2;                                // second wrap leaves r < 38: cannot carry
   return r;
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FIELD_ADD_GENERIC)
+__host__ inline Fp fp_sub(const Fp& a, const Fp& b) {
+#else
 SP_HD Fp fp_sub(const Fp& a, const Fp& b) {
+#endif
   Fp r;
   uint64_t borrow = 0;
 #pragma unroll
