@@ -321,6 +321,17 @@ template <int V> __global__ void k_lib(uint32_t* out, const uint32_t* in, int it
     sp::Fe10 a = sp::fe10_load(x), b = sp::fe10_load(y), a2 = b, b2 = a;
     for (int it = 0; it < iters; it++) { a = sp::fe10_mul(a, b); a2 = sp::fe10_mul(a2, b2); b.v[0] ^= a2.v[1] & 0xff; b2.v[0] ^= a.v[1] & 0xff; }
     uint32_t s = 0; for (int i = 0; i < 10; i++) s ^= (uint32_t)(a.v[i] ^ a2.v[i]); out[tid] = s;
+  } else if (V == 4 || V == 5) {  // the product library's F_q multiplication (Montgomery, q = group order) and addition
+    sp::Fq a, b;
+    for (int i = 0; i < 4; i++) { a.l[i] = x.v[i]; b.l[i] = y.v[i]; }
+    a.l[3] &= 0x0fffffffffffffffULL; b.l[3] &= 0x0fffffffffffffffULL;  // < 2^252 < q
+    sp::Fq a2 = b, b2 = a;
+    for (int it = 0; it < iters; it++) {
+      if (V == 4) { a = sp::fq_mul(a, b); a2 = sp::fq_mul(a2, b2); }
+      else { a = sp::fq_add(a, b); a2 = sp::fq_sub(a2, b2); }
+      b.l[0] ^= a2.l[1] & 0xffff; b2.l[0] ^= a.l[1] & 0xffff;
+    }
+    uint64_t s = 0; for (int i = 0; i < 4; i++) s ^= a.l[i] ^ a2.l[i]; out[tid] = (uint32_t)s;
   } else {
     sp::Pt acc = sp::pt_identity();
     sp::Niels n{x, y, sp::fp_add(x, y)};
@@ -405,6 +416,7 @@ template <typename F> static double timeit(F launch, int reps) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--selftest")) return selftest();
+  const bool json = argc > 1 && !strcmp(argv[1], "--json");  // ceilings of the library's own arithmetic only, one JSON line (bench.py)
   const int blocks = 256 * 8, threads = 256, iters = 256;
   uint32_t* out; uint32_t* in; hipMalloc(&out, blocks * threads * 4); hipMalloc(&in, 64);
   uint32_t hin[16]; for (int i = 0; i < 16; i++) hin[i] = 0x9e3779b9u * (i + 1); hin[7] &= 0x7fffffff; hin[15] &= 0x0fffffff;
@@ -412,6 +424,15 @@ int main(int argc, char** argv) {
   double nmul = 2.0 * blocks * threads * iters;
   const char* names[] = {"A 8x32 operand-scan", "B 8x32 product-scan", "C 10x25.5", "D 4x64 int128", "E 5x51 int128", "Q fq mont 8x32 CIOS"};
   double ms;
+  if (json) {
+    double fp = nmul / timeit([&] { k_lib<0><<<blocks, threads>>>(out, in, iters); }, 5) / 1e6;
+    double fq = nmul / timeit([&] { k_lib<4><<<blocks, threads>>>(out, in, iters); }, 5) / 1e6;
+    double fa = nmul / timeit([&] { k_lib<5><<<blocks, threads>>>(out, in, iters); }, 5) / 1e6;
+    double ma = 0.5 * nmul / timeit([&] { k_lib<3><<<blocks, threads>>>(out, in, iters); }, 5) / 1e6;
+    double mad = 64.0 * blocks * threads * 1024 / timeit([&] { k_mad64<<<blocks, threads>>>(out, 1024); }, 5) / 1e6;
+    printf("{\"fp_mul_G_per_s\": %.2f, \"fq_mul_G_per_s\": %.2f, \"fq_addsub_G_per_s\": %.2f, \"pt_madd_G_per_s\": %.2f, \"v_mad_u64_u32_G_lane_ops_per_s\": %.1f}\n", fp, fq, fa, ma, mad);
+    return 0;
+  }
   ms = timeit([&] { k_chain<0><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[0], ms, nmul / ms / 1e6);
   ms = timeit([&] { k_chain<1><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[1], ms, nmul / ms / 1e6);
   ms = timeit([&] { k_chain<2><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[2], ms, nmul / ms / 1e6);
@@ -422,6 +443,8 @@ int main(int argc, char** argv) {
   ms = timeit([&] { k_lib<1><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fp_mul+fp_sqr pairs", ms, 2 * nmul / ms / 1e6);
   ms = timeit([&] { k_lib<2><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fe10_mul (10x25.5 s)", ms, nmul / ms / 1e6);
   ms = timeit([&] { k_lib<3><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gadd/s (x7 = %.1f Gmul/s)\n", "lib pt_madd", ms, 0.5 * nmul / ms / 1e6, 3.5 * nmul / ms / 1e6);
+  ms = timeit([&] { k_lib<4><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fq_mul (Montgomery)", ms, nmul / ms / 1e6);
+  ms = timeit([&] { k_lib<5><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gop/s\n", "lib fq_add / fq_sub", ms, nmul / ms / 1e6);
   double nop = 64.0 * blocks * threads * 1024;
   ms = timeit([&] { k_mad64<<<blocks, threads>>>(out, 1024); }, 5); printf("v_mad_u64_u32          %8.3f ms  %8.2f Gop/s (lane-ops)\n", ms, nop / ms / 1e6);
   ms = timeit([&] { k_mullo<<<blocks, threads>>>(out, 1024); }, 5); printf("v_mul_lo_u32(+add)     %8.3f ms  %8.2f Gop/s\n", ms, nop / ms / 1e6);

@@ -51,6 +51,16 @@ int32_t sp_prof_select(sp_ctx* ctx, const char* family);
 /* Fills up to cap entries; returns number of kernel families. name[i] is a static string. */
 int32_t sp_prof_read(sp_ctx* ctx, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap);
 
+/* Algorithmic operation counts of the same families (F_q multiplications of the sum-check / streaming kernels, mixed point
+ * additions of the MSM kernels assuming non-zero scalars): the numerators of the ALU roofline. */
+int32_t sp_prof_read_ops(sp_ctx* ctx, double* alg_ops, int cap);
+/* Per-launch-shape totals inside one family (msm_rows_fixed: shape = rows << 32 | cols, bit 63 set for launches on the
+ * background stream): returns the number of shapes seen, fills up to cap entries. */
+int32_t sp_prof_read_shapes(sp_ctx* ctx, const char* family, uint64_t* shape, double* total_ms, uint64_t* launches, double* alg_bytes,
+                            double* alg_ops, int cap);
+/* signed window width c of the fixed-base tables: a committed scalar costs ceil(254 / c) mixed additions */
+int sp_msm_window_bits(void);
+
 /* ---- generators: MultiCommitGens (src/commitments.rs:8-33) ------------------------------------------
  * A sp_gens is a list of n points P[0..n). A MultiCommitGens{G[0..m), h} made by
  * MultiCommitGens::new(m, label) is the list of its m+1 stream points with h = P[m]; gens that are prefixes

@@ -62,6 +62,10 @@ void prof_drain(sp_ctx* c) {
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
     c->prof_ms[r.fam] += ms;
     c->prof_n[r.fam] += 1;
+    if (r.shape) {
+      ProfShape& ps = c->prof_shapes[std::make_pair(r.fam, r.shape)];
+      ps.ms += ms; ps.n += 1; ps.bytes += r.bytes; ps.ops += r.ops;
+    }
     c->free_events.push_back(r.e0);
     c->free_events.push_back(r.e1);
   }
@@ -466,6 +470,7 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   memset(c->prof_ms, 0, sizeof c->prof_ms);
   memset(c->prof_n, 0, sizeof c->prof_n);
   memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+  memset(c->prof_ops, 0, sizeof c->prof_ops);
   {
     // main stream: the Fiat-Shamir critical path, highest priority; background stream: throughput MSMs queued under it,
     // lowest priority. (CU masks would be the cleaner partition, but hipExtStreamCreateWithCUMask is not honoured on this
@@ -537,8 +542,38 @@ int32_t sp_prof_reset(sp_ctx* c) {
   memset(c->prof_ms, 0, sizeof c->prof_ms);
   memset(c->prof_n, 0, sizeof c->prof_n);
   memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+  memset(c->prof_ops, 0, sizeof c->prof_ops);
+  c->prof_shapes.clear();
   return SP_OK;
 }
+int32_t sp_prof_read_ops(sp_ctx* c, double* alg_ops, int cap) {
+  if (!c || !alg_ops) return SP_EINVAL;
+  prof_drain(c);
+  for (int i = 0; i < PF_COUNT && i < cap; i++) alg_ops[i] = c->prof_ops[i];
+  return PF_COUNT;
+}
+int32_t sp_prof_read_shapes(sp_ctx* c, const char* family, uint64_t* shape, double* total_ms, uint64_t* launches, double* alg_bytes, double* alg_ops, int cap) {
+  if (!c || !family) return SP_EINVAL;
+  prof_drain(c);
+  int fam = -1;
+  for (int i = 0; i < PF_COUNT; i++)
+    if (strcmp(kProfNames[i], family) == 0) fam = i;
+  if (fam < 0) return SP_EINVAL;
+  int k = 0;
+  for (auto& kv : c->prof_shapes) {
+    if (kv.first.first != fam) continue;
+    if (k < cap) {
+      if (shape) shape[k] = kv.first.second;
+      if (total_ms) total_ms[k] = kv.second.ms;
+      if (launches) launches[k] = kv.second.n;
+      if (alg_bytes) alg_bytes[k] = kv.second.bytes;
+      if (alg_ops) alg_ops[k] = kv.second.ops;
+    }
+    k++;
+  }
+  return k;
+}
+int sp_msm_window_bits(void) { return MSM_WBITS; }
 int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap) {
   if (!c) return SP_EINVAL;
   prof_drain(c);
@@ -690,7 +725,9 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
                        g_off, didx, dblinds, h_idx, partial);
   } else {
     // K1: 32 B read per committed scalar + 32 B written per row
-    ProfScope ps = scope(PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows);
+    // ops: mixed additions if no scalar is zero; shape key: rows | cols | background launch
+    uint64_t shape = ((uint64_t)rows << 32) | (uint64_t)cols | (st != c->stream ? (1ULL << 63) : 0);
+    ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * MSM_NWIN, shape);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
     if (st != c->stream && !didx && !dblinds && c->bg_blocks > 0) {

@@ -413,7 +413,7 @@ int32_t sp_sumcheck_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntab
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
   Fq* partials = partials_dst(c, nblk, 3);
   {
-    ProfScope ps(c, PF_SC_EVAL, 32.0 * (double)len * (double)ntabs);
+    ProfScope ps(c, PF_SC_EVAL, 32.0 * (double)len * (double)ntabs, nullptr, (kind == 0 ? 2.0 : 6.0) * (double)half);
     if (kind == 0) hipLaunchKernelGGL(k_sc_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
     if (kind == 1) hipLaunchKernelGGL(k_sc_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
     if (kind == 2) hipLaunchKernelGGL(k_sc_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, half, partials);
@@ -496,7 +496,7 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
   Fq* partials = partials_dst(c, nblk, 3);
   {
-    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
+    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs, nullptr, (kind == 0 ? 6.0 : (kind == 1 ? 12.0 : 14.0)) * (double)quarter);
     if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -535,7 +535,7 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
   Fq* partials = partials_dst(c, nblk, 3);
   {
-    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs);
+    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs, nullptr, (kind == 0 ? 6.0 : (kind == 1 ? 12.0 : 14.0)) * (double)quarter);
     if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -572,7 +572,7 @@ int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, u
   Fq* partial = (Fq*)c->scratch;
   Fq* dres = partial + nchunks * R;
   {
-    ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R);
+    ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R, nullptr, (double)Z->len);
     hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
                        (const Fq*)Z->d, R, jchunk, partial);
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, dres);
@@ -591,7 +591,7 @@ int32_t sp_vecmat_dev(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* 
   SPCHK(table_new(c, R, false, out));
   Fq* partial = (Fq*)c->scratch;
   {
-    ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R);
+    ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R, nullptr, (double)Z->len);
     hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
                        (const Fq*)Z->d, R, jchunk, partial);
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, (*out)->d);
@@ -606,7 +606,7 @@ int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, si
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
   Fq* partials = partials_dst(c, nblk, 1);
   {
-    ProfScope ps(c, PF_DOT, 64.0 * (double)n);
+    ProfScope ps(c, PF_DOT, 64.0 * (double)n, nullptr, (double)n);
     hipLaunchKernelGGL(k_dot, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)(a->d + a_off), (const Fq*)(b->d + b_off), n, partials);
   }
   return reduce_and_fetch(c, partials, nblk, 1, out);

@@ -42,6 +42,12 @@ extern const char* kProfNames[PF_COUNT];
 struct ProfRec {
   hipEvent_t e0, e1;
   int fam;
+  uint64_t shape;  // launch shape inside the family (0 = not tracked): the MSM families key (rows, cols, background)
+  double bytes, ops;
+};
+struct ProfShape {
+  double ms = 0, bytes = 0, ops = 0;
+  uint64_t n = 0;
 };
 
 struct sp_ctx {
@@ -90,6 +96,8 @@ struct sp_ctx {
   double prof_ms[PF_COUNT];
   uint64_t prof_n[PF_COUNT];
   double prof_bytes[PF_COUNT];
+  double prof_ops[PF_COUNT];  // algorithmic field multiplications (F_q kernels) / mixed point additions (MSM kernels)
+  std::map<std::pair<int, uint64_t>, ProfShape> prof_shapes;
 };
 struct sp_gens {
   sp_ctx* ctx;
@@ -135,8 +143,10 @@ struct ProfScope {
   hipEvent_t e0, e1;
   bool on;
   hipStream_t st;  // the stream the timed kernels are launched on
-  ProfScope(sp_ctx* c_, int fam_, double bytes, hipStream_t st_ = nullptr)
-      : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)), st(st_ ? st_ : c_->stream) {
+  uint64_t shape;
+  double bytes, ops;
+  ProfScope(sp_ctx* c_, int fam_, double bytes_, hipStream_t st_ = nullptr, double ops_ = 0.0, uint64_t shape_ = 0)
+      : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)), st(st_ ? st_ : c_->stream), shape(shape_), bytes(bytes_), ops(ops_) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -151,12 +161,13 @@ struct ProfScope {
     e0 = get();
     e1 = get();
     c->prof_bytes[fam] += bytes;
+    c->prof_ops[fam] += ops;
     (void)hipEventRecord(e0, st);
   }
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, st);
-    c->pending.push_back(ProfRec{e0, e1, fam});
+    c->pending.push_back(ProfRec{e0, e1, fam, shape, bytes, ops});
   }
 };
 

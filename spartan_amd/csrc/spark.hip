@@ -353,7 +353,7 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
   Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
-    ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst);
+    ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, 6.0 * (double)half * (double)ninst);
     if (tiny) hipLaunchKernelGGL(k_cubic_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
     else hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
   }
@@ -375,7 +375,7 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
   Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
   {
-    ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst);
+    ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst, nullptr, 12.0 * (double)quarter * (double)ninst);
     if (tiny)
       hipLaunchKernelGGL(k_cubic_bind_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
                          limbs(r), partials);
@@ -404,7 +404,7 @@ int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1) * nt));
   Fq* partials = (Fq*)c->scratch;
   {
-    ProfScope ps(c, PF_DOT, 32.0 * (double)n * (double)(nt + 1));
+    ProfScope ps(c, PF_DOT, 32.0 * (double)n * (double)(nt + 1), nullptr, (double)n * (double)nt);
     hipLaunchKernelGGL(k_dot_many, dim3((unsigned)nblk, (unsigned)nt), dim3(256), 0, c->stream, (const Fq*)chi->d, (Fq* const*)c->hmap, n, partials);
   }
   {
@@ -421,7 +421,7 @@ int32_t sp_dot3(sp_ctx* c, const sp_table* l, const sp_table* r, const sp_table*
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1)));
   Fq* partials = partials_dst(c, nblk, 1);
   {
-    ProfScope ps(c, PF_DOT, 96.0 * (double)n);
+    ProfScope ps(c, PF_DOT, 96.0 * (double)n, nullptr, 2.0 * (double)n);
     hipLaunchKernelGGL(k_dot3, dim3((unsigned)nblk), dim3(256), 0, c->stream, (const Fq*)(l->d + off), (const Fq*)(r->d + off), (const Fq*)(w->d + off), n,
                        partials);
   }
