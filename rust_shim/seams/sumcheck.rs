@@ -1,0 +1,106 @@
+// src/sumcheck.rs — SumcheckInstanceProof::prove_cubic_batched (:254-424) under `--features gpu`.
+// The round body (:287-357 evaluations, :379-393 binds) is one C-ABI call per round, exactly as the C++ host driver issues
+// it (spartan_amd/host/spark.inc: prove_cubic_batched): sp_sumcheck_eval_batched once, then sp_sumcheck_bind_eval_batched
+// per round (bind at r_j fused with the next round's evaluations), and sp_table_bind_top_heads for the last round, which
+// also returns the final claims (:395-419). Every transcript operation stays where the reference has it.
+// comb_func is always the cubic product on this path (product_tree.rs:316-318), which is what the kernels compute.
+#[cfg(feature = "gpu")]
+impl SumcheckInstanceProof {
+  pub fn prove_cubic_batched_gpu(
+    claim: &Scalar,
+    num_rounds: usize,
+    poly_vec_par: (&mut Vec<&mut DensePolynomial>, &mut Vec<&mut DensePolynomial>, &mut DensePolynomial),
+    poly_vec_seq: (&mut Vec<&mut DensePolynomial>, &mut Vec<&mut DensePolynomial>, &mut Vec<&mut DensePolynomial>),
+    coeffs: &[Scalar],
+    transcript: &mut Transcript,
+  ) -> (Self, Vec<Scalar>, (Vec<Scalar>, Vec<Scalar>, Scalar), (Vec<Scalar>, Vec<Scalar>, Vec<Scalar>)) {
+    use super::gpu::{self, sp_table};
+    let (poly_A_vec_par, poly_B_vec_par, poly_C_par) = poly_vec_par;
+    let (poly_A_vec_seq, poly_B_vec_seq, poly_C_vec_seq) = poly_vec_seq;
+    let (np, ns) = (poly_A_vec_par.len(), poly_A_vec_seq.len());
+    let ni = np + ns;
+    let dev = |p: &DensePolynomial| -> *mut sp_table { p.dev.as_ref().expect("device-resident polynomial").0 };
+    // instance k = (A_k, B_k, C_k); the `par` instances share poly_C_par (the library binds a shared table once)
+    let mut A: Vec<*mut sp_table> = poly_A_vec_par.iter().map(|p| dev(p)).collect();
+    let mut B: Vec<*mut sp_table> = poly_B_vec_par.iter().map(|p| dev(p)).collect();
+    let mut C: Vec<*mut sp_table> = vec![dev(poly_C_par); np];
+    A.extend(poly_A_vec_seq.iter().map(|p| dev(p)));
+    B.extend(poly_B_vec_seq.iter().map(|p| dev(p)));
+    C.extend(poly_C_vec_seq.iter().map(|p| dev(p)));
+    // every table once, for the last round: A_i, B_i interleaved, then the distinct C tables
+    let mut all: Vec<*mut sp_table> = Vec::with_capacity(2 * ni + 1 + ns);
+    for i in 0..ni {
+      all.push(A[i]);
+      all.push(B[i]);
+    }
+    all.push(dev(poly_C_par));
+    all.extend(poly_C_vec_seq.iter().map(|p| dev(p)));
+
+    let mut e = *claim;
+    let mut r: Vec<Scalar> = Vec::new();
+    let mut cubic_polys: Vec<CompressedUniPoly> = Vec::new();
+    let mut ev = vec![Scalar::zero(); 3 * ni]; // (eval_point_0, eval_point_2, eval_point_3) per instance
+    let mut heads = vec![Scalar::zero(); all.len()];
+    let mut have_heads = false;
+    if num_rounds > 0 {
+      gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(gpu::ctx(), A.as_ptr(), B.as_ptr(), C.as_ptr(), ni, gpu::limbs_mut(&mut ev)) });
+    }
+    for _j in 0..num_rounds {
+      let evals_combined_0: Scalar = (0..ni).map(|i| ev[3 * i] * coeffs[i]).sum();
+      let evals_combined_2: Scalar = (0..ni).map(|i| ev[3 * i + 1] * coeffs[i]).sum();
+      let evals_combined_3: Scalar = (0..ni).map(|i| ev[3 * i + 2] * coeffs[i]).sum();
+      let evals = vec![evals_combined_0, e - evals_combined_0, evals_combined_2, evals_combined_3];
+      let poly = UniPoly::from_evals(&evals);
+      poly.append_to_transcript(b"poly", transcript);
+      let r_j = transcript.challenge_scalar(b"challenge_nextround");
+      r.push(r_j);
+      let len = unsafe { gpu::sp_table_len(A[0]) };
+      if len >= 4 {
+        gpu::ok(unsafe {
+          gpu::sp_sumcheck_bind_eval_batched(gpu::ctx(), A.as_ptr(), B.as_ptr(), C.as_ptr(), ni, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev))
+        });
+      } else {
+        gpu::ok(unsafe { gpu::sp_table_bind_top_heads(gpu::ctx(), all.as_ptr(), all.len(), gpu::limbs1(&r_j), gpu::limbs_mut(&mut heads)) });
+        have_heads = true;
+      }
+      e = poly.evaluate(&r_j);
+      cubic_polys.push(poly.compress());
+    }
+    if !have_heads {
+      gpu::ok(unsafe { gpu::sp_table_heads(gpu::ctx(), all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) });
+    }
+    // host-side bookkeeping of the bound polynomials (their tables were halved num_rounds times on the device)
+    for p in poly_A_vec_par.iter_mut().chain(poly_B_vec_par.iter_mut()).chain(poly_A_vec_seq.iter_mut())
+      .chain(poly_B_vec_seq.iter_mut()).chain(poly_C_vec_seq.iter_mut()) {
+      p.num_vars -= num_rounds;
+      p.len >>= num_rounds;
+    }
+    poly_C_par.num_vars -= num_rounds;
+    poly_C_par.len >>= num_rounds;
+
+    let claims_prod = (
+      (0..np).map(|k| heads[2 * k]).collect(),
+      (0..np).map(|k| heads[2 * k + 1]).collect(),
+      heads[2 * ni],
+    );
+    let claims_dotp = (
+      (0..ns).map(|k| heads[2 * (np + k)]).collect(),
+      (0..ns).map(|k| heads[2 * (np + k) + 1]).collect(),
+      (0..ns).map(|k| heads[2 * ni + 1 + k]).collect(),
+    );
+    (SumcheckInstanceProof::new(cubic_polys), r, claims_prod, claims_dotp)
+  }
+}
+
+// ZKSumcheckInstanceProof::prove_quad (:428-586) and ::prove_cubic_with_additive_term (:588-776): the round body becomes
+//   round 0:  sp_sumcheck_eval(kind, tabs) -> evals -> UniPoly -> comm_poly via sp_msm_indexed (gens_n ++ [h])
+//   round j:  sp_sumcheck_bind_eval_commit(kind, tabs, r_j, evals_next, gens, idx, cols, S, rows = 2, out_points)
+//             = bound_poly_var_top on every table (:485-486 / :673-676) fused with the next round's evaluations
+//               (:460-469 / :624-652), plus comm_eval and the DotProductProof's delta of THIS round on a second stream
+//               (their scalars are known as soon as r_j is); then sp_msm_indexed for (Cy, beta, next comm_poly).
+// kind 0 = A*B (prove_quad), kind 2 = A*(B*C - D) (prove_cubic_with_additive_term); tabs in that order.
+// Every commitment is a row of scalars over the generator index list (gens_n.G ..., gens_n.h, gens_1.G[0], gens_1.h) of
+// ONE device generator stream: `delta = b3*X + b5*h` style commitments over derived bases (nizk/mod.rs:197-205) are
+// rewritten over the original generators ((b3*x)*G + (b3*rX + b5)*h), and `gens_1.scale(r)` (nizk/mod.rs:479-480) becomes a
+// scalar factor r on that column — same group elements, hence the same 32 compressed bytes.
+// The complete C++ rendering of both provers, line-by-line against sumcheck.rs, is spartan_amd/host/prover.cc:469-587.

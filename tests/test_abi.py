@@ -29,3 +29,73 @@ def test_no_cpu_fallback_without_device():
     rc = capi.lib.sp_ctx_create(ctypes.c_int(0), ctypes.byref(h))
     assert rc == -3 and not h  # SP_EHIP: fails loudly, never computes on the CPU
     assert capi.lib.sp_strerror(rc).decode().startswith("HIP runtime error")
+
+
+def _header_protos():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_gpu_rs", os.path.join(ROOT, "rust_shim", "gen_gpu_rs.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    return gen, gen.parse_header()
+
+
+def test_rust_binding_matches_header():
+    """rust_shim/src/gpu.rs (the `extern "C"` block libspartan's `gpu` feature links against) declares every entry point of
+    include/spartan_hip.h with the same name, arity, pointer depth and constness — and nothing else. No Rust toolchain
+    exists here, so this is the mechanical check the binding gets."""
+    import re
+    gen, protos = _header_protos()
+    src = open(os.path.join(ROOT, "rust_shim", "src", "gpu.rs")).read()
+    block = src[src.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    rust = {}
+    for m in re.finditer(r"pub fn (sp_\w+)\((.*?)\)(?: -> ([^;]+))?;", block):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip()]
+        rust[m.group(1)] = ([a.split(":", 1)[1].strip() for a in args], (m.group(3) or "").strip())
+    assert sorted(rust) == sorted(p[0] for p in protos)
+    from spartan_amd import capi
+    assert sorted(rust) == sorted(capi.SYMBOLS)          # ... which are the symbols the shared library exports (test above)
+    for name, ret, params in protos:
+        rtypes, rret = rust[name]
+        assert len(rtypes) == len(params), name
+        for (ctype, _), rt in zip(params, rtypes):
+            assert rt == gen.rust_type(ctype), (name, ctype, rt)
+            assert rt.count("*") == ctype.count("*"), (name, ctype, rt)             # pointer depth
+            if ctype.startswith("const ") and "*" in ctype:
+                assert "*const" in rt, (name, ctype, rt)                              # constness of the pointee
+        assert rret == {"int32_t": "i32", "size_t": "usize", "int": "c_int", "const char*": "*const c_char", "void": ""}[ret], name
+    # the generator is idempotent: the committed file is what it emits today
+    committed = src
+    gen.emit()
+    assert open(os.path.join(ROOT, "rust_shim", "src", "gpu.rs")).read() == committed
+
+
+def test_rust_seams_call_only_declared_symbols():
+    """every `gpu::sp_*(...)` call in rust_shim/seams/*.rs and in the hand-written tail of gpu.rs names an entry point of the
+    header and passes as many arguments as the C prototype takes"""
+    import re, glob
+    _, protos = _header_protos()
+    arity = {p[0]: len(p[2]) for p in protos}
+    files = glob.glob(os.path.join(ROOT, "rust_shim", "seams", "*.rs")) + [os.path.join(ROOT, "rust_shim", "src", "gpu_tail.rs.in")]
+    ncalls = 0
+    for f in files:
+        src = re.sub(r"//[^\n]*", "", open(f).read())
+        for m in re.finditer(r"\b(sp_\w+)\s*\(", src):
+            name = m.group(1)
+            if name not in arity:
+                continue   # a Rust helper, not an FFI call
+            depth, i, nargs, cur = 1, m.end(), 0, ""
+            while depth:
+                ch = src[i]
+                if ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                if depth == 1 and ch == ",":
+                    nargs += 1; cur = ""
+                elif depth >= 1:
+                    cur += ch
+                i += 1
+            nargs += 1 if cur.strip() else 0
+            assert nargs == arity[name], (os.path.basename(f), name, nargs, arity[name])
+            ncalls += 1
+    assert ncalls >= 20
