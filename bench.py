@@ -187,6 +187,48 @@ def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
     return out
 
 
+def enable_sharding(P, ctx, dist, rank, world):
+    """row-shard every commitment of `ctx` over the ranks: RCCL inside the library when the job runs on the nccl backend
+    (rank 0 draws the ncclUniqueId, one broadcast hands it to everyone), the torch.distributed byte gather otherwise (gloo tests)"""
+    if dist.get_backend() == "nccl":
+        box = [P.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.set_commit_shard_rccl(rank, world, box[0])
+        return "rccl: ncclAllGather on device buffers inside libspartan_host.so"
+    ctx.set_commit_shard(dist, "cpu")
+    return "torch.distributed all_gather of bytes (%s), via callback" % dist.get_backend()
+
+
+def strong_scaling_leg(P, ctx, dist, rank, world, s, steps, dev):
+    """ONE proof over all ranks (lock-step, row-sharded commitments + all-gather), measured in the same command as the replica
+    throughput: every rank proves the seed-0 instance; the sharded bytes must equal the unsharded ones."""
+    import torch
+    N = 1 << s
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=0)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", 100)
+    run = lambda: P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    ref = run()
+    transport = enable_sharding(P, ctx, dist, rank, world)
+    if run() != ref:
+        raise RuntimeError("sharded proof differs from the unsharded proof")
+    ctx.shard_stats(reset=True)
+    dist_barrier(dist); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if run() != ref:
+            raise RuntimeError("sharded proof differs from the unsharded proof")
+    torch.cuda.synchronize(); dist_barrier(dist)
+    dt = dist_max(dist, time.perf_counter() - t0, dev if dist.get_backend() == "nccl" else "cpu")
+    st = ctx.shard_stats()
+    ctx.set_commit_shard_virtual(1)  # clears the sharding (and leaves the RCCL communicator)
+    enc.free(); gens.free(); inst.free()
+    return {"scaling": "strong", "value": N * steps / dt, "unit": "constraints/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "transport": transport,
+            "all_gathers_per_proof": st["gathers"] / steps, "all_gather_bytes_per_proof": st["bytes"] / steps, "byte_identical_to_unsharded": True,
+            "note": "one proof's latency over %d GPUs: only the two row commitments shard (K1); the ~500 Fiat-Shamir-ordered steps are replicated (DESIGN.md, multi-GPU)" % world}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +240,8 @@ def main():
     ap.add_argument("--no-side-metrics", action="store_true", help="skip the NIZK::prove / SNARK::encode side measurements")
     ap.add_argument("--concurrent", type=int, default=2, help="also measure K independent proofs in flight on the GPU (0 = skip); reported separately, never as `value`")
     ap.add_argument("--shard-commits", action="store_true", help="N>1: one proof, row commitments sharded over the ranks + all-gather (strong scaling)")
+    ap.add_argument("--strong-timeout", type=int, default=120, help="seconds the strong-scaling leg may take before the job prints what it has and exits")
+    ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling leg (one sharded proof) that follows the replica measurement")
     ap.add_argument("--phases", action="store_true", help="also print the per-phase span times (timer.rs names) to stderr")
     args = ap.parse_args()
 
@@ -252,7 +296,7 @@ def main():
     ceil = measured_ceilings() if rank == 0 else None
     if sharded:
         proof = step()  # unsharded bytes: every sharded proof below must equal them
-        ctx.set_commit_shard(dist, dev if dist.get_backend() == "nccl" else "cpu")
+        shard_transport = enable_sharding(P, ctx, dist, rank, world)
     for _ in range(args.warmup):
         p2 = step()
         if proof is not None and p2 != proof:
@@ -270,8 +314,7 @@ def main():
     if not os.environ.get("BENCH_NO_PROF"):
         capi.lib.sp_prof_select(raw, dom.encode()); capi.lib.sp_prof_enable(raw, ctypes.c_int(1))
     if sharded:
-        from spartan_amd import shard
-        shard.STATS.update(gathers=0, bytes=0)
+        ctx.shard_stats(reset=True)
     dist_barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -286,6 +329,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = dist_max(dist, dt, dev if dist is not None and dist.get_backend() == "nccl" else "cpu")
     capi.lib.sp_prof_enable(raw, ctypes.c_int(0))
+    n_ranks_seen = int(round(dist_sum(dist, 1.0, dev if dist is not None and dist.get_backend() == "nccl" else "cpu")))
+    strong = None
     fam = read_prof() or {dom: breakdown[dom]}
     shapes = read_shapes(dom) if dom == "msm_rows_fixed" else []
     capi.lib.sp_prof_select(raw, None)
@@ -383,8 +428,11 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         if sharded:
-            out["config"]["all_gathers_per_proof"] = shard.STATS["gathers"] / args.steps
-            out["config"]["all_gather_bytes_per_proof"] = shard.STATS["bytes"] / args.steps
+            st_ = ctx.shard_stats()
+            out["config"]["all_gathers_per_proof"] = st_["gathers"] / args.steps
+            out["config"]["all_gather_bytes_per_proof"] = st_["bytes"] / args.steps
+            out["config"]["shard_transport"] = shard_transport
+        out["n_ranks_seen"] = n_ranks_seen
         if args.concurrent > 1 and world == 1:
             out["throughput_concurrent"] = concurrent_throughput(P, local_rank, s, args.concurrent, max(2, args.steps))
         if world == 1 and not args.no_side_metrics:
@@ -404,6 +452,29 @@ def main():
                 out["cpu_baseline_multicore"] = cpu_baseline(args.cpu_log2_cons, threads=nthr)
         if args.phases:
             print("phases (s):", json.dumps({k_: round(v, 5) for k_, v in phase.items()}), file=sys.stderr)
+    else:
+        out = None
+    if dist is not None and not sharded and not args.no_strong:
+        # The same command also reports ONE proof's latency over all ranks (strong scaling). It runs after everything above is
+        # measured; a watchdog guarantees the job ends (and rank 0 still prints the replica line) if a collective of this leg hangs.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["strong"] = {"scaling": "strong", "error": "timed out after %d s" % args.strong_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(args.strong_timeout, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            strong = strong_scaling_leg(P, ctx, dist, rank, world, s, max(2, args.steps), dev)
+        except Exception as e:  # noqa: BLE001  (reported, not fatal: the headline is the replica throughput above)
+            strong = {"scaling": "strong", "error": repr(e)[:300]}
+        wd.cancel()
+        if rank == 0:
+            out["strong"] = strong
+    if rank == 0:
         print(json.dumps(out))
     enc.free(); gens.free(); inst.free(); ctx.close()
     if dist is not None:

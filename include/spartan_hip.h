@@ -42,6 +42,9 @@ const char* sp_version(void);
 /* ---- context --------------------------------------------------------------------------------------- */
 int32_t sp_ctx_create(int device_id, sp_ctx** out);
 void sp_ctx_destroy(sp_ctx* ctx);
+/* Waits until everything queued on the context has run (calls that return results already do; calls that only enqueue —
+ * sp_eq_expand, sp_gather, sp_hash_layer, sp_table_copy ... — do not). */
+int32_t sp_ctx_sync(sp_ctx* ctx);
 /* HIP-event timing of every kernel family on the context's stream (bench.py's roofline numbers). */
 int32_t sp_prof_enable(sp_ctx* ctx, int on);
 int32_t sp_prof_reset(sp_ctx* ctx);

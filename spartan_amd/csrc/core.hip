@@ -522,6 +522,12 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+int32_t sp_ctx_sync(sp_ctx* c) {
+  if (!c) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(sync_spin(c));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
 int32_t sp_prof_enable(sp_ctx* c, int on) {
   if (!c) return SP_EINVAL;
   prof_drain(c);

@@ -45,6 +45,22 @@ int spz_ctx_set_commit_shard(void* c, int rank, int world, CommitGatherFn gather
   }
 }
 
+// RCCL inside the library (shard.cc): rank 0 draws the id, the caller distributes it, every rank joins; 0 = ok
+int spz_rccl_unique_id(uint8_t out[128]) {
+  try { rccl_unique_id(out); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int spz_ctx_set_commit_shard_rccl(void* c, int rank, int world, const uint8_t unique_id[128]) {
+  try { set_commit_shard_rccl(*(Ctx*)c, rank, world, unique_id); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// W shards on one GPU, in-process gather (the partitioning logic without a second GPU); nshards <= 1 clears it
+int spz_ctx_set_commit_shard_virtual(void* c, int nshards) {
+  try { set_commit_shard_virtual(*(Ctx*)c, nshards); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+void spz_ctx_shard_stats(void* c, int reset, uint64_t out[2]) {
+  ShardStats s = commit_shard_stats(*(Ctx*)c, reset != 0);
+  out[0] = s.gathers; out[1] = s.bytes;
+}
+
 // Instance::new (lib.rs:121-128): entries of A, B, C back to back as (row, col, [u8;32] canonical little-endian value).
 // Errors mirror R1CSError: "InvalidIndex", "InvalidScalar" (spz_last_error()).
 void* spz_instance_new(void* ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const size_t nnz[3], const uint64_t* rows,

@@ -34,13 +34,30 @@ struct Ctx {
   ~Ctx();
   Ctx(const Ctx&) = delete;
 };
-// Row-sharded DensePolynomial::commit across the ranks of one node: every rank runs the same proof in
-// lock-step; for a commitment of L rows rank r computes rows [r L/W, (r+1) L/W) and `gather` exchanges the 32-byte
-// compressed commitments (an all-gather of bytes: there is no elliptic-curve reduction in RCCL and none is needed).
-// gather(user, buf, total, off, len): on entry buf[off, off+len) holds this rank's bytes; on return buf[0,total) is complete.
+// Row-sharded DensePolynomial::commit across the GPUs of one node (spartan_amd/host/shard.cc): every rank
+// runs the same proof in lock-step; for a commitment of L rows rank r computes rows [r L/W, (r+1) L/W) and the 32-byte
+// compressed commitments are exchanged with one all-gather of bytes (rows are independent MSMs: no elliptic-curve
+// reduction exists in RCCL and none is needed). Three transports:
+//   set_commit_shard_rccl     RCCL inside the library: rank 0 draws the id (rccl_unique_id), the caller hands it to every
+//                             rank by whatever channel it has, each rank joins with ncclCommInitRank; commits then use
+//                             ncclAllGather on device buffers. librccl.so is dlopen'ed on first use.
+//   set_commit_shard          the caller moves the bytes: gather(user, buf, total, off, len) — on entry buf[off, off+len)
+//                             holds this rank's bytes, on return buf[0, total) is complete (tests: gloo)
+//   set_commit_shard_virtual  W shards on ONE GPU (W sub-contexts, in-process gather): the partitioning under test
+// world <= 1 (or nshards <= 1) clears the setting. All ranks must then run identical prove() calls.
 void unipoly_probe(const FqVec& evals, const Fq& r, FqVec* coeffs, FqVec* compressed, Fq* eval_at_r);  // test hook
 typedef int (*CommitGatherFn)(void* user, uint8_t* buf, size_t total, size_t off, size_t len);
-void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user);  // world <= 1 clears it
+void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user);
+void rccl_unique_id(uint8_t out[128]);
+void set_commit_shard_rccl(Ctx& c, int rank, int world, const uint8_t unique_id[128]);
+void set_commit_shard_virtual(Ctx& c, int nshards);
+struct ShardStats { size_t gathers = 0, bytes = 0; };  // exchanges since the last reset (bench.py reports them per proof)
+ShardStats commit_shard_stats(Ctx& c, bool reset);
+// internal to the driver (prover.cc <-> shard.cc)
+bool commit_shard_active(sp_ctx* c);
+void commit_shard_forget(sp_ctx* c);
+bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,
+                         uint8_t* out);
 struct DevTable {  // DensePolynomial with Z resident in HBM (src/dense_mlpoly.rs:14-18)
   sp_ctx* c = nullptr;
   sp_table* h = nullptr;

@@ -100,31 +100,9 @@ static size_t log_2(size_t n) {  // math.rs:21-29: ceil for non powers of two
 static size_t next_pow2(size_t n) { return pow2(log_2(n == 0 ? 1 : n)); }
 
 // ------------------------------------------------------------------ handles
-namespace {
-struct CommitShard {
-  int rank = 0, world = 1;
-  CommitGatherFn gather = nullptr;
-  void* user = nullptr;
-};
-std::mutex g_shard_mu;
-std::map<sp_ctx*, CommitShard> g_shard;  // poly_commit only sees the sp_ctx*; 3 look-ups per proof
-CommitShard commit_shard_of(sp_ctx* c) {
-  std::lock_guard<std::mutex> lk(g_shard_mu);
-  auto it = g_shard.find(c);
-  return it == g_shard.end() ? CommitShard() : it->second;
-}
-}  // namespace
-static bool commit_shard_active(sp_ctx* c) { return commit_shard_of(c).world > 1; }
-void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user) {
-  std::lock_guard<std::mutex> lk(g_shard_mu);
-  if (world <= 1) { g_shard.erase(c.h); return; }
-  REQUIRE(gather && rank >= 0 && rank < world);
-  CommitShard s; s.rank = rank; s.world = world; s.gather = gather; s.user = user;
-  g_shard[c.h] = s;
-}
 Ctx::Ctx(int device) { SPX(sp_ctx_create(device, &h)); }
 Ctx::~Ctx() {
-  { std::lock_guard<std::mutex> lk(g_shard_mu); g_shard.erase(h); }
+  commit_shard_forget(h);
   sp_ctx_destroy(h);
 }
 DevTable::~DevTable() { sp_table_free(h); }
@@ -342,14 +320,9 @@ static PolyCommitment poly_commit(sp_ctx* c, const DevTable& Z, size_t num_vars,
   REQUIRE(g.n() == Rs && Z.len() == Ls * Rs);
   REQUIRE(!blinds || blinds->size() == Ls);
   std::vector<uint8_t> out(32 * Ls);
-  CommitShard sh = commit_shard_of(c);
-  if (sh.world > 1 && Ls % (size_t)sh.world == 0 && Ls / sh.world >= 8) {  // rows are independent MSMs over shared generators
-    size_t per = Ls / sh.world, lo = per * sh.rank;
-    SPX(sp_commit_rows_dev(c, g.g, g.G[0], g.h, Z.h, lo * Rs, per, Rs, blinds ? U(*blinds) + 4 * lo : nullptr, out.data() + 32 * lo));
-    if (sh.gather(sh.user, out.data(), out.size(), 32 * lo, 32 * per) != 0) throw Error("commit shard gather failed");
-  } else {
+  // rows are independent MSMs over shared generators: sharded over the ranks / virtual shards of the context when configured
+  if (!sharded_commit_rows(c, g.g, g.G[0], g.h, Z.h, Ls, Rs, blinds ? U(*blinds) : nullptr, out.data()))
     SPX(sp_commit_rows_dev(c, g.g, g.G[0], g.h, Z.h, 0, Ls, Rs, blinds ? U(*blinds) : nullptr, out.data()));
-  }
   PolyCommitment pc;
   pc.C.resize(Ls);
   for (size_t i = 0; i < Ls; i++) pc.C[i] = to_cp(&out[32 * i]);

@@ -1,0 +1,227 @@
+// spartan_amd host driver: row-sharded commitments across the GPUs of one node — inside the library.
+//
+// Every rank runs the same proof in lock-step (same instance, tape seed and transcript). For a DensePolynomial::commit
+// (dense_mlpoly.rs:179-204) of L rows, rank r computes rows [r L/W, (r+1) L/W) on its GPU; the 32-byte compressed
+// commitments are exchanged with ONE all-gather of bytes per commitment. Rows are independent MSMs over shared generators,
+// so there is no elliptic-curve reduction to do (RCCL has no such operator; "all-reduce of partial bucket sums" would be
+// an all-gather plus local point additions, and is only needed when a single row is too wide for one GPU).
+// Three transports behind one code path (partition, blind offsets, result layout are shared):
+//   rccl     ncclAllGather on device buffers, on the context's stream. librccl.so is dlopen'ed on first use: a single-GPU
+//            deployment, and the CPU-only test box, never load it.
+//   callback the caller moves the bytes (tests: torch.distributed over gloo)
+//   virtual  W shards on ONE physical GPU: W sub-contexts (own streams, shared generator tables) compute their row ranges
+//            concurrently and the "gather" is a memcpy — the partitioning logic under test without a second GPU
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
+
+#include "libspartan.hpp"
+
+namespace spz {
+namespace {
+
+// ---- the slice of RCCL's API this file uses (rccl/rccl.h), bound at run time
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef void* ncclComm_p;
+typedef int (*fn_ncclGetUniqueId)(ncclUniqueId_t*);
+typedef int (*fn_ncclCommInitRank)(ncclComm_p*, int, ncclUniqueId_t, int);
+typedef int (*fn_ncclAllGather)(const void*, void*, size_t, int /*ncclDataType_t: ncclUint8 = 1*/, ncclComm_p, hipStream_t);
+typedef int (*fn_ncclCommDestroy)(ncclComm_p);
+typedef const char* (*fn_ncclGetErrorString)(int);
+struct Rccl {
+  void* lib = nullptr;
+  fn_ncclGetUniqueId GetUniqueId = nullptr;
+  fn_ncclCommInitRank CommInitRank = nullptr;
+  fn_ncclAllGather AllGather = nullptr;
+  fn_ncclCommDestroy CommDestroy = nullptr;
+  fn_ncclGetErrorString GetErrorString = nullptr;
+};
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (x.lib) break;
+    }
+    if (x.lib) {
+      x.GetUniqueId = (fn_ncclGetUniqueId)dlsym(x.lib, "ncclGetUniqueId");
+      x.CommInitRank = (fn_ncclCommInitRank)dlsym(x.lib, "ncclCommInitRank");
+      x.AllGather = (fn_ncclAllGather)dlsym(x.lib, "ncclAllGather");
+      x.CommDestroy = (fn_ncclCommDestroy)dlsym(x.lib, "ncclCommDestroy");
+      x.GetErrorString = (fn_ncclGetErrorString)dlsym(x.lib, "ncclGetErrorString");
+      if (!x.GetUniqueId || !x.CommInitRank || !x.AllGather || !x.CommDestroy) { dlclose(x.lib); x.lib = nullptr; }
+    }
+    return x;
+  }();
+  return r;
+}
+void need_rccl() {
+  if (!rccl().lib) throw Error("librccl.so could not be loaded: RCCL sharding is unavailable on this machine");
+}
+void nccl_ok(int rc, const char* what) {
+  if (rc != 0) throw Error(std::string(what) + " failed: " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "nccl error") + " (" + std::to_string(rc) + ")");
+}
+void hip_ok(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw Error(std::string(what) + " failed: " + hipGetErrorString(e));
+}
+
+struct ShardState {
+  int mode = 0;  // 0 none, 1 callback, 2 rccl, 3 virtual
+  int rank = 0, world = 1;
+  CommitGatherFn gather = nullptr;
+  void* user = nullptr;
+  ncclComm_p comm = nullptr;
+  hipStream_t stream = nullptr;  // rccl: the collective's stream
+  uint8_t* dbuf = nullptr;       // rccl: device staging [send | recv]
+  size_t dbuf_bytes = 0;
+  std::vector<sp_ctx*> vctx;     // virtual: sub-contexts 1..W-1 (shard 0 runs on the owning context)
+  ShardStats stats;
+};
+std::mutex g_mu;
+std::map<sp_ctx*, ShardState> g_state;
+
+void release(ShardState& s) {
+  for (sp_ctx* v : s.vctx) sp_ctx_destroy(v);
+  s.vctx.clear();
+  if (s.comm && rccl().CommDestroy) (void)rccl().CommDestroy(s.comm);
+  s.comm = nullptr;
+  if (s.dbuf) (void)hipFree(s.dbuf);
+  s.dbuf = nullptr;
+  if (s.stream) (void)hipStreamDestroy(s.stream);
+  s.stream = nullptr;
+}
+
+}  // namespace
+
+bool commit_shard_active(sp_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c);
+  return it != g_state.end() && it->second.mode != 0 && it->second.world > 1;
+}
+void commit_shard_forget(sp_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c);
+  if (it == g_state.end()) return;
+  release(it->second);
+  g_state.erase(it);
+}
+void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user) {
+  commit_shard_forget(c.h);
+  if (world <= 1) return;
+  if (!gather || rank < 0 || rank >= world) throw Error("set_commit_shard: bad arguments");
+  std::lock_guard<std::mutex> lk(g_mu);
+  ShardState& s = g_state[c.h];
+  s.mode = 1; s.rank = rank; s.world = world; s.gather = gather; s.user = user;
+}
+void rccl_unique_id(uint8_t out[128]) {
+  need_rccl();
+  ncclUniqueId_t id;
+  nccl_ok(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(out, id.internal, 128);
+}
+void set_commit_shard_rccl(Ctx& c, int rank, int world, const uint8_t unique_id[128]) {
+  commit_shard_forget(c.h);
+  if (world < 1 || rank < 0 || rank >= world || !unique_id) throw Error("set_commit_shard_rccl: bad arguments");
+  need_rccl();
+  ShardState s;
+  s.mode = 2; s.rank = rank; s.world = world;
+  ncclUniqueId_t id;
+  memcpy(id.internal, unique_id, 128);
+  hip_ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+  try {
+    nccl_ok(rccl().CommInitRank(&s.comm, world, id, rank), "ncclCommInitRank");
+  } catch (...) {
+    release(s);
+    throw;
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_state[c.h] = s;
+}
+void set_commit_shard_virtual(Ctx& c, int nshards) {
+  commit_shard_forget(c.h);
+  if (nshards <= 1) return;
+  ShardState s;
+  s.mode = 3; s.rank = 0; s.world = nshards;
+  int dev = 0;
+  hip_ok(hipGetDevice(&dev), "hipGetDevice");
+  for (int k = 1; k < nshards; k++) {
+    sp_ctx* v = nullptr;
+    if (sp_ctx_create(dev, &v) != SP_OK) { release(s); throw Error("set_commit_shard_virtual: sp_ctx_create failed"); }
+    s.vctx.push_back(v);
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_state[c.h] = s;
+}
+ShardStats commit_shard_stats(Ctx& c, bool reset) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c.h);
+  if (it == g_state.end()) return ShardStats();
+  ShardStats r = it->second.stats;
+  if (reset) it->second.stats = ShardStats();
+  return r;
+}
+
+// DensePolynomial::commit_inner over the shards of the context; returns false when the commitment is not sharded (no
+// sharding configured, or too few rows per shard) and the caller takes the single-GPU path.
+bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,
+                         uint8_t* out /*32*Ls*/) {
+  ShardState* sp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_state.find(c);
+    if (it == g_state.end() || it->second.mode == 0) return false;
+    sp = &it->second;  // entries are only removed by the owning thread (set_* / ~Ctx)
+  }
+  ShardState& s = *sp;
+  size_t W = (size_t)s.world;
+  if (W <= 1 && s.mode != 2) return false;
+  if (Ls % W != 0 || Ls / W <= 8) return false;  // rows are independent MSMs: shard only when every rank gets a real batch
+  size_t per = Ls / W;
+  auto chk = [](int32_t rc, const char* what) { if (rc != SP_OK) throw Error(std::string(what) + " failed: " + sp_strerror(rc)); };
+  if (s.mode == 3) {
+    // virtual shards: shard k on its own context (own streams) of the same GPU, all in flight together
+    chk(sp_ctx_sync(c), "sp_ctx_sync");  // Z as produced by everything queued on the owning context
+    std::vector<sp_job*> jobs(W, nullptr);
+    try {
+      for (size_t k = 0; k < W; k++) {
+        sp_ctx* ck = k == 0 ? c : s.vctx[k - 1];
+        chk(sp_commit_rows_dev_start(ck, g, g_off, h_idx, Z, k * per * Rs, per, Rs, blinds ? blinds + 4 * k * per : nullptr, &jobs[k]), "sp_commit_rows_dev_start");
+      }
+      for (size_t k = 0; k < W; k++) {
+        sp_job* j = jobs[k];
+        jobs[k] = nullptr;
+        chk(sp_job_wait(j, out + 32 * k * per), "sp_job_wait");
+      }
+    } catch (...) {
+      std::vector<uint8_t> sink(32 * per);
+      for (sp_job* j : jobs) if (j) (void)sp_job_wait(j, sink.data());
+      throw;
+    }
+    s.stats.gathers++; s.stats.bytes += 32 * Ls;
+    return true;
+  }
+  size_t lo = per * (size_t)s.rank;
+  chk(sp_commit_rows_dev(c, g, g_off, h_idx, Z, lo * Rs, per, Rs, blinds ? blinds + 4 * lo : nullptr, out + 32 * lo), "sp_commit_rows_dev");
+  if (s.mode == 1) {
+    if (s.gather(s.user, out, 32 * Ls, 32 * lo, 32 * per) != 0) throw Error("commit shard gather failed");
+  } else {
+    // RCCL: all-gather of the compressed commitments on device buffers (32*per bytes from each rank, rank order)
+    size_t need = 32 * per + 32 * Ls;
+    if (s.dbuf_bytes < need) {
+      if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
+      s.dbuf = nullptr;
+      hip_ok(hipMalloc((void**)&s.dbuf, need), "hipMalloc");
+      s.dbuf_bytes = need;
+    }
+    hip_ok(hipMemcpyAsync(s.dbuf, out + 32 * lo, 32 * per, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+    nccl_ok(rccl().AllGather(s.dbuf, s.dbuf + 32 * per, 32 * per, 1 /*ncclUint8*/, s.comm, s.stream), "ncclAllGather");
+    hip_ok(hipMemcpyAsync(out, s.dbuf + 32 * per, 32 * Ls, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+    hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+  }
+  s.stats.gathers++; s.stats.bytes += 32 * Ls;
+  return true;
+}
+
+}  // namespace spz

@@ -37,8 +37,8 @@ class Ctx:
         return vp(H.spz_ctx_raw(self.h))
 
     def set_commit_shard(self, dist, device="cpu"):
-        """row-shard every DensePolynomial::commit over the ranks of `dist` (spartan_amd/shard.py); None clears it. All
-        ranks must then run identical prove() calls in lock-step."""
+        """row-shard every DensePolynomial::commit over the ranks of `dist`, the bytes moved by torch.distributed
+        (spartan_amd/shard.py; gloo in the CPU tests); None clears it. All ranks must then run identical prove() calls in lock-step."""
         from . import shard
         if dist is None or dist.get_world_size() == 1:
             H.spz_ctx_set_commit_shard(self.h, ctypes.c_int(0), ctypes.c_int(1), None, None); self._gather = None
@@ -46,6 +46,22 @@ class Ctx:
         self._gather = shard.make_gather_callback(dist, device)
         if H.spz_ctx_set_commit_shard(self.h, ctypes.c_int(dist.get_rank()), ctypes.c_int(dist.get_world_size()), self._gather, None) != 0:
             raise SpartanHipError(f"set_commit_shard: {H.spz_last_error().decode()}")
+
+    def set_commit_shard_rccl(self, rank, world, unique_id):
+        """the same with RCCL inside the library: `unique_id` = the 128 bytes rank 0 got from rccl_unique_id(), handed to
+        every rank by the caller (bench.py: one torch.distributed broadcast); ncclAllGather on device buffers per commit"""
+        if H.spz_ctx_set_commit_shard_rccl(self.h, ctypes.c_int(rank), ctypes.c_int(world), unique_id) != 0:
+            raise SpartanHipError(f"set_commit_shard_rccl: {H.spz_last_error().decode()}")
+
+    def set_commit_shard_virtual(self, nshards):
+        """nshards row shards on this one GPU (sub-contexts with their own streams, in-process gather); <= 1 clears it"""
+        if H.spz_ctx_set_commit_shard_virtual(self.h, ctypes.c_int(nshards)) != 0:
+            raise SpartanHipError(f"set_commit_shard_virtual: {H.spz_last_error().decode()}")
+
+    def shard_stats(self, reset=False):
+        out = (ctypes.c_uint64 * 2)()
+        H.spz_ctx_shard_stats(self.h, ctypes.c_int(1 if reset else 0), out)
+        return {"gathers": int(out[0]), "bytes": int(out[1])}
 
     def close(self):
         if self.h:
@@ -103,6 +119,14 @@ class NIZKGens:
     def free(self):
         if self.h:
             H.spz_nizk_gens_free(self.h); self.h = None
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls it; the 128 bytes go to every rank)"""
+    out = (ctypes.c_uint8 * 128)()
+    if H.spz_rccl_unique_id(out) != 0:
+        raise SpartanHipError(f"rccl_unique_id: {H.spz_last_error().decode()}")
+    return bytes(out)
 
 
 def seed_scalar(domain, seed):

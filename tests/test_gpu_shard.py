@@ -32,3 +32,77 @@ def test_sharded_commit_proof_is_byte_identical(s):
     assert line["config"]["all_gathers_per_proof"] == 2
     assert line["config"]["all_gather_bytes_per_proof"] == 32 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))
     assert line["value"] == pytest.approx((1 << s) / (line["ms_per_step"] * 1e-3), rel=1e-6)  # one proof, not two
+
+
+def test_default_multi_rank_run_reports_replicas_and_strong_leg():
+    """`bench.py --gpus 2` as the driver launches it (no --shard-commits): the headline is the replica throughput
+    ("weak": one independent proof per rank, no data-path collective) and the same command adds the strong-scaling leg
+    (one proof, row commitments sharded, byte-identical to the unsharded proof). Two gloo ranks on the one GPU of the box."""
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_NO_PROF="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-cons", "14", "--steps", "2", "--warmup", "1"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    line = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["n_ranks_seen"] == 2
+    assert line["value"] == pytest.approx(2 * (1 << 14) / (line["ms_per_step"] * 1e-3), rel=1e-6)  # two proofs per step
+    st = line["strong"]
+    assert "error" not in st, st
+    assert st["scaling"] == "strong" and st["byte_identical_to_unsharded"] and st["all_gathers_per_proof"] == 2
+    assert st["value"] == pytest.approx((1 << 14) / (st["ms_per_step"] * 1e-3), rel=1e-6)             # one proof per step
+    assert not [l for l in outs[1].splitlines() if l.startswith("{")]                                   # rank 0 alone prints
+
+
+@pytest.mark.parametrize("s,nshards", [(14, 8), (16, 4)])
+def test_virtual_shards_on_one_gpu_are_byte_identical(s, nshards):
+    """SURVEY §8e "Test reality": W row shards on one physical GPU (W sub-contexts with their own streams, in-process gather).
+    Partition, blind offsets and result layout are the code the RCCL path runs; the proof must not change."""
+    from spartan_amd import prover as P
+    N = 1 << s
+    ctx = P.Ctx(0)
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", s)
+    ref = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    ctx.set_commit_shard_virtual(nshards)
+    ctx.shard_stats(reset=True)
+    got = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    st = ctx.shard_stats()
+    assert got == ref
+    assert st["gathers"] == 2 and st["bytes"] == 32 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))   # witness + derefs commitments
+    enc2 = P.SNARK.encode(ctx, inst, gens)    # SNARK::encode's multi_commit shards the same way
+    assert enc2.serialize_commitment() == enc.serialize_commitment()
+    ctx.set_commit_shard_virtual(1)
+    assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
+    enc2.free(); enc.free(); gens.free(); inst.free(); ctx.close()
+
+
+def test_rccl_transport_inside_the_library_single_rank():
+    """the RCCL path of spartan_amd/host/shard.cc on the one GPU of the box: librccl.so is dlopen'ed, rank 0 draws the
+    ncclUniqueId, joins a 1-rank communicator, and every commitment goes through ncclAllGather on device buffers."""
+    from spartan_amd import prover as P
+    s = 12
+    N = 1 << s
+    ctx = P.Ctx(0)
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=1)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", 2)
+    ref = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    uid = P.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.set_commit_shard_rccl(0, 1, uid)
+    ctx.shard_stats(reset=True)
+    assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
+    # with one rank the witness commitment keeps its overlapped single-GPU path; the derefs commitment goes through RCCL
+    assert ctx.shard_stats()["gathers"] >= 1
+    ctx.set_commit_shard_virtual(1)
+    enc.free(); gens.free(); inst.free(); ctx.close()
