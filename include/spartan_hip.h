@@ -226,6 +226,25 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* cons
  * once, out of place. Requires current length >= 4. */
 int32_t sp_sumcheck_bind_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst,
                                       const uint64_t r[4], uint64_t* out);
+/* TWO rounds per call, for the latency-bound rounds of prove_cubic_batched (a round trip to the device costs more than the
+ * arithmetic of a short round). The evaluations of the round after a bind are a cubic in that bind's challenge r:
+ *   E(t; r) = (1-r)^3 M0(t) + (1-r)^2 r M1(t) + (1-r) r^2 M2(t) + r^3 M3(t),   M1 = (T1 - T2)/2 - M3,  M2 = (T1 + T2)/2 - M0,
+ * so a caller that holds (M0, M3, T1, T2) for t = 0, 2, 3 can derive the next challenge, evaluate the round after it and
+ * derive that challenge too before it talks to the device again.
+ *   sp_sumcheck_eval_coeffs_batched: the tables as they are (current length n >= 2): out_evals[12*ninst] as
+ *     sp_sumcheck_eval_batched, and, when n >= 4, out_coeffs[48*ninst] = per instance, for t = 0, 2, 3: M0, M3, T1, T2 of the
+ *     round that follows a bind of these tables.
+ *   sp_sumcheck_bind2_eval_batched: binds every table at r0 and, when r1 != NULL, then at r1 (length L becomes L/2 or L/4; a
+ *     shared C table is bound once, out of place), and returns for the tables so bound: out_evals (new length >= 2),
+ *     out_coeffs (new length >= 4), or, when the new length is 1, out_heads = A_0, B_0, A_1, B_1, ..., then each distinct C
+ *     table in order of first appearance (the final claims, as sp_table_bind_top_heads). Unused outputs may be NULL.
+ *   weights != NULL (4*ninst limbs: the `coeffs` of sumcheck.rs:359-369): the evaluations and coefficients are multiplied by
+ *     their instance's weight on the device and summed over the instances — out_evals[12] and out_coeffs[48] in all, which is
+ *     all the protocol uses. */
+int32_t sp_sumcheck_eval_coeffs_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* weights,
+                                        uint64_t* out_evals, uint64_t* out_coeffs);
+int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t r0[4],
+                                       const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads);
 /* Resident form of the two calls above for the latency-bound tail of a sum-check: tables of at most
  * sp_sumcheck_session_max_len() (512) entries, ~270 of the ~400 batched rounds of a 2^20 proof. ONE kernel stays on the
  * device for all remaining rounds, one workgroup per instance with that instance's tables held in LDS; each round is a

@@ -162,6 +162,115 @@ __global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restric
   }
   if (threadIdx.x < 3) st_fq(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x, red[threadIdx.x][0]);
 }
+
+// ---- two rounds per launch (the latency-bound tail of prove_cubic_batched, sumcheck.rs:287-393) -----------------------
+// A round trip (launch, completion flag, host wake-up) costs ~20 us, the arithmetic of a short round ~4 us. Two facts let
+// one trip advance TWO rounds. (1) With both challenges in hand, the doubly bound table is a four-term combination of the
+// current one, T''[z] = (1-r1)((1-r0) T[z] + r0 T[z+L/2]) + r1((1-r0) T[z+L/4] + r0 T[z+3L/4]), computed per entry with no
+// dependency between workgroups. (2) The evaluations of the round AFTER a bind are a cubic in that bind's challenge:
+// with x0..x3 the entries (i, i+q, i+2q, i+3q) of a table of length 4q, P(t) the line through (x0, x1) and U(t) the line
+// through (x2, x3), the entry pair of the bound table is ((1-r) x0 + r x2, (1-r) x1 + r x3) and its line at t is
+// (1-r) P(t) + r U(t); so sum_i A(t)B(t)C(t) = (1-r)^3 M0 + (1-r)^2 r M1 + (1-r) r^2 M2 + r^3 M3 with M0 = sum P_A P_B P_C,
+// M3 = sum U_A U_B U_C and M1, M2 from T1 = sum (P+U)(P+U)(P+U) = M0+M1+M2+M3, T2 = sum (P-U)(P-U)(P-U) = M0-M1+M2-M3. The kernel
+// returns (M0, M3, T1, T2) for t = 0, 2, 3 next to the evaluations of its own round: the caller derives the next challenge,
+// evaluates the cubic for the round after it, derives that challenge too, and only then comes back. Exact field
+// arithmetic: the values are those of the one-round-per-launch path.
+// Block = 8 groups x 32 lanes; group g holds the (up to) four entries z = g + p*ng, p = 0..3, of each bound table.
+// partials[(inst*nblk + blk)*18 + {0..2: evaluations at t = 0, 2, 3 | 3 + 4 t' + {0,1,2,3}: M0, M3, T1, T2 | 15..17: the entries
+// of A, B, C when the bound tables have length 1}]
+struct Triple2 {
+  Fq *a, *b, *c;
+  Fq* c_out;
+};
+__device__ __forceinline__ Fq line_at(const Fq& u, const Fq& v, int t) {  // the line through (0, u), (1, v) at t = 0, 2, 3
+  Fq x2 = fq_sub(fq_dbl(v), u), x3 = fq_sub(fq_add(x2, v), u), r;
+#pragma unroll
+  for (int w = 0; w < 4; w++) r.l[w] = t == 0 ? u.l[w] : (t == 1 ? x2.l[w] : x3.l[w]);
+  return r;
+}
+__global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
+                                                          Fq* __restrict__ partials) {
+  __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
+  __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
+  __shared__ Fq red[18][8];
+  const Triple2 t = T[blockIdx.y];
+  const int grp = threadIdx.x >> 5, lane = threadIdx.x & 31;
+  const size_t n2 = len >> nbind;                  // length of the tables the outputs describe (nbind = 0, 1 or 2 binds first)
+  const size_t np = n2 < 4 ? n2 : 4, ng = n2 / np; // entries per group, groups
+  const size_t g = (size_t)blockIdx.x * 8 + grp;
+  const bool live = g < ng;
+  Fq* const ptr[3] = {t.a, t.b, t.c};
+  if (nbind) {
+    if (nbind == 2) {
+      if (live && lane < 24) {
+        const int k = lane >> 3, p = (lane >> 1) & 3, h = lane & 1;
+        if ((size_t)p < np) {
+          const size_t y = g + (size_t)p * ng + (size_t)h * (len / 4);
+          Fq lo = ld_fq(ptr[k] + y), hi = ld_fq(ptr[k] + y + len / 2);
+          first[grp][k * 4 + p][h] = fq_add(lo, fq_mul(r0, fq_sub(hi, lo)));
+        }
+      }
+      __syncthreads();
+    }
+    if (live && lane < 12) {
+      const int k = lane >> 2, p = lane & 3;
+      if ((size_t)p < np) {
+        Fq lo, hi;
+        if (nbind == 2) { lo = first[grp][lane][0]; hi = first[grp][lane][1]; }
+        else { lo = ld_fq(ptr[k] + g + (size_t)p * ng); hi = ld_fq(ptr[k] + g + (size_t)p * ng + len / 2); }
+        Fq v = fq_add(lo, fq_mul(nbind == 2 ? r1 : r0, fq_sub(hi, lo)));
+        const size_t z = g + (size_t)p * ng;
+        if (k < 2) st_fq(ptr[k] + z, v);
+        else if (t.c_out) st_fq(t.c_out + z, v);  // C may be shared between instances: bound out of place, once
+        bnd[grp][k * 4 + (np == 2 && p == 1 ? 2 : p)] = v;  // a two-entry table is the pair (x0, x2)
+      }
+    }
+  } else if (live && lane < 12) {
+    const int k = lane >> 2, p = lane & 3;
+    if ((size_t)p < np) bnd[grp][k * 4 + (np == 2 && p == 1 ? 2 : p)] = ld_fq(ptr[k] + g + (size_t)p * ng);
+  }
+  __syncthreads();
+  // 18 triple products per group: lane = 6 t' + kind, kind 0/1 = the two entry pairs of this round, 2..5 = M0, M3, T1, T2
+  Fq e = fq_zero();
+  if (live && lane < 18 && np >= 2) {
+    const int tt = lane / 6, kind = lane % 6;
+    if (kind == 0 || np == 4) {
+      Fq f[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const Fq x0 = bnd[grp][k * 4], x1 = bnd[grp][k * 4 + 1], x2 = bnd[grp][k * 4 + 2], x3 = bnd[grp][k * 4 + 3];
+        if (kind <= 1) {
+          f[k] = kind == 0 ? line_at(x0, x2, tt) : line_at(x1, x3, tt);
+        } else {
+          Fq P = line_at(x0, x1, tt), U = line_at(x2, x3, tt);
+          Fq s = fq_add(P, U), d = fq_sub(P, U);
+#pragma unroll
+          for (int w = 0; w < 4; w++) f[k].l[w] = kind == 2 ? P.l[w] : (kind == 3 ? U.l[w] : (kind == 4 ? s.l[w] : d.l[w]));
+        }
+      }
+      e = fq_mul(fq_mul(f[0], f[1]), f[2]);
+      if (weights) e = fq_mul(e, ld_fq(weights + blockIdx.y));  // coeffs[i] of sumcheck.rs:359-369: the caller only adds the instances up
+    }
+  }
+  if (lane < 18) red[lane][grp] = e;
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    Fq acc = red[threadIdx.x][0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) acc = fq_add(acc, red[threadIdx.x][k]);
+    red[threadIdx.x][0] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    Fq* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 18;
+    const int x = threadIdx.x;
+    Fq v;
+    if (x < 3) v = fq_add(red[6 * x][0], red[6 * x + 1][0]);               // evaluations at t = 0, 2, 3
+    else if (x < 15) v = red[6 * ((x - 3) / 4) + 2 + (x - 3) % 4][0];       // M0, M3, T1, T2 per t
+    else v = (n2 == 1 && blockIdx.x == 0) ? bnd[0][(x - 15) * 4] : fq_zero();  // final claims
+    st_fq(o + x, v);
+  }
+}
 // partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
 __global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
   __shared__ Fq sm[256];
@@ -389,6 +498,114 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   for (size_t k = 0; k < ninst; k++)
     if (C[k]->len == len) table_swap_to_alt(C[k], len / 2);
   return batched_finish(c, partials, nblk, ninst, out);
+}
+
+// partials[ninst][nblk][18] -> out[ninst][18], one block per instance: thread = (component k < 18 of 32, slice of blocks)
+__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out) {
+  __shared__ Fq sm[8][18];
+  const int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const Fq* p = partials + (size_t)blockIdx.x * nblk * 18;
+  if (k < 18) {
+    Fq acc = fq_zero();
+    for (size_t b = sl; b < nblk; b += 8) acc = fq_add(acc, ld_fq(p + b * 18 + k));
+    sm[sl][k] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    Fq acc = sm[0][threadIdx.x];
+#pragma unroll
+    for (int j = 1; j < 8; j++) acc = fq_add(acc, sm[j][threadIdx.x]);
+    st_fq(out + (size_t)blockIdx.x * 18 + threadIdx.x, acc);
+  }
+}
+// shared by the two entry points below: launch k_cubic_bind2_eval, bring the 18 sums per instance to the host
+static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int nbind, const uint64_t* r0, const uint64_t* r1,
+                            const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads) {
+  if (!c || !A || !B || !C || ninst == 0 || ninst > 64) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t len = A[0] ? A[0]->len : 0;
+  if (len < ((size_t)1 << nbind) || len < 2 || !is_pow2(len)) return SP_EINVAL;
+  const int do_bind = nbind;
+  size_t n2 = len >> nbind;
+  if ((n2 >= 2 && !out_evals) || (n2 >= 4 && !out_coeffs) || (n2 == 1 && !out_heads)) return SP_EINVAL;
+  std::vector<Triple2> T(ninst);
+  std::vector<sp_table*> distinctC;
+  for (size_t k = 0; k < ninst; k++) {
+    if (!A[k] || !B[k] || !C[k] || A[k]->len != len || B[k]->len != len || C[k]->len != len) return SP_EINVAL;
+    T[k] = Triple2{A[k]->d, B[k]->d, C[k]->d, nullptr};
+    bool first = true;
+    for (size_t m = 0; m < k; m++) first = first && C[m] != C[k];
+    if (first) {
+      distinctC.push_back(C[k]);
+      if (do_bind) {
+        SPCHK(table_ensure_alt(C[k], n2));
+        T[k].c_out = C[k]->alt;
+      }
+    }
+  }
+  stage_small(c, 0, T.data(), sizeof(Triple2) * ninst);
+  const Fq* dweights = weights ? (const Fq*)stage_small(c, sizeof(Triple2) * 64, weights, 32 * ninst) : nullptr;
+  size_t np = n2 < 4 ? n2 : 4, ng = n2 / np, nblk = (ng + 7) / 8;
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 18 * (nblk + 1) * ninst));
+  bool host = 32 * 18 * nblk * ninst <= HOST_SUM_BYTES;
+  Fq* partials = host ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq z = fq_zero();
+  {
+    ProfScope ps(c, do_bind ? PF_SC_BIND_EVAL : PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, (do_bind ? 36.0 + 36.0 : 36.0) * (double)ng * (double)ninst);
+    hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple2*)c->hmap, dweights, len, nbind,
+                       r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials);
+  }
+  std::vector<Fq> sums(18 * ninst);
+  if (!host) {
+    ProfScope ps(c, PF_REDUCE, 32.0 * 18 * (double)(nblk * ninst));
+    hipLaunchKernelGGL(k_reduce_partials18, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, (Fq*)hres(c));
+    SPCHK(fetch_small(c, sums.data(), 32 * 18 * ninst));
+  } else {
+    SPCHK(sync_spin(c));
+    const Fq* p = (const Fq*)hres(c);
+    for (size_t i = 0; i < ninst; i++)
+      for (int k = 0; k < 18; k++) {
+        Fq acc = p[(i * nblk) * 18 + k];
+        for (size_t b = 1; b < nblk; b++) acc = fq_add(acc, p[(i * nblk + b) * 18 + k]);
+        sums[18 * i + k] = acc;
+      }
+  }
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  if (do_bind) {
+    for (size_t k = 0; k < ninst; k++) { A[k]->len = n2; B[k]->len = n2; }
+    for (sp_table* t : distinctC) table_swap_to_alt(t, n2);
+  }
+  if (weights) {  // the instances' weighted sums added up: 3 evaluations and 12 coefficients in all
+    Fq tot[15];
+    for (int k = 0; k < 15; k++) {
+      Fq acc = sums[k];
+      for (size_t i = 1; i < ninst; i++) acc = fq_add(acc, sums[18 * i + k]);
+      tot[k] = acc;
+    }
+    if (n2 >= 2) memcpy(out_evals, tot, 96);
+    if (n2 >= 4) memcpy(out_coeffs, tot + 3, 384);
+  }
+  for (size_t i = 0; i < ninst; i++) {
+    if (!weights && n2 >= 2) memcpy(out_evals + 12 * i, &sums[18 * i], 96);
+    if (!weights && n2 >= 4) memcpy(out_coeffs + 48 * i, &sums[18 * i + 3], 384);
+    if (n2 == 1) { memcpy(out_heads + 8 * i, &sums[18 * i + 15], 64); }
+  }
+  if (n2 == 1)
+    for (size_t k = 0; k < distinctC.size(); k++) {
+      size_t owner = 0;
+      while (C[owner] != distinctC[k]) owner++;
+      memcpy(out_heads + 8 * ninst + 4 * k, &sums[18 * owner + 17], 32);
+    }
+  return SP_OK;
+}
+int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t r0[4],
+                                       const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads) {
+  if (!r0) return SP_EINVAL;
+  return bind2_launch(c, A, B, C, ninst, r1 ? 2 : 1, r0, r1, weights, out_evals, out_coeffs, out_heads);
+}
+int32_t sp_sumcheck_eval_coeffs_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* weights,
+                                        uint64_t* out_evals, uint64_t* out_coeffs) {
+  return bind2_launch(c, A, B, C, ninst, 0, nullptr, nullptr, weights, out_evals, out_coeffs, nullptr);
 }
 int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out) {
   if (!c || !chi || !tabs || !out || nt == 0 || nt > 64) return SP_EINVAL;

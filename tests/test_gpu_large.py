@@ -408,3 +408,99 @@ def test_resident_sumcheck_session_matches_reference_arithmetic(ctx, ell, first_
     assert from_mont_bulk(tA[2].download(ln // 2), ln // 2) == cA[2]
     for t in tA + tB + tCseq + [tCpar]:
         t.free()
+
+
+@pytest.mark.parametrize("ell", [2, 3, 4, 5, 9, 13, 15])
+def test_two_rounds_per_launch_match_reference_arithmetic(ctx, ell):
+    """sp_sumcheck_eval_coeffs_batched / sp_sumcheck_bind2_eval_batched (spark.hip k_cubic_bind2_eval): two rounds of
+    prove_cubic_batched (sumcheck.rs:287-393) per device round trip. Checked against the reference arithmetic in Python:
+    the evaluations of each round, the cubic (M0, M3, T1, T2) that predicts the round after the next bind, the doubly bound
+    tables, and the final claims; 3 instances share their C table, 2 own theirs. 2^15 = the longest tables the driver
+    sends down this path."""
+    from spartan_amd import capi
+    n = 1 << ell
+    rng = random.Random(9100 + ell)
+    npar, nseq = 3, 2
+    ni = npar + nseq
+    A = [fast_scalars(rng, n) for _ in range(ni)]
+    B = [fast_scalars(rng, n) for _ in range(ni)]
+    Cpar = fast_scalars(rng, n)
+    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
+    tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
+    tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
+    hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
+    hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
+    Cs = lambda: [Cpar] * npar + Cseq
+    ev = (ctypes.c_uint64 * (12 * ni))(); co = (ctypes.c_uint64 * (48 * ni))()
+    heads = (ctypes.c_uint64 * (4 * (2 * ni + 1 + nseq)))()
+    half = pow(2, Q - 2, Q)
+
+    def predicted(coeffs, r):   # E(t; r) from (M0, M3, T1, T2), as the host driver evaluates it
+        out = []
+        om = (1 - r) % Q
+        for k in range(3 * ni):
+            M0, M3, T1, T2 = coeffs[4 * k:4 * k + 4]
+            M1 = ((T1 - T2) * half - M3) % Q; M2 = ((T1 + T2) * half - M0) % Q
+            out.append((M0 * om ** 3 + M1 * om ** 2 * r + M2 * om * r ** 2 + M3 * r ** 3) % Q)
+        return out
+    assert capi.lib.sp_sumcheck_eval_coeffs_batched(ctx.h, hA, hB, hC, sz(ni), None, ev, co if n >= 4 else None) == 0
+    got = from_mont_bulk(ev, 3 * ni)
+    for k in range(ni):
+        assert got[3 * k:3 * k + 3] == cubic_evals(A[k], B[k], Cs()[k]), k
+    length = n
+    while length >= 4:
+        coeffs = from_mont_bulk(co, 12 * ni)
+        r0, r1 = rng.getrandbits(251), rng.getrandbits(250)
+        A = [bind(a, r0) for a in A]; B = [bind(b, r0) for b in B]; Cpar = bind(Cpar, r0); Cseq = [bind(c, r0) for c in Cseq]
+        want_mid = [x for k in range(ni) for x in cubic_evals(A[k], B[k], Cs()[k])] if length >= 4 else None
+        assert predicted(coeffs, r0) == want_mid, length          # the cubic predicts the round after the bind at r0
+        A = [bind(a, r1) for a in A]; B = [bind(b, r1) for b in B]; Cpar = bind(Cpar, r1); Cseq = [bind(c, r1) for c in Cseq]
+        length //= 4
+        rc = capi.lib.sp_sumcheck_bind2_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(r0), fq1(r1), None, ev if length >= 2 else None, co if length >= 4 else None,
+                                                     heads if length == 1 else None)
+        assert rc == 0
+        assert len(tA[0]) == length and len(tCpar) == length and len(tCseq[0]) == length
+        if length >= 2:
+            got = from_mont_bulk(ev, 3 * ni)
+            for k in range(ni):
+                assert got[3 * k:3 * k + 3] == cubic_evals(A[k], B[k], Cs()[k]), (length, k)
+        assert from_mont_bulk(tA[2].download(length), length) == A[2] and from_mont_bulk(tCpar.download(length), length) == Cpar
+        assert from_mont_bulk(tB[4].download(length), length) == B[4] and from_mont_bulk(tCseq[1].download(length), length) == Cseq[1]
+    if length == 1:
+        want = []
+        for k in range(ni):
+            want += [A[k][0], B[k][0]]
+        want += [Cpar[0]] + [c[0] for c in Cseq]
+        assert from_mont_bulk(heads, 2 * ni + 1 + nseq) == want
+    for t in tA + tB + tCseq + [tCpar]:
+        t.free()
+    if ell < 4:
+        return
+    # weighted form (the `coeffs` of sumcheck.rs:359-369 applied on the device, instances summed) and the single-bind form
+    # (r1 = NULL: the round at which the tables become short)
+    A = [fast_scalars(rng, n) for _ in range(ni)]; B = [fast_scalars(rng, n) for _ in range(ni)]
+    Cpar = fast_scalars(rng, n); Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
+    w = fast_scalars(rng, ni)
+    tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
+    tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
+    hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
+    hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
+    ev1 = (ctypes.c_uint64 * 12)(); co1 = (ctypes.c_uint64 * 48)()
+    comb = lambda: [sum(w[k] * cubic_evals(A[k], B[k], Cs()[k])[t_] for k in range(ni)) % Q for t_ in range(3)]
+    assert capi.lib.sp_sumcheck_eval_coeffs_batched(ctx.h, hA, hB, hC, sz(ni), mont_bulk(w), ev1, co1) == 0
+    assert from_mont_bulk(ev1, 3) == comb()
+    c12 = from_mont_bulk(co1, 12)
+    r0 = rng.getrandbits(251)
+    A = [bind(a, r0) for a in A]; B = [bind(b, r0) for b in B]; Cpar = bind(Cpar, r0); Cseq = [bind(c, r0) for c in Cseq]
+    om = (1 - r0) % Q
+    pred = []
+    for t_ in range(3):
+        M0, M3, T1, T2 = c12[4 * t_:4 * t_ + 4]
+        M1 = ((T1 - T2) * half - M3) % Q; M2 = ((T1 + T2) * half - M0) % Q
+        pred.append((M0 * om ** 3 + M1 * om ** 2 * r0 + M2 * om * r0 ** 2 + M3 * r0 ** 3) % Q)
+    assert pred == comb()
+    assert capi.lib.sp_sumcheck_bind2_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(r0), None, mont_bulk(w), ev1, co1, None) == 0   # one bind
+    assert from_mont_bulk(ev1, 3) == comb() and len(tA[0]) == n // 2 and len(tCpar) == n // 2
+    assert from_mont_bulk(tA[1].download(n // 2), n // 2) == A[1] and from_mont_bulk(tCpar.download(n // 2), n // 2) == Cpar
+    for t in tA + tB + tCseq + [tCpar]:
+        t.free()
