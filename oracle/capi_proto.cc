@@ -317,6 +317,25 @@ size_t orc_snark_gens_bincode(void* gv, uint8_t* out, size_t cap) {  // lib.rs:2
   if (out && cap >= w.b.size()) memcpy(out, w.b.data(), w.b.size());
   return w.b.size();
 }
+// bincode of ComputationDecommitment (lib.rs:50-54 -> r1cs.rs:67-70 -> sparse_mlpoly.rs:274-282, 212-218; dense_mlpoly.rs:17-22):
+// DensePolynomial = {num_vars, len, Vec<Scalar>}, AddrTimestamps = {Vec<Vec<usize>>, Vec<DensePolynomial> x2, DensePolynomial}
+size_t orc_decommitment_bincode(void* ev, uint8_t* out, size_t cap) {
+  const MultiSparseMatPolynomialAsDense& d = ((EncH*)ev)->decomm.dense;
+  Wb w;
+  auto poly = [&](const DensePoly& p) {
+    w.u64(p.num_vars); w.u64(p.len); w.u64(p.Z.size());
+    for (auto& x : p.Z) for (int i = 0; i < 4; i++) w.u64(x.l[i]);
+  };
+  auto polys = [&](const std::vector<DensePoly>& v) { w.u64(v.size()); for (auto& p : v) poly(p); };
+  auto at = [&](const AddrTimestamps& a) {
+    w.u64(a.ops_addr_usize.size());
+    for (auto& v : a.ops_addr_usize) { w.u64(v.size()); for (size_t x : v) w.u64(x); }
+    polys(a.ops_addr); polys(a.read_ts); poly(a.audit_ts);
+  };
+  w.u64(d.batch_size); polys(d.val); at(d.row); at(d.col); poly(d.comb_ops); poly(d.comb_mem);
+  if (out && cap >= w.b.size()) memcpy(out, w.b.data(), w.b.size());
+  return w.b.size();
+}
 size_t orc_commitment_bincode(void* ev, uint8_t* out, size_t cap) {  // lib.rs:44-48 -> r1cs.rs:50-56, sparse_mlpoly.rs:320-327
   const R1CSCommitment& c = ((EncH*)ev)->comm;
   Wb w;

@@ -158,6 +158,17 @@ size_t spz_commitment_bincode(void* e, uint8_t* out, size_t cap) {
   if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
   return b.size();
 }
+// bincode(ComputationDecommitment): returns the size; fills out when cap suffices
+size_t spz_decommitment_bincode(void* e, uint8_t* out, size_t cap) {
+  try {
+    std::vector<uint8_t> b = ((EncH*)e)->decomm.serialize();
+    if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
+    return b.size();
+  } catch (const std::exception& ex) {
+    g_err = ex.what();
+    return 0;
+  }
+}
 size_t spz_encode_comm(void* ev, int which, uint8_t* out, size_t cap) {
   EncH* e = (EncH*)ev;
   const PolyCommitment& c = which == 0 ? e->comm.comm.comm_comb_ops : e->comm.comm.comm_comb_mem;

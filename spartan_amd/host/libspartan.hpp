@@ -220,6 +220,9 @@ struct ComputationCommitment {  // lib.rs:44-48 -> r1cs.rs:50-56
 };
 struct ComputationDecommitment {  // lib.rs:50-54 -> r1cs.rs:67-70
   MultiSparseMatPolynomialAsDense dense;
+  // bincode of the serde-derived struct (sparse_mlpoly.rs:274-282, 212-218; dense_mlpoly.rs:17-22): every DensePolynomial is
+  // {num_vars, len, Vec<Scalar>}; the tables are downloaded from the device (1.3 GB at 2^20: an interchange format, not a hot path)
+  std::vector<uint8_t> serialize() const;
 };
 
 struct ProveTimes {  // span names follow src/timer.rs call sites

@@ -878,6 +878,31 @@ std::vector<uint8_t> ComputationCommitment::serialize() const {
   w.cpv(comm.comm_comb_mem.C);
   return w.b;
 }
+std::vector<uint8_t> ComputationDecommitment::serialize() const {
+  Wr w;
+  const MultiSparseMatPolynomialAsDense& d = dense;
+  auto poly = [&](const DevTable& t) {  // DensePolynomial {num_vars, len, Z}
+    size_t n = t.len();
+    FqVec z(n);
+    SPX(sp_table_download(t.c, t.h, 0, n, U(z)));
+    w.u64(log_2(n)); w.u64(n); w.fqv(z);
+  };
+  auto polys = [&](const std::vector<DevTable>& v) { w.u64(v.size()); for (auto& t : v) poly(t); };
+  auto at = [&](const AddrTimestamps& a) {
+    // ops_addr_usize: Vec<Vec<usize>> — the same numbers as ops_addr (DensePolynomial::from_usize, sparse_mlpoly.rs:246-248), read back from it
+    w.u64(a.ops_addr.size());
+    for (auto& t : a.ops_addr) {
+      size_t n = t.len();
+      FqVec z(n);
+      SPX(sp_table_download(t.c, t.h, 0, n, U(z)));
+      w.u64(n);
+      for (auto& x : z) w.u64(sp::fq_from_mont(x).l[0]);
+    }
+    polys(a.ops_addr); polys(a.read_ts); poly(a.audit_ts);
+  };
+  w.u64(d.batch_size); polys(d.val); at(d.row); at(d.col); poly(d.comb_ops); poly(d.comb_mem);
+  return w.b;
+}
 std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p) { Wr w; w_r1cs(w, p); return w.b; }
 std::vector<uint8_t> NIZK::serialize() const { Wr w; w_r1cs(w, r1cs_sat_proof); w.fqv(rx); w.fqv(ry); return w.b; }
 std::vector<uint8_t> SNARK::serialize() const {

@@ -12,7 +12,7 @@ H = ctypes.CDLL(HOST_PATH)
 for f in ("spz_ctx_new", "spz_instance_new", "spz_instance_synthetic", "spz_snark_gens_new", "spz_nizk_gens_new", "spz_snark_encode",
           "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw"):
     getattr(H, f).restype = vp
-for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script", "spz_snark_gens_bincode", "spz_commitment_bincode"):
+for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script", "spz_snark_gens_bincode", "spz_commitment_bincode", "spz_decommitment_bincode"):
     getattr(H, f).restype = sz
 H.spz_last_error.restype = ctypes.c_char_p
 for f in ("spz_ctx_free", "spz_instance_free", "spz_snark_gens_free", "spz_nizk_gens_free", "spz_encode_free", "spz_proof_free"):
@@ -185,6 +185,11 @@ class Encoded:
     def serialize_commitment(self):
         n = H.spz_commitment_bincode(self.h, None, sz(0)); b = (ctypes.c_uint8 * n)()
         H.spz_commitment_bincode(self.h, b, sz(n))
+        return bytes(b)
+
+    def serialize_decommitment(self):
+        n = H.spz_decommitment_bincode(self.h, None, sz(0)); b = (ctypes.c_uint8 * n)()
+        H.spz_decommitment_bincode(self.h, b, sz(n))
         return bytes(b)
 
     def free(self):

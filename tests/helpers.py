@@ -24,7 +24,7 @@ def load_oracle():
     for f in ("orc_instance_synthetic", "orc_instance_new", "orc_instance_new_padded", "orc_snark_gens_new", "orc_nizk_gens_new", "orc_snark_encode",
               "orc_snark_prove", "orc_nizk_prove"):
         getattr(L, f).restype = vp
-    for f in ("orc_proof_bytes", "orc_instance_nnz", "orc_instance_shape_bincode", "orc_encode_comm", "orc_merlin_script", "orc_snark_gens_bincode", "orc_commitment_bincode"):
+    for f in ("orc_proof_bytes", "orc_instance_nnz", "orc_instance_shape_bincode", "orc_encode_comm", "orc_merlin_script", "orc_snark_gens_bincode", "orc_commitment_bincode", "orc_decommitment_bincode"):
         getattr(L, f).restype = sz
     return L
 

@@ -235,8 +235,8 @@ def test_concurrent_contexts_produce_identical_proofs(P, orc):
 
 
 def test_wire_formats_of_gens_and_commitment_match_oracle(P, ctx, orc):
-    """bincode of SNARKGens (lib.rs:278-282) and ComputationCommitment (lib.rs:44-48): same bytes as the oracle's writer; the
-    lengths follow from the serde struct definitions."""
+    """bincode of SNARKGens (lib.rs:278-282), ComputationCommitment (lib.rs:44-48) and ComputationDecommitment (lib.rs:50-54):
+    same bytes as the oracle's writer; the lengths follow from the serde struct definitions."""
     s_ = 6; N = 1 << s_
     inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=4)
     gens = P.SNARKGens(ctx, N, N, 10, N)
@@ -258,6 +258,13 @@ def test_wire_formats_of_gens_and_commitment_match_oracle(P, ctx, orc):
     R = lambda v: 1 << (v - v // 2)
     assert len(gb) == mcg(1) + mcg(3) + mcg(4) + pcg(r_sat) + pcg(R(v_ops)) + pcg(R(v_mem)) + pcg(R(v_der))
     assert len(cb) == 6 * 8 + (8 + 32 * (1 << (v_ops // 2))) + (8 + 32 * (1 << (v_mem // 2)))
+    # ComputationDecommitment (lib.rs:50-54): the dense representation downloaded from the device, serde field order
+    db = enc.serialize_decommitment()
+    assert db == ob(orc.orc_decommitment_bincode, oe)
+    dp = lambda n: 8 + 8 + 8 + 32 * n                      # DensePolynomial {num_vars, len, Vec<Scalar>}
+    at = lambda n, cells: (8 + 3 * (8 + 8 * n)) + 2 * (8 + 3 * dp(n)) + dp(cells)   # AddrTimestamps for 3 matrices
+    cells = 2 * N                                           # max(2^nvx, 2^nvy) with nvy = log2(2 * num_vars)
+    assert len(db) == 8 + (8 + 3 * dp(N)) + 2 * at(N, cells) + dp(16 * N) + dp(2 * cells)
     enc.free(); gens.free(); inst.free()
 
 
