@@ -353,30 +353,32 @@ def main():
                     "alg_bytes_per_launch": f["alg_bytes"] / f["launches"],
                     "note": "255-bit EC / 253-bit field integer work: VALU-bound by construction, the HBM fraction is reported as the contract asks; `alu` below is the roofline that can approach 1 (DESIGN.md, roofline)"}
         # ---- ALU roofline: mixed additions/s of each MSM launch shape against the pt_madd chain measured on this GPU
-        nwin = -(-254 // capi.lib.sp_msm_window_bits())
+        wb_sat, wb_eval = gens.window_bits(0), gens.window_bits(1)
+        nwin_of = {False: -(-254 // wb_sat), True: -(-254 // wb_eval)}  # witness commit: gens_r1cs_sat stream; derefs: gens_r1cs_eval
         R = 1 << ((s + 3) - (s + 3) // 2)   # columns of the derefs commitment (2^(s+3) entries, dense_mlpoly.rs:188-191)
         named = {}
         if s >= 6:
             # scalars that are actually non-zero: the derefs polynomial holds 6 * 2^s values, its top quarter is padding
             rows_row_half = 3 * N // R
-            named[(1 << (s // 2), 1 << (s - s // 2), False)] = ("witness commit (poly_vars, + one blind per row)", N + (1 << (s // 2)))
-            named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, half of the CUs)", 3 * N)
-            named[((8 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (+ zero padding rows)", 3 * N)
+            named[(1 << (s // 2), 1 << (s - s // 2), False)] = ("witness commit (poly_vars, + one blind per row)", N + (1 << (s // 2)), False)
+            named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, half of the CUs)", 3 * N, True)
+            named[((8 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (+ zero padding rows)", 3 * N, True)
         alu_shapes = []
         for sh in shapes:
             nm = named.get((sh["rows"], sh["cols"], sh["background"]))
             if not nm or not sh["launches"]:
                 continue
             lms = sh["ms"] / sh["launches"]
+            nwin = nwin_of[nm[2]]
             madds = nm[1] * nwin
-            e = {"shape": f'{sh["rows"]} x {sh["cols"]}', "what": nm[0], "launch_ms": round(lms, 4), "mixed_additions": madds,
+            e = {"shape": f'{sh["rows"]} x {sh["cols"]}', "what": nm[0], "launch_ms": round(lms, 4), "window_bits": wb_eval if nm[2] else wb_sat, "mixed_additions": madds,
                  "achieved_G_per_s": round(madds / lms / 1e6, 2)}
             if ceil:
                 e["frac"] = round(madds / lms / 1e6 / ceil["pt_madd_G_per_s"], 3)
             alu_shapes.append(e)
         roofline["alu"] = {"unit": "G mixed additions/s (7 F_p multiplications + 8 additions each)", "ceiling": ceil["pt_madd_G_per_s"] if ceil else None,
                            "ceiling_source": "bench/ubench_fpmul --json on this GPU, this run: dependent pt_madd chains at full occupancy" if ceil else "bench/ubench_fpmul not built",
-                           "additions_per_scalar": nwin, "shapes": alu_shapes,
+                           "additions_per_scalar": {"gens_r1cs_sat": nwin_of[False], "gens_r1cs_eval": nwin_of[True]}, "shapes": alu_shapes,
                            "frac": max([e.get("frac", 0) for e in alu_shapes if "background" not in e["what"]] or [None])}
         # F_q streaming kernels (the HBM-shaped part): multiplications/s against the fq_mul chain ceiling, bytes/s against HBM
         fq = {}

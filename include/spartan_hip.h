@@ -61,21 +61,24 @@ int32_t sp_prof_read_ops(sp_ctx* ctx, double* alg_ops, int cap);
  * background stream): returns the number of shapes seen, fills up to cap entries. */
 int32_t sp_prof_read_shapes(sp_ctx* ctx, const char* family, uint64_t* shape, double* total_ms, uint64_t* launches, double* alg_bytes,
                             double* alg_ops, int cap);
-/* signed window width c of the fixed-base tables: a committed scalar costs ceil(254 / c) mixed additions */
+/* default signed window width c (the width of a given set: sp_gens_window_bits): a committed scalar costs ceil(254 / c) mixed additions */
 int sp_msm_window_bits(void);
 
 /* ---- generators: MultiCommitGens (src/commitments.rs:8-33) ------------------------------------------
  * A sp_gens is a list of n points P[0..n). A MultiCommitGens{G[0..m), h} made by
  * MultiCommitGens::new(m, label) is the list of its m+1 stream points with h = P[m]; gens that are prefixes
  * of one SHAKE stream (gens_3/gens_4/gens_pc of R1CSGens, src/r1csproof.rs:48-73) share one sp_gens.
- * Upload builds signed 13-bit fixed-base window tables (20 windows x 4096 affine entries per point, 7.5 MiB
- * per point in HBM; 288 GB makes that cheap): generators are public parameters reused across proofs, so this
- * is setup cost (~85 ms per 1000 points). */
+ * Upload builds signed c-bit fixed-base window tables (ceil(254/c) windows x 2^(c-1) affine entries of 96 B per point):
+ * generators are public parameters reused across proofs, so this is setup cost. c is the widest of 15/14/13/12/10/8 whose
+ * tables fit the HBM budget of the set (SPARTAN_MSM_TABLE_GB, default 112; SPARTAN_MSM_WBITS forces a width): 15 bits — 17
+ * additions per committed scalar, 26 MiB per point — for the generators of a 2^20 instance, 13 bits for a 2^22 one.
+ * SP_ENOMEM if not even 8-bit tables fit. */
 int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n, sp_gens** out);
 /* MultiCommitGens::new body (commitments.rs:21-30): n blocks of 64 uniform bytes from the caller's
  * SHAKE256 stream -> from_uniform_bytes on the device. compressed_out (32*n) may be NULL. */
 int32_t sp_gens_from_uniform(sp_ctx* ctx, const uint8_t* uniform /*64*n*/, size_t n, uint8_t* compressed_out, sp_gens** out);
 size_t sp_gens_len(const sp_gens* g);
+int sp_gens_window_bits(const sp_gens* g); /* the width c the tables of this set were built with */
 void sp_gens_free(sp_gens* g);
 
 /* ---- Pedersen commitments (src/commitments.rs:73-92, src/dense_mlpoly.rs:164-177, src/group.rs:98-117) --

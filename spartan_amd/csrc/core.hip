@@ -152,29 +152,28 @@ __global__ void k_points_load(const uint8_t* __restrict__ in, int mode, size_t n
   }
   pts[i] = p;
 }
-// stage 2: one thread per (point, window, chunk of TB_CHUNK magnitudes): entries k * 2^(c w) * P in affine Niels form.
-constexpr int TB_CHUNK = MSM_TENT < 128 ? MSM_TENT : 128;
-constexpr int TB_NCHUNK = MSM_TENT / TB_CHUNK;
-__global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __restrict__ table) {
+// stage 2: one thread per (point, window, chunk of up to 128 magnitudes): entries k * 2^(c w) * P in affine Niels form.
+__global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __restrict__ table, MsmGeom geom) {
+  const int chunk = geom.tent < 128 ? geom.tent : 128, nchunk = geom.tent / chunk;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * MSM_NWIN * TB_NCHUNK) return;
-  int ck = (int)(t % TB_NCHUNK);
-  size_t pw = t / TB_NCHUNK;
-  size_t pt = pw / MSM_NWIN;
-  int w = (int)(pw % MSM_NWIN);
+  if (t >= n * geom.nwin * nchunk) return;
+  int ck = (int)(t % nchunk);
+  size_t pw = t / nchunk;
+  size_t pt = pw / geom.nwin;
+  int w = (int)(pw % geom.nwin);
   Pt base = pts[pt];
-  for (int k = 0; k < MSM_WBITS * w; k++) base = pt_dbl(base);
-  // first multiple of this chunk: (ck * TB_CHUNK + 1) * base by double-and-add
-  int m0 = ck * TB_CHUNK + 1;
+  for (int k = 0; k < geom.wbits * w; k++) base = pt_dbl(base);
+  // first multiple of this chunk: (ck * chunk + 1) * base by double-and-add
+  int m0 = ck * chunk + 1;
   Pt acc = pt_identity();
   for (int b = 15; b >= 0; b--) {
     acc = pt_dbl(acc);
     if ((m0 >> b) & 1) acc = pt_add(acc, base);
   }
-  for (int m = m0; m < m0 + TB_CHUNK; m++) {
+  for (int m = m0; m < m0 + chunk; m++) {
     Fp zinv = fp_invert(acc.Z);
-    table[msm_tidx(pt, w, m)] = pt_to_niels(acc, zinv);
-    if (m + 1 < m0 + TB_CHUNK) acc = pt_add(acc, base);
+    table[msm_tidx(geom, pt, w, m)] = pt_to_niels(acc, zinv);
+    if (m + 1 < m0 + chunk) acc = pt_add(acc, base);
   }
 }
 
@@ -185,7 +184,7 @@ __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __res
 __device__ __forceinline__ void msm_rows_tile(size_t lb, unsigned tid, const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols,
                                               size_t strip, size_t nstrips, const Niels* __restrict__ table, size_t g_off,
                                               const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial,
-                                              int xcd_map) {
+                                              int xcd_map, const MsmGeom& geom) {
   size_t row, s;
   if (xcd_map) {
     // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): all row-blocks of a column strip are
@@ -206,16 +205,16 @@ __device__ __forceinline__ void msm_rows_tile(size_t lb, unsigned tid, const Fq*
   for (size_t j = j0; j < j1; j++) {
     Fq sc = ld_fq(Z + row * z_row_stride + j);
     size_t pt = idx ? (size_t)idx[j] : g_off + j;
-    msm_accumulate(acc, sc, table, pt);
+    msm_accumulate(acc, sc, table, pt, geom);
   }
-  if (blinds && s == 0) msm_accumulate(acc, ld_fq(blinds + row), table, h_idx);
+  if (blinds && s == 0) msm_accumulate(acc, ld_fq(blinds + row), table, h_idx, geom);
   partial[row * nstrips + s] = acc;
 }
 __global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
                                                   size_t nstrips, const Niels* __restrict__ table, size_t g_off,
                                                   const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx,
-                                                  Pt* __restrict__ partial, int xcd_map) {
-  msm_rows_tile(blockIdx.x, threadIdx.x, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, idx, blinds, h_idx, partial, xcd_map);
+                                                  Pt* __restrict__ partial, int xcd_map, MsmGeom geom) {
+  msm_rows_tile(blockIdx.x, threadIdx.x, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, idx, blinds, h_idx, partial, xcd_map, geom);
 }
 // Background form: persistent 1024-thread workgroups, launched on fewer workgroups than the chip has CUs. At 127 VGPRs a
 // CU holds exactly one of them (16 waves, 508 of 512 registers per lane), so the CUs left over cannot receive a second
@@ -223,20 +222,20 @@ __global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size
 // would give, which this platform does not honour.
 __global__ void __launch_bounds__(1024) k_msm_rows_bg(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
                                                       size_t nstrips, const Niels* __restrict__ table, size_t g_off, Pt* __restrict__ partial,
-                                                      int xcd_map, size_t ntiles) {
+                                                      int xcd_map, size_t ntiles, MsmGeom geom) {
   extern __shared__ uint8_t occupancy_fence[];
   for (size_t lb = (size_t)blockIdx.x * 4 + threadIdx.x / 256; lb < ntiles; lb += (size_t)gridDim.x * 4)
-    msm_rows_tile(lb, threadIdx.x % 256, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, nullptr, nullptr, 0, partial, xcd_map);
+    msm_rows_tile(lb, threadIdx.x % 256, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, nullptr, nullptr, 0, partial, xcd_map, geom);
 }
 // Latency-bound shapes (Sigma-protocol commits, IPA rounds, single-row commits): one thread per (row, column,
 // window) performs a single table lookup, so the serial chain per thread is one mixed addition instead of 32.
 // partial[row][w*cols + j].  The blind, if any, is column `cols` (generator h_idx).
 __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols,
                                                      const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
-                                                     const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial) {
+                                                     const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial, MsmGeom geom) {
   size_t ncol = cols + (blinds ? 1 : 0);
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * ncol * MSM_NWIN) return;
+  if (t >= rows * ncol * geom.nwin) return;
   size_t row = t % rows, rest = t / rows;
   size_t j = rest % ncol;
   int w = (int)(rest / ncol);
@@ -245,10 +244,10 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
   Pt acc = pt_identity();
   if (!fq_is_zero(sc)) {
     Fq s = fq_from_mont(sc);
-    int d = msm_digit(s, w);
-    if (d != 0) acc = pt_madd(acc, table[msm_tidx(pt, w, d < 0 ? -d : d)], d < 0);
+    int d = msm_digit(s, w, geom);
+    if (d != 0) acc = pt_madd(acc, table[msm_tidx(geom, pt, w, d < 0 ? -d : d)], d < 0);
   }
-  partial[row * (ncol * MSM_NWIN) + (size_t)w * ncol + j] = acc;
+  partial[row * (ncol * geom.nwin) + (size_t)w * ncol + j] = acc;
 }
 // In-place LDS tree sum of sm[0..n) into sm[0] for a 256-thread block, with every point addition spread over FOUR lanes.
 // A full extended addition is 9 dependent-ish field multiplications (~3.5 us for a lone lane); here lane `role` of a quad
@@ -311,10 +310,10 @@ template <bool FINAL>
 __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__ Z, size_t z_row_stride, size_t cols,
                                                           const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
                                                           size_t idx_row_stride, const Fq* __restrict__ blinds, size_t h_idx,
-                                                          void* __restrict__ out) {
+                                                          void* __restrict__ out, MsmGeom geom) {
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
-  size_t ncol = cols + (blinds ? 1 : 0), P = ncol * MSM_NWIN, row = blockIdx.y;
+  size_t ncol = cols + (blinds ? 1 : 0), P = ncol * geom.nwin, row = blockIdx.y;
   int t = threadIdx.x;
   size_t p = (size_t)blockIdx.x * 256 + t;
   Pt10 acc = pt10_identity();
@@ -324,9 +323,9 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
     Fq sc = j < cols ? ld_fq(Z + row * z_row_stride + j) : ld_fq(blinds + row);
     size_t pt = j < cols ? (idx ? (size_t)idx[row * idx_row_stride + j] : g_off + j) : h_idx;
     if (!fq_is_zero(sc)) {
-      int d = msm_digit(fq_from_mont(sc), w);
+      int d = msm_digit(fq_from_mont(sc), w, geom);
       if (d != 0) {
-        Niels n = table[msm_tidx(pt, w, d < 0 ? -d : d)];
+        Niels n = table[msm_tidx(geom, pt, w, d < 0 ? -d : d)];
         Fp dx = fp_sub(n.yp, n.ym), sy = fp_add(n.yp, n.ym);
         Fp X = fp_add(dx, dx), T = fp_mul(dx, sy);
         if (d < 0) { X = fp_neg(X); T = fp_neg(T); }
@@ -580,6 +579,7 @@ int32_t sp_prof_read_shapes(sp_ctx* c, const char* family, uint64_t* shape, doub
   return k;
 }
 int sp_msm_window_bits(void) { return MSM_WBITS; }
+int sp_gens_window_bits(const sp_gens* g) { return g ? g->geom.wbits : 0; }
 int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap) {
   if (!c) return SP_EINVAL;
   prof_drain(c);
@@ -597,7 +597,7 @@ int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* 
 // they are built once per (device, generator bytes) and shared by every context of the process — concurrent proving
 // contexts on one GPU hold one copy, and re-creating a SNARKGens is free. Reference-counted; freed with the last handle.
 struct GensCacheEntry {
-  int dev, mode;
+  int dev, mode, wbits;
   size_t n, refs;
   std::vector<uint8_t> in, comp;
   Niels* table;
@@ -605,15 +605,41 @@ struct GensCacheEntry {
 static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
 
+// Window width of a generator set: the widest c whose tables (n points x ceil(254/c) windows x 2^(c-1) entries x 96 B) fit the
+// budget — SPARTAN_MSM_TABLE_GB (default 112) per set, and never more than the free device memory less a 24 GB reserve.
+// 288 GB of HBM3E is what makes this a knob: at 2^20 both generator streams get 15-bit windows (17 additions per scalar,
+// 27 + 110 GB of tables), at 2^22 the 8194-point evaluation stream falls back to 13 bits (20 additions, 64 GB), and a set too
+// large for 8-bit tables is refused. SPARTAN_MSM_WBITS forces a width (the tests use it to cover several).
+static int choose_wbits(size_t n) {
+  if (const char* e = getenv("SPARTAN_MSM_WBITS")) {
+    int v = atoi(e);
+    if (v >= 8 && v <= 15) return v;
+  }
+  double budget = 112.0;
+  if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    double avail = (double)free_b / 1e9 - 24.0;
+    if (avail < budget) budget = avail;
+  }
+  for (int cbits : {15, 14, 13, 12, 10, 8}) {
+    MsmGeom g = msm_geom(cbits);
+    if ((double)n * (double)g.pt_entries * sizeof(Niels) / 1e9 <= budget) return cbits;
+  }
+  return 0;
+}
 static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint8_t* comp_out, sp_gens** out) {
   if (!c || !in || !out || n == 0) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   size_t in_bytes = (mode == 0 ? 32 : 64) * n;
   std::lock_guard<std::mutex> lk(g_gens_mu);  // also serialises concurrent builds of the same table
   GensCacheEntry* hit = nullptr;
-  for (auto& e : g_gens_cache)
+  for (auto& e : g_gens_cache)  // a resident table set serves every later handle on the same points, whatever width it was built with
     if (e.dev == c->dev && e.mode == mode && e.n == n && memcmp(e.in.data(), in, in_bytes) == 0) { hit = &e; break; }
   if (!hit) {
+    int wbits = choose_wbits(n);
+    if (wbits == 0) return SP_ENOMEM;
+    MsmGeom geom = msm_geom(wbits);
     // scratch layout: [in bytes][pad][Pt n][comp 32n][bad int]
     size_t off_pts = (in_bytes + 255) & ~(size_t)255;
     size_t off_comp = off_pts + n * sizeof(Pt);
@@ -624,13 +650,13 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     HIPCHK(hipMemcpyAsync(base, in, in_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(base + off_bad, 0, 4, c->stream));
     Niels* table = nullptr;
-    HIPCHK(hipMalloc((void**)&table, n * MSM_PT_ENTRIES * sizeof(Niels)));
+    HIPCHK(hipMalloc((void**)&table, n * geom.pt_entries * sizeof(Niels)));
     {
-      ProfScope ps(c, PF_GENS_TABLE, (double)n * MSM_PT_ENTRIES * sizeof(Niels));
+      ProfScope ps(c, PF_GENS_TABLE, (double)n * geom.pt_entries * sizeof(Niels));
       hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
                          mode == 1 ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
-      size_t nt = n * MSM_NWIN * TB_NCHUNK;
-      hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table);
+      size_t nt = n * geom.nwin * (size_t)(geom.tent < 128 ? 1 : geom.tent / 128);
+      hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table, geom);
     }
     int bad = 0;
     std::vector<uint8_t> comp(mode == 1 ? 32 * n : 0);
@@ -641,7 +667,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
       (void)hipFree(table);
       return rc != SP_OK ? rc : SP_EPOINT;
     }
-    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table});
+    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table});
     hit = &g_gens_cache.back();
   }
   sp_gens* g = new (std::nothrow) sp_gens();
@@ -657,6 +683,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   g->ctx = c;
   g->n = n;
   g->table = hit->table;
+  g->geom = msm_geom(hit->wbits);
   g->cache_entry = hit;
   *out = g;
   return SP_OK;
@@ -689,13 +716,14 @@ struct MsmPlan {
   bool windowed, two_pass;
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
-static MsmPlan msm_plan(size_t rows, size_t cols, bool has_blinds) {
+static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_blinds) {
   MsmPlan m;
+  const size_t NWIN = (size_t)g->geom.nwin;
   size_t total = rows * cols, ncol = cols + (has_blinds ? 1 : 0);
-  m.windowed = rows * ncol * MSM_NWIN <= ((size_t)1 << 19);  // latency-bound shapes: one addition per thread
+  m.windowed = rows * ncol * NWIN <= ((size_t)1 << 19);  // latency-bound shapes: one addition per thread
   m.strip = 1; m.nstrips = 0;
   if (m.windowed) {
-    m.P = ncol * MSM_NWIN;
+    m.P = ncol * NWIN;
   } else {
     m.strip = total / 524288;  // enough threads for >= 4 waves per SIMD on 256 CUs
     if (m.strip < 1) m.strip = 1;
@@ -728,20 +756,20 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     ProfScope ps = scope(PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * m.P));
     size_t nthreads = rows * m.P;
     hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, dZ, z_stride, rows, cols, (const Niels*)g->table,
-                       g_off, didx, dblinds, h_idx, partial);
+                       g_off, didx, dblinds, h_idx, partial, g->geom);
   } else {
     // K1: 32 B read per committed scalar + 32 B written per row
     // ops: mixed additions if no scalar is zero; shape key: rows | cols | background launch
     uint64_t shape = ((uint64_t)rows << 32) | (uint64_t)cols | (st != c->stream ? (1ULL << 63) : 0);
-    ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * MSM_NWIN, shape);
+    ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * g->geom.nwin, shape);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
     if (st != c->stream && !didx && !dblinds && c->bg_blocks > 0) {
       hipLaunchKernelGGL(k_msm_rows_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
-                         (const Niels*)g->table, g_off, partial, xcd_map, nblocks);
+                         (const Niels*)g->table, g_off, partial, xcd_map, nblocks, g->geom);
     } else {
       hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
-                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map);
+                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
     }
   }
   if (m.two_pass) {
@@ -768,7 +796,7 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
 int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride) {
   if (idx_row_stride && (!didx || rows > SP_HOST_ENCODE_ROWS)) return SP_EINVAL;
-  MsmPlan m = msm_plan(rows, cols, dblinds != nullptr);
+  MsmPlan m = msm_plan(g, rows, cols, dblinds != nullptr);
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
   if (rows <= SP_HOST_ENCODE_ROWS) {  // latency path: the device sums, the host core runs the encode chain
@@ -781,10 +809,10 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
         ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));
         if (nblk == 1)
           hipLaunchKernelGGL((k_msm_windows_tree<true>), dim3(1, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols, (const Niels*)g->table,
-                             g_off, didx, idx_row_stride, dblinds, h_idx, (void*)sums_dst);
+                             g_off, didx, idx_row_stride, dblinds, h_idx, (void*)sums_dst, g->geom);
         else
           hipLaunchKernelGGL((k_msm_windows_tree<false>), dim3((unsigned)nblk, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols,
-                             (const Niels*)g->table, g_off, didx, idx_row_stride, dblinds, h_idx, (void*)part);
+                             (const Niels*)g->table, g_off, didx, idx_row_stride, dblinds, h_idx, (void*)part, g->geom);
       }
       if (nblk > 1) {
         ProfScope ps(c, PF_MSM_REDUCE, 160.0 * (double)(rows * nblk) + 128.0 * (double)rows);
@@ -830,7 +858,7 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
                                  sp_job** out) {
   if (!c || !g || !Z || !out || rows == 0 || cols == 0 || g_off + cols > g->n || z_off + rows * cols > Z->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  MsmPlan m = msm_plan(rows, cols, false);
+  MsmPlan m = msm_plan(g, rows, cols, false);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream_bg;
@@ -869,7 +897,7 @@ int32_t sp_commit_rows_dev_start(sp_ctx* c, const sp_gens* g, size_t g_off, size
     SPCHK(stage_in(c, 0, blinds, 32 * rows));
     dbl = (const Fq*)c->dstage;
   }
-  MsmPlan m = msm_plan(rows, cols, blinds != nullptr);
+  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream;
@@ -940,7 +968,7 @@ int32_t sp_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, 
 }
 int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows,
                           uint8_t* sums_out) {
-  if (!c || !g || !idx || !S || !sums_out || rows == 0 || rows > SP_HOST_ENCODE_ROWS || cols == 0 || cols * MSM_NWIN > 256) return SP_EINVAL;
+  if (!c || !g || !idx || !S || !sums_out || rows == 0 || rows > SP_HOST_ENCODE_ROWS || cols == 0 || cols * (size_t)g->geom.nwin > 256) return SP_EINVAL;
   for (size_t j = 0; j < cols; j++)
     if (idx[j] >= g->n) return SP_EINVAL;
   size_t sb = 32 * rows * cols, ib = (4 * cols + 31) & ~(size_t)31;
@@ -949,7 +977,7 @@ int32_t msm_small_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const uin
   const uint32_t* di = (const uint32_t*)stage_small(c, sb, idx, 4 * cols);
   ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 128.0 * (double)rows, st);
   hipLaunchKernelGGL((k_msm_windows_tree<true>), dim3(1, (unsigned)rows), dim3(256), 0, st, ds, cols, cols, (const Niels*)g->table, (size_t)0, di, (size_t)0,
-                     (const Fq*)nullptr, (size_t)0, (void*)sums_out);
+                     (const Fq*)nullptr, (size_t)0, (void*)sums_out, g->geom);
   return SP_OK;
 }
 int32_t sp_msm_indexed(sp_ctx* c, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out) {

@@ -102,7 +102,8 @@ struct sp_ctx {
 struct sp_gens {
   sp_ctx* ctx;
   size_t n;
-  Niels* table;  // [n][MSM_NWIN][MSM_TENT]; owned by the process-wide table cache (core.hip), shared between contexts
+  Niels* table;  // [n][nwin][tent]; owned by the process-wide table cache (core.hip), shared between contexts
+  MsmGeom geom;  // window geometry these tables were built with
   void* cache_entry;
 };
 struct sp_index {  // a usize vector kept as u32 on the device (addresses of the SPARK memory checks)

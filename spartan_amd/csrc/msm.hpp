@@ -22,17 +22,35 @@ constexpr int MSM_TENT = 1 << (MSM_WBITS - 1);                 // entries per (p
 constexpr size_t MSM_PT_ENTRIES = (size_t)MSM_NWIN * MSM_TENT;
 static_assert(MSM_WBITS >= 4 && MSM_WBITS <= 15, "window width");
 
-// index of entry (point pt, window w, magnitude m in 1..MSM_TENT)
+// The window width is a property of a generator set (sp_gens), chosen when its tables are built: the widest c whose tables
+// fit the HBM budget (core.hip, choose_wbits) — 15 bits (17 additions per scalar) for the generators of a 2^20 instance,
+// 13 for a 2^22 one, less for larger sets. The constants above are the default geometry (and the one the host-side
+// arithmetic tests use).
+struct MsmGeom {
+  int wbits, nwin, tent;   // signed window width c, windows per scalar, entries per (point, window) = 2^(c-1)
+  size_t pt_entries;       // nwin * tent
+};
+SP_HD MsmGeom msm_geom(int wbits) {
+  MsmGeom g;
+  g.wbits = wbits;
+  g.nwin = (254 + wbits - 1) / wbits;
+  g.tent = 1 << (wbits - 1);
+  g.pt_entries = (size_t)g.nwin * (size_t)g.tent;
+  return g;
+}
+// index of entry (point pt, window w, magnitude m in 1..tent)
+SP_HD size_t msm_tidx(const MsmGeom& g, size_t pt, int w, int m) { return (pt * g.nwin + (size_t)w) * g.tent + (size_t)(m - 1); }
 SP_HD size_t msm_tidx(size_t pt, int w, int m) { return (pt * MSM_NWIN + (size_t)w) * MSM_TENT + (size_t)(m - 1); }
 
 // raw c-bit field of a canonical 256-bit integer at window w
-SP_HD uint32_t msm_field(const Fq& s, int w) {
-  int bit = w * MSM_WBITS, k = bit >> 6, sh = bit & 63;
+SP_HD uint32_t msm_field(const Fq& s, int w, int wbits) {
+  int bit = w * wbits, k = bit >> 6, sh = bit & 63;
   if (k > 3) return 0;
   uint64_t x = s.l[k] >> sh;
-  if (sh + MSM_WBITS > 64 && k < 3) x |= s.l[k + 1] << (64 - sh);
-  return (uint32_t)(x & ((1u << MSM_WBITS) - 1));
+  if (sh + wbits > 64 && k < 3) x |= s.l[k + 1] << (64 - sh);
+  return (uint32_t)(x & ((1u << wbits) - 1));
 }
+SP_HD uint32_t msm_field(const Fq& s, int w) { return msm_field(s, w, MSM_WBITS); }
 // signed recoding of a canonical scalar (< 2^253): digits d_w in [-2^(c-1), 2^(c-1) - 1], sum d_w 2^(c w) = s.
 // mag[w] = |d_w| (0..2^(c-1)), neg bit w = (d_w < 0).
 SP_HD void msm_recode(const Fq& s, uint16_t mag[MSM_NWIN], uint32_t* neg) {
@@ -49,47 +67,51 @@ SP_HD void msm_recode(const Fq& s, uint16_t mag[MSM_NWIN], uint32_t* neg) {
   *neg = ng;
 }
 // digit of window w only (latency-bound kernels: one thread per window)
-SP_HD int msm_digit(const Fq& s, int w) {
+SP_HD int msm_digit(const Fq& s, int w, const MsmGeom& g) {
   int carry = 0, d = 0;
   for (int k = 0; k <= w; k++) {  // the carry into window w depends on all lower windows
-    d = (int)msm_field(s, k) + carry;
-    carry = d >= MSM_TENT;
-    d -= carry << MSM_WBITS;
+    d = (int)msm_field(s, k, g.wbits) + carry;
+    carry = d >= g.tent;
+    d -= carry << g.wbits;
   }
   return d;
 }
+SP_HD int msm_digit(const Fq& s, int w) { return msm_digit(s, w, msm_geom(MSM_WBITS)); }
 
 // acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar. The table entry of the
 // next window is requested before the current mixed addition so the gather latency overlaps the 7 multiplications.
-SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) {
+SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) {
   if (fq_is_zero(s_mont)) return;
   Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
-  const Niels* base = table + pt * MSM_PT_ENTRIES;
+  const Niels* base = table + pt * g.pt_entries;
   // digits are produced on the fly by shifting the scalar down one window per step (8 live registers instead of a
-  // 22-entry digit array; the loop stays rolled so the register budget allows a third wave per SIMD)
-  int d = (int)(s.l[0] & ((1u << MSM_WBITS) - 1));
-  int carry = d >= MSM_TENT;
-  d -= carry << MSM_WBITS;
+  // digit array; the loop stays rolled so the register budget allows a third wave per SIMD)
+  const int c = g.wbits;
+  const uint32_t mask = (1u << c) - 1;
+  int d = (int)(s.l[0] & mask);
+  int carry = d >= g.tent;
+  d -= carry << c;
   uint32_t m = (uint32_t)(d < 0 ? -d : d);
   bool ng = d < 0;
   Niels cur = base[m ? m - 1 : 0];
 #pragma unroll 1
-  for (int w = 0; w < MSM_NWIN; w++) {
-    s.l[0] = (s.l[0] >> MSM_WBITS) | (s.l[1] << (64 - MSM_WBITS));
-    s.l[1] = (s.l[1] >> MSM_WBITS) | (s.l[2] << (64 - MSM_WBITS));
-    s.l[2] = (s.l[2] >> MSM_WBITS) | (s.l[3] << (64 - MSM_WBITS));
-    s.l[3] >>= MSM_WBITS;
-    int dn = (int)(s.l[0] & ((1u << MSM_WBITS) - 1)) + carry;  // window w+1 (zero past the top: s < 2^253)
-    carry = dn >= MSM_TENT;
-    dn -= carry << MSM_WBITS;
+  for (int w = 0; w < g.nwin; w++) {
+    s.l[0] = (s.l[0] >> c) | (s.l[1] << (64 - c));
+    s.l[1] = (s.l[1] >> c) | (s.l[2] << (64 - c));
+    s.l[2] = (s.l[2] >> c) | (s.l[3] << (64 - c));
+    s.l[3] >>= c;
+    int dn = (int)(s.l[0] & mask) + carry;  // window w+1 (zero past the top: s < 2^253)
+    carry = dn >= g.tent;
+    dn -= carry << c;
     uint32_t mn = (uint32_t)(dn < 0 ? -dn : dn);
-    int wn = (w + 1 < MSM_NWIN) ? w + 1 : w;
-    Niels nxt = base[(size_t)wn * MSM_TENT + (mn ? mn - 1 : 0)];
+    int wn = (w + 1 < g.nwin) ? w + 1 : w;
+    Niels nxt = base[(size_t)wn * g.tent + (mn ? mn - 1 : 0)];
     if (m != 0) acc = pt_madd(acc, cur, ng);
     cur = nxt;
     m = mn;
     ng = dn < 0;
   }
 }
+SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) { msm_accumulate(acc, s_mont, table, pt, msm_geom(MSM_WBITS)); }
 
 }  // namespace sp

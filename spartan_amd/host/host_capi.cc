@@ -133,6 +133,8 @@ size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
   if (out && cap >= v.size()) memcpy(out, v.data(), v.size());
   return v.size();
 }
+// window width of the fixed-base tables of a generator stream (0: gens_r1cs_sat, 1: gens_r1cs_eval)
+int spz_snark_gens_window_bits(void* g, int which) { return sp_gens_window_bits(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
 // bincode of SNARKGens / ComputationCommitment (wire formats)
 size_t spz_snark_gens_bincode(void* g, uint8_t* out, size_t cap) {
   std::vector<uint8_t> b = ((SNARKGens*)g)->serialize();

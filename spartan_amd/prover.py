@@ -102,6 +102,10 @@ class SNARKGens:
         H.spz_snark_gens_stream(self.h, ctypes.c_int(which), b, sz(n))
         return bytes(b)
 
+    def window_bits(self, which):
+        """signed window width of the fixed-base tables of generator stream `which` (0: gens_r1cs_sat, 1: gens_r1cs_eval)"""
+        return int(H.spz_snark_gens_window_bits(self.h, ctypes.c_int(which)))
+
     def serialize(self):
         n = H.spz_snark_gens_bincode(self.h, None, sz(0)); b = (ctypes.c_uint8 * n)()
         H.spz_snark_gens_bincode(self.h, b, sz(n))

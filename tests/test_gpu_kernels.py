@@ -108,6 +108,36 @@ def test_commit_rows_launch_plans_match_oracle(ctx, orc, gens301, rows, cols, bl
     assert got == bytes(want)
 
 
+@pytest.mark.parametrize("wbits", [8, 10, 12, 13, 14, 15])
+def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
+    """the window width is a property of the generator set, chosen at upload (core.hip choose_wbits; SPARTAN_MSM_WBITS forces
+    it): every width gives the same commitments through every launch plan (one-launch small, windowed trees, row strips, the
+    indexed lookups of the inner-product argument)"""
+    from spartan_amd import capi
+    monkeypatch.setenv("SPARTAN_MSM_WBITS", str(wbits))
+    label = b"gens_width_%d" % wbits      # fresh points per width: a resident table set would be reused whatever its width
+    g = capi.Gens(ctx, compressed=gens_bytes(orc, 130, label))
+    assert g.window_bits() == wbits
+    gb = g.compressed
+    rng = random.Random(wbits)
+    for rows, cols, blind, kind in [(1, 130, True, "uniform"), (6, 3, False, "edge"), (40, 128, True, "uniform"), (300, 64, True, "uniform"), (9, 17, False, "sparse")]:
+        Z = rand_scalars(rng, rows * cols, kind)
+        bl = rand_scalars(rng, rows, "uniform") if blind else None
+        got = g.commit_rows(mont_array(Z), rows, cols, mont_array(bl) if blind else None, g_off=0, h_idx=130)
+        want = (ctypes.c_uint8 * (32 * rows))()
+        assert orc.orc_commit_rows(gb[:32 * cols], sz(cols), gb[32 * 130:], mont_array(Z), sz(rows), sz(cols), mont_array(bl) if blind else None, want) == 0
+        assert got == bytes(want), (wbits, rows, cols)
+    idx = [130, 0, 7, 7, 99]
+    S = rand_scalars(rng, 2 * len(idx))
+    got = g.msm_indexed(idx, mont_array(S), rows=2)
+    pts = b"".join(gb[32 * i:32 * i + 32] for i in idx)
+    out = (ctypes.c_uint8 * 32)()
+    for r in range(2):
+        assert orc.orc_pt_msm(mont_array(S[r * 5:(r + 1) * 5]), pts, sz(5), out) == 1
+        assert got[32 * r:32 * r + 32] == bytes(out)
+    g.free()
+
+
 def test_commit_rows_dev_and_offset(ctx, orc, gens40):
     from spartan_amd import capi
     rng = random.Random(5)
