@@ -133,6 +133,12 @@ int32_t sp_table_bind_top(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, cons
 int32_t sp_table_bind_top_heads(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_heads);
 /* Fused: bind all tables at r, then evaluate the next round on the bound tables in the same pass. */
 int32_t sp_sumcheck_bind_eval(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals);
+/* sp_sumcheck_bind_eval in two halves: _start queues the bind and the evaluation and returns at once, _collect waits for the
+ * sums. The host driver computes the round's few-term commitments on its own core in between (the device needs ~25 us for a
+ * small round, the commitments about as long). No other call on ctx may come between the two; SP_EINVAL if one is pending
+ * (_start) or none is (_collect). */
+int32_t sp_sumcheck_bind_eval_start(sp_ctx* ctx, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4]);
+int32_t sp_sumcheck_bind_eval_collect(sp_ctx* ctx, uint64_t* out_evals);
 /* One round body of the zero-knowledge sum-checks (sumcheck.rs:471-583 / 661-772): sp_sumcheck_bind_eval at r and, at the
  * same time on a second stream, the `rows` <= 8 small commitments of the round whose scalars are known as soon as r is
  * (comm_eval and the DotProductProof's delta): out_points[k] = compress( sum_j S[k*cols+j] * P[idx[j]] ), cols <= 11.

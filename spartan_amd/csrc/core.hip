@@ -88,9 +88,12 @@ __global__ void k_done(volatile uint32_t* flag, uint32_t seq) {
 }
 // Wait until everything queued on the main stream has run. The stream is in-order, so the flag kernel runs after the
 // kernels (and copies) before it have completed, and their results in host memory precede the flag on the way to the host.
-int32_t sync_spin(sp_ctx* c) {
+uint32_t sync_post(sp_ctx* c) {
   uint32_t seq = ++c->done_seq;
   hipLaunchKernelGGL(k_done, dim3(1), dim3(1), 0, c->stream, c->done_flag, seq);
+  return seq;
+}
+int32_t sync_wait(sp_ctx* c, uint32_t seq) {
   for (uint64_t spins = 1;; spins++) {
     if (*c->done_flag == seq) { c->sync_epoch++; return SP_OK; }
     if ((spins & 0xFFFFF) == 0) {  // every ~ms: a faulted queue never delivers the flag
@@ -107,6 +110,14 @@ int32_t sync_spin(sp_ctx* c) {
     }
   }
 }
+int32_t sync_spin(sp_ctx* c) { return sync_wait(c, sync_post(c)); }
+DoneSig sig_make(sp_ctx* c, size_t total_workgroups) {
+  static const bool off = getenv("SPARTAN_NO_KERNEL_SIGNAL") != nullptr;  // A/B switch: completion by a flag kernel behind the last kernel
+  if (off || !c->done_counter) return sig_none();
+  return DoneSig{c->done_flag, c->done_counter, ++c->done_seq, (uint32_t)total_workgroups};
+}
+// wait for a trip whose last kernel was launched with `sig` (falls back to the flag kernel when the signal is off)
+int32_t sig_wait(sp_ctx* c, const DoneSig& sig) { return sig.flag ? sync_wait(c, sig.seq) : sync_spin(c); }
 int32_t fetch_small(sp_ctx* c, void* hdst, size_t bytes) {
   SPCHK(sync_spin(c));
   memcpy(hdst, hres(c), bytes);
@@ -495,6 +506,8 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   HIPCHK(hipHostMalloc((void**)&c->done_flag, 64, hipHostMallocDefault));
   *c->done_flag = 0;
   c->done_seq = 0;
+  HIPCHK(hipMalloc((void**)&c->done_counter, 64));
+  HIPCHK(hipMemset(c->done_counter, 0, 64));
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
   return SP_OK;
 }
@@ -514,6 +527,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->sess_slots) (void)hipHostFree(c->sess_slots);
   if (c->sess_dev) (void)hipFree(c->sess_dev);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
+  if (c->done_counter) (void)hipFree(c->done_counter);
   if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
   if (c->side_ev) (void)hipEventDestroy(c->side_ev);
   if (c->stream_side) (void)hipStreamDestroy(c->stream_side);

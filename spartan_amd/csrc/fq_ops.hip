@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval(Tabs4 T, size_t quarter, F
 }
 // the same for any number of tables of one length (pointer list in the host-mapped page); heads != nullptr with half == 1:
 // the bound value (the table's only remaining entry) also goes to the result area — bound_poly_var_top + [0] in one launch
-__global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ ptrs, size_t ntabs, size_t half, Fq r, Fq* __restrict__ heads) {
+__global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ ptrs, size_t ntabs, size_t half, Fq r, Fq* __restrict__ heads, DoneSig sig) {
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ntabs * half; idx += (size_t)gridDim.x * blockDim.x) {
     size_t t = idx / half, i = idx % half;
     Fq* p = ptrs[t];
@@ -210,13 +210,14 @@ __global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ p
     st_fq(p + i, v);
     if (heads) st_fq(heads + t, v);
   }
+  signal_done(sig);
 }
 // Latency form of k_sc_bind_eval for short tables (quarter <= 8192), kinds 0 (A*B) and 2 (A*(B*C-D)): as in
 // k_cubic_bind_eval_tiny (spark.hip) the multiplications of one index are spread over 8 lanes — lane 2k+h binds half h of
 // table k, then lanes 0..2 evaluate t = 0, 2, 3 with one instruction stream (operands chosen by selects). Block = 32
 // indices x 8 lanes; partials[blk][3].
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
   constexpr int NT = KIND == 0 ? 2 : 4;
   __shared__ Fq bound[32][8];  // [index][table*2 + half]
   __shared__ Fq red[3][32];
@@ -255,6 +256,7 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quart
     __syncthreads();
   }
   if (threadIdx.x < 3) st_fq(partials + (size_t)blockIdx.x * 3 + threadIdx.x, red[threadIdx.x][0]);
+  signal_done(sig);
 }
 __global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t half, Fq r) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t hal
   }
 }
 // partials[nblk][K] -> out[K] ; single block
-__global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) {
   __shared__ Fq sm[256];
   for (int k = 0; k < K; k++) {
     Fq acc[1] = {fq_zero()};
@@ -273,6 +275,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ 
     block_sum_fq<1>(acc, sm);
     if (threadIdx.x == 0) st_fq(out + k, acc[0]);
   }
+  signal_done(sig);
 }
 // DensePolynomial::bound (dense_mlpoly.rs:206-213): out[i] = sum_j L[j] * Z[j*R + i], in two stages.
 // Stage 1, grid (ceil(R/64), nchunks): a block covers 64 columns x one chunk of rows; its 256 threads are 64 columns x 4 row
@@ -337,11 +340,13 @@ static void host_sum(const Fq* p, size_t nblk, int K, uint64_t* out) {
 }
 int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out) {
   if (partials != (Fq*)hres(c)) {
+    DoneSig sig = sig_make(c, 1);
     {
       ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * K));
-      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, (Fq*)hres(c));
+      hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, K, (Fq*)hres(c), sig);
     }
-    SPCHK(fetch_small(c, out, 32 * K));
+    SPCHK(sig_wait(c, sig));
+    memcpy(out, hres(c), 32 * K);
     return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
   }
   SPCHK(sync_spin(c));
@@ -467,14 +472,15 @@ static int32_t bind_top_list(sp_ctx* c, sp_table* const* tabs, size_t ntabs, con
   HIPCHK(hipSetDevice(c->dev));
   Fq* const* dp = (Fq* const*)stage_small(c, 0, ptrs.data(), 8 * ntabs);
   size_t half = len / 2;
+  DoneSig sig = sig_make(c, grid_for(ntabs * half));
   {
     ProfScope ps(c, PF_SC_BIND, 48.0 * (double)len * (double)ntabs);
     hipLaunchKernelGGL(k_bind_top_list, dim3((unsigned)grid_for(ntabs * half)), dim3(256), 0, c->stream, dp, ntabs, half, limbs4(r),
-                       out_heads ? (Fq*)hres(c) : (Fq*)nullptr);
+                       out_heads ? (Fq*)hres(c) : (Fq*)nullptr, sig);
   }
   for (size_t k = 0; k < ntabs; k++) tabs[k]->len = half;
-  if (out_heads) SPCHK(fetch_small(c, out_heads, 32 * ntabs));
-  else SPCHK(sync_spin(c));  // the pointer list sits in the shared input page
+  SPCHK(sig_wait(c, sig));  // also without heads: the pointer list sits in the shared input page
+  if (out_heads) memcpy(out_heads, hres(c), 32 * ntabs);
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_table_bind_top_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_heads) {
@@ -497,8 +503,8 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs, nullptr, (kind == 0 ? 6.0 : (kind == 1 ? 12.0 : 14.0)) * (double)quarter);
-    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
-    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials, sig_none());
+    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials, sig_none());
     else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -509,6 +515,58 @@ int32_t sp_sumcheck_bind_eval(sp_ctx* c, int kind, sp_table* const* tabs, size_t
   memcpy(out_evals, e, 32);
   memcpy(out_evals + 4, e + 4, 32);
   if (kind != 0) memcpy(out_evals + 8, e + 8, 32);
+  return SP_OK;
+}
+// The same round in two halves: _start queues the bind and the evaluation and returns; _collect waits for the sums. The
+// caller (the ZK sum-check of the host driver) computes the round's commitments on its own core in between. No other call
+// on this context may come between the two: the sums travel through the context's result page.
+int32_t sp_sumcheck_bind_eval_start(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4]) {
+  if (kind < 0 || kind > 2 || !r) return SP_EINVAL;
+  Tabs4 T;
+  size_t len;
+  SPCHK(tabs_check(c, tabs, ntabs, kind == 0 ? 2 : (kind == 1 ? 3 : 4), &T, &len));
+  if (len < 4 || c->pend_eval.active) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  Fq rr;
+  memcpy(rr.l, r, 32);
+  size_t quarter = len / 4;
+  bool tiny = kind != 1 && quarter <= 8192;
+  size_t nblk = tiny ? (quarter + 31) / 32 : grid_for(quarter, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk * 3 + 3)));
+  Fq* partials = tiny ? partials_dst(c, nblk, 3) : (Fq*)c->scratch;
+  const bool on_host = partials == (Fq*)hres(c);
+  DoneSig sig = sig_make(c, on_host ? nblk : 1);
+  {
+    ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs, nullptr, (kind == 0 ? 6.0 : (kind == 1 ? 12.0 : 14.0)) * (double)quarter);
+    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials, on_host ? sig : sig_none());
+    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials, on_host ? sig : sig_none());
+    else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    else hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+  }
+  for (size_t k = 0; k < ntabs; k++) tabs[k]->len = len / 2;
+  if (!on_host) {
+    ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * 3));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c), sig);
+  }
+  c->pend_eval.active = true;
+  c->pend_eval.kind = kind;
+  c->pend_eval.nblk = nblk;
+  c->pend_eval.on_host = on_host;
+  c->pend_eval.seq = sig.flag ? sig.seq : sync_post(c);
+  return SP_OK;
+}
+int32_t sp_sumcheck_bind_eval_collect(sp_ctx* c, uint64_t* out_evals) {
+  if (!c || !out_evals || !c->pend_eval.active) return SP_EINVAL;
+  c->pend_eval.active = false;
+  SPCHK(sync_wait(c, c->pend_eval.seq));
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  uint64_t e[12];
+  if (c->pend_eval.on_host) host_sum((const Fq*)hres(c), c->pend_eval.nblk, 3, e);
+  else memcpy(e, hres(c), 96);
+  memcpy(out_evals, e, 32);
+  memcpy(out_evals + 4, e + 4, 32);
+  if (c->pend_eval.kind != 0) memcpy(out_evals + 8, e + 8, 32);
   return SP_OK;
 }
 int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs, size_t ntabs, const uint64_t r[4], uint64_t* out_evals,
@@ -536,8 +594,8 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
   Fq* partials = partials_dst(c, nblk, 3);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, 48.0 * (double)len * (double)ntabs, nullptr, (kind == 0 ? 6.0 : (kind == 1 ? 12.0 : 14.0)) * (double)quarter);
-    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
-    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
+    if (tiny && kind == 0) hipLaunchKernelGGL(k_sc_bind_eval_tiny<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials, sig_none());
+    else if (tiny) hipLaunchKernelGGL(k_sc_bind_eval_tiny<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials, sig_none());
     else if (kind == 0) hipLaunchKernelGGL(k_sc_bind_eval<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else if (kind == 1) hipLaunchKernelGGL(k_sc_bind_eval<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
     else hipLaunchKernelGGL(k_sc_bind_eval<2>, dim3((unsigned)nblk), dim3(256), 0, c->stream, T, quarter, rr, partials);
@@ -545,7 +603,7 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
   for (size_t k = 0; k < ntabs; k++) tabs[k]->len = len / 2;
   if (partials != (Fq*)hres(c)) {
     ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * 3));
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c));
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c), sig_none());
   }
   HIPCHK(hipStreamWaitEvent(c->stream, c->side_ev, 0));  // one completion for both streams
   SPCHK(sync_spin(c));

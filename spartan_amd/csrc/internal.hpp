@@ -76,6 +76,8 @@ struct sp_ctx {
   unsigned eq_next;
   volatile uint32_t* done_flag;
   uint32_t done_seq;
+  uint32_t* done_counter = nullptr;  // DoneSig::counter
+  struct { bool active; int kind; size_t nblk; bool on_host; uint32_t seq; } pend_eval = {false, 0, 0, false, 0};  // sp_sumcheck_bind_eval_start .. _collect
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
 
   // resident sum-check sessions (session.hip): command mailbox + per-workgroup result slots in coherent host memory, the
@@ -183,6 +185,34 @@ void prof_drain(sp_ctx* c);
 int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes);   // host -> c->dstage (+off), async
 int32_t ensure_dstage(sp_ctx* c, size_t need);
 int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes);  // device -> host, synchronous
+// Completion signalled by the LAST KERNEL of a round trip itself instead of by a flag kernel queued behind it (~4 us of
+// dispatch per trip, ~500 trips per proof): every workgroup fences its results to system scope and counts itself in; the
+// last one stores the sequence number the host is spinning on. flag == nullptr: no signal (the kernel is not the last).
+struct DoneSig {
+  volatile uint32_t* flag;
+  uint32_t* counter;  // device word, zero between kernels (the signalling workgroup resets it)
+  uint32_t seq, total;  // total: workgroups of the launch
+};
+static inline DoneSig sig_none() { return DoneSig{nullptr, nullptr, 0, 0}; }
+DoneSig sig_make(sp_ctx* c, size_t total_workgroups);
+int32_t sig_wait(sp_ctx* c, const DoneSig& sig);  // reserves the next sequence number; wait for it with sync_wait(c, sig.seq)
+#if defined(__HIPCC__)
+__device__ __forceinline__ void signal_done(const DoneSig& d) {  // call once per workgroup, by all its threads, after its last result store
+  if (!d.flag) return;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    __threadfence_system();
+    if (d.total > 1) {
+      if (atomicAdd(d.counter, 1u) != d.total - 1) return;
+      __threadfence_system();
+      *d.counter = 0;
+    }
+    *d.flag = d.seq;
+  }
+}
+#endif
+uint32_t sync_post(sp_ctx* c);               // queue the completion flag behind everything on the main stream
+int32_t sync_wait(sp_ctx* c, uint32_t seq);  // spin until that flag has arrived
 // Enqueue (no wait) the lookups + tree of a commitment with <= 256 (column, window) pairs per row and rows <= 8 on `st`:
 // scalars S[rows][cols] and generator indices are staged in the host-mapped input page, the row sums (extended points)
 // land at sums_out (device-visible). core.hip.

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* _
 // Latency form of the fused round for short tables (quarter <= a few hundred): the ~12 dependent field
 // multiplications of one index are spread over 8 lanes (six do one bind each, then three do one evaluation point
 // each), so a round costs ~3 multiplications of latency instead of 12. Block = 32 indices x 8 roles; grid (nblk, ninst).
-__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
   __shared__ Fq bound[32][6];  // [index][table*2 + half]
   __shared__ Fq red[3][32];
   Triple t = T[blockIdx.y];
@@ -133,10 +133,11 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __re
     __syncthreads();
   }
   if (threadIdx.x < 3) st_fq(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x, red[threadIdx.x][0]);
+  signal_done(sig);
 }
 // Latency form of k_cubic_eval_batched (the first round of a layer's sum-check, half <= 8192): four lanes per index, lanes
 // 0..2 evaluate t = 0, 2, 3 with one instruction stream; block = 64 indices; grid (nblk, ninst).
-__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, size_t half, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, size_t half, Fq* __restrict__ partials, DoneSig sig) {
   __shared__ Fq red[3][64];
   Triple t = T[blockIdx.y];
   int li = threadIdx.x >> 2, role = threadIdx.x & 3;
@@ -161,6 +162,7 @@ __global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restric
     __syncthreads();
   }
   if (threadIdx.x < 3) st_fq(partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x, red[threadIdx.x][0]);
+  signal_done(sig);
 }
 
 // ---- two rounds per launch (the latency-bound tail of prove_cubic_batched, sumcheck.rs:287-393) -----------------------
@@ -189,7 +191,7 @@ __device__ __forceinline__ Fq line_at(const Fq& u, const Fq& v, int t) {  // the
   return r;
 }
 __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
-                                                          Fq* __restrict__ partials) {
+                                                          Fq* __restrict__ partials, DoneSig sig) {
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
   __shared__ Fq red[18][8];
@@ -270,9 +272,10 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
     else v = (n2 == 1 && blockIdx.x == 0) ? bnd[0][(x - 15) * 4] : fq_zero();  // final claims
     st_fq(o + x, v);
   }
+  signal_done(sig);
 }
 // partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
-__global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) {
   __shared__ Fq sm[256];
   const Fq* p = partials + (size_t)blockIdx.x * nblk * K;
   for (int k = 0; k < K; k++) {
@@ -281,6 +284,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __res
     block_sum_fq<1>(acc, sm);
     if (threadIdx.x == 0) st_fq(out + (size_t)blockIdx.x * K + k, acc[0]);
   }
+  signal_done(sig);
 }
 // grid (nblk, nt): partials[t*nblk + blk] = partial <chi, T_t>
 __global__ void __launch_bounds__(256) k_dot_many(const Fq* __restrict__ chi, Fq* const* __restrict__ tabs, size_t n, Fq* __restrict__ partials) {
@@ -432,14 +436,19 @@ static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, 
 // straight into the host-mapped result page and the calling thread adds them — F_q additions are nanoseconds there,
 // while a second launch to add them costs ~10 us on the critical path.
 static bool host_sums(size_t nblk, size_t ninst) { return nblk == 1 || 96 * nblk * ninst <= HOST_SUM_BYTES; }
-static int32_t batched_finish(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out) {
+// sig: the completion signal of the trip — already raised by the evaluation kernel when it wrote its partials into the
+// host page (on_host), raised by the reduction kernel launched here otherwise
+static int32_t batched_finish(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out, const DoneSig& sig) {
   if (partials != (Fq*)hres(c)) {
-    ProfScope ps(c, PF_REDUCE, 96.0 * (double)(nblk * ninst));
-    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c));
-    SPCHK(fetch_small(c, out, 96 * ninst));
+    {
+      ProfScope ps(c, PF_REDUCE, 96.0 * (double)(nblk * ninst));
+      hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 3, (Fq*)hres(c), sig);
+    }
+    SPCHK(sig_wait(c, sig));
+    memcpy(out, hres(c), 96 * ninst);
     return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
   }
-  SPCHK(sync_spin(c));
+  SPCHK(sig_wait(c, sig));
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
   const Fq* p = (const Fq*)hres(c);  // [inst][blk][3]
   Fq* o = (Fq*)out;
@@ -460,13 +469,15 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   bool tiny = half <= 8192;
   size_t nblk = tiny ? (half + 63) / 64 : grid_for(half, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
-  Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
+  bool on_host = host_sums(nblk, ninst) && tiny;
+  Fq* partials = on_host ? (Fq*)hres(c) : (Fq*)c->scratch;
+  DoneSig sig = sig_make(c, on_host ? nblk * ninst : ninst);
   {
     ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, 6.0 * (double)half * (double)ninst);
-    if (tiny) hipLaunchKernelGGL(k_cubic_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
+    if (tiny) hipLaunchKernelGGL(k_cubic_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials, on_host ? sig : sig_none());
     else hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
   }
-  return batched_finish(c, partials, nblk, ninst, out);
+  return batched_finish(c, partials, nblk, ninst, out, sig);
 }
 int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t r[4],
                                       uint64_t* out) {
@@ -482,12 +493,14 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   bool tiny = quarter <= 8192;  // one index per 8 lanes while the round is latency-bound (512 / 2048 / 8192 / 32768 measured: 45.3 / 45.0 / 44.8 / 45.6 ms per proof)
   size_t nblk = tiny ? (quarter + 31) / 32 : grid_for(quarter, 256);
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 3 * (nblk + 1) * ninst));
-  Fq* partials = host_sums(nblk, ninst) ? (Fq*)hres(c) : (Fq*)c->scratch;
+  bool on_host = host_sums(nblk, ninst) && tiny;
+  Fq* partials = on_host ? (Fq*)hres(c) : (Fq*)c->scratch;
+  DoneSig sig = sig_make(c, on_host ? nblk * ninst : ninst);
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst, nullptr, 12.0 * (double)quarter * (double)ninst);
     if (tiny)
       hipLaunchKernelGGL(k_cubic_bind_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
-                         limbs(r), partials);
+                         limbs(r), partials, on_host ? sig : sig_none());
     else
       hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
                          limbs(r), partials);
@@ -497,11 +510,11 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   for (size_t k = 0; k < ninst; k++) { A[k]->len = len / 2; B[k]->len = len / 2; }
   for (size_t k = 0; k < ninst; k++)
     if (C[k]->len == len) table_swap_to_alt(C[k], len / 2);
-  return batched_finish(c, partials, nblk, ninst, out);
+  return batched_finish(c, partials, nblk, ninst, out, sig);
 }
 
 // partials[ninst][nblk][18] -> out[ninst][18], one block per instance: thread = (component k < 18 of 32, slice of blocks)
-__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out, DoneSig sig) {
   __shared__ Fq sm[8][18];
   const int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const Fq* p = partials + (size_t)blockIdx.x * nblk * 18;
@@ -517,6 +530,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict_
     for (int j = 1; j < 8; j++) acc = fq_add(acc, sm[j][threadIdx.x]);
     st_fq(out + (size_t)blockIdx.x * 18 + threadIdx.x, acc);
   }
+  signal_done(sig);
 }
 // shared by the two entry points below: launch k_cubic_bind2_eval, bring the 18 sums per instance to the host
 static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int nbind, const uint64_t* r0, const uint64_t* r1,
@@ -550,18 +564,22 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
   bool host = 32 * 18 * nblk * ninst <= HOST_SUM_BYTES;
   Fq* partials = host ? (Fq*)hres(c) : (Fq*)c->scratch;
   Fq z = fq_zero();
+  DoneSig sig = sig_make(c, host ? nblk * ninst : ninst);  // raised by the last kernel of the trip
   {
     ProfScope ps(c, do_bind ? PF_SC_BIND_EVAL : PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, (do_bind ? 36.0 + 36.0 : 36.0) * (double)ng * (double)ninst);
     hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple2*)c->hmap, dweights, len, nbind,
-                       r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials);
+                       r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials, host ? sig : sig_none());
   }
   std::vector<Fq> sums(18 * ninst);
   if (!host) {
-    ProfScope ps(c, PF_REDUCE, 32.0 * 18 * (double)(nblk * ninst));
-    hipLaunchKernelGGL(k_reduce_partials18, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, (Fq*)hres(c));
-    SPCHK(fetch_small(c, sums.data(), 32 * 18 * ninst));
+    {
+      ProfScope ps(c, PF_REDUCE, 32.0 * 18 * (double)(nblk * ninst));
+      hipLaunchKernelGGL(k_reduce_partials18, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, (Fq*)hres(c), sig);
+    }
+    SPCHK(sig_wait(c, sig));
+    memcpy(sums.data(), hres(c), 32 * 18 * ninst);
   } else {
-    SPCHK(sync_spin(c));
+    SPCHK(sig_wait(c, sig));
     const Fq* p = (const Fq*)hres(c);
     for (size_t i = 0; i < ninst; i++)
       for (int k = 0; k < 18; k++) {
@@ -626,7 +644,7 @@ int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_
   }
   {
     ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * nt));
-    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, (Fq*)hres(c));
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, (Fq*)hres(c), sig_none());
   }
   SPCHK(fetch_small(c, out, 32 * nt));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;

@@ -133,6 +133,11 @@ size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
   if (out && cap >= v.size()) memcpy(out, v.data(), v.size());
   return v.size();
 }
+// few-term commitments (small_msm.cc): where they run (0 device, 1 this core, -1 SPARTAN_SMALL_MSM), and a device-free probe
+void spz_set_small_msm_mode(int mode) { small_msm_set_mode(mode); }
+int spz_small_msm_probe(const uint8_t* compressed, size_t npts, const uint64_t* scalars, size_t rows, uint8_t* out) {
+  return small_msm_probe(compressed, npts, scalars, rows, out);
+}
 // window width of the fixed-base tables of a generator stream (0: gens_r1cs_sat, 1: gens_r1cs_eval)
 int spz_snark_gens_window_bits(void* g, int which) { return sp_gens_window_bits(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
 // bincode of SNARKGens / ComputationCommitment (wire formats)
@@ -188,6 +193,42 @@ void* spz_snark_prove(void* ctx, void* inst, void* gens, void* enc, const uint64
     EncH* e = (EncH*)enc;
     SNARK p = SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(SNARKGens*)gens,
                            t, tape_seed ? &seed : nullptr, &tm);
+    fill_times(tm, times10);
+    ProofH* h = new ProofH;
+    h->bytes = p.serialize();
+    return h;
+  });
+}
+// VarsAssignment::new: the assignment uploaded once; spz_*_prove_resident prove from the device copy
+void* spz_vars_assignment_new(void* ctx, const uint64_t* vars, size_t nvars) {
+  return guard([&]() -> void* { return new VarsAssignment(*(Ctx*)ctx, (const sp::Fq*)vars, nvars); });
+}
+void spz_vars_assignment_free(void* a) { delete (VarsAssignment*)a; }
+void* spz_snark_prove_resident(void* ctx, void* inst, void* gens, void* enc, void* assignment, const uint64_t* inputs, size_t ninputs,
+                               const char* transcript_label, const uint64_t tape_seed[4], double* times10) {
+  return guard([&]() -> void* {
+    Transcript t(transcript_label);
+    Fq seed;
+    if (tape_seed) memcpy(seed.l, tape_seed, 32);
+    ProveTimes tm;
+    EncH* e = (EncH*)enc;
+    SNARK p = SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, *(VarsAssignment*)assignment, limbs_vec(inputs, ninputs), *(SNARKGens*)gens,
+                           t, tape_seed ? &seed : nullptr, &tm);
+    fill_times(tm, times10);
+    ProofH* h = new ProofH;
+    h->bytes = p.serialize();
+    return h;
+  });
+}
+void* spz_nizk_prove_resident(void* ctx, void* inst, void* gens, void* assignment, const uint64_t* inputs, size_t ninputs, const char* transcript_label,
+                              const uint64_t tape_seed[4], double* times10) {
+  return guard([&]() -> void* {
+    Transcript t(transcript_label);
+    Fq seed;
+    if (tape_seed) memcpy(seed.l, tape_seed, 32);
+    ProveTimes tm;
+    NIZK p = NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, *(VarsAssignment*)assignment, limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t,
+                         tape_seed ? &seed : nullptr, &tm);
     fill_times(tm, times10);
     ProofH* h = new ProofH;
     h->bytes = p.serialize();

@@ -5,8 +5,10 @@
 // ComputationCommitment/Decommitment, SNARK::{encode,prove}, NIZK::prove. Verifiers are out of scope
 // (SURVEY.md §2.1); tests verify the emitted bytes with the oracle's restated verifier.
 //
-// All field/group work of the prover runs on the GPU through sp_* calls; the host keeps only what the
-// reference keeps next to its Transcript: Fiat–Shamir, O(log n)-sized scalar bookkeeping, and serialization.
+// All table-sized field/group work of the prover runs on the GPU through sp_* calls; the host keeps what the
+// reference keeps next to its Transcript — Fiat–Shamir, O(log n)-sized scalar bookkeeping, serialization — and the
+// 2..5-term commitments of the Sigma protocols, whose dependent chains a host core finishes before a lone wavefront
+// would (small_msm.cc).
 #pragma once
 #include <array>
 #include <cstdint>
@@ -139,6 +141,16 @@ struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the m
   static std::unique_ptr<Instance> produce_synthetic_r1cs(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, uint64_t seed,
                                                           FqVec* vars, FqVec* inputs);
 };
+// VarsAssignment (lib.rs:56-105, Assignment::new) with the scalars resident in HBM: the reference parses the caller's bytes
+// into Scalars in the constructor, outside prove; here the constructor also uploads them, once, and every proof over the
+// assignment starts from the device copy (one 32 MB PCIe transfer less per 2^20 proof). The padding to the instance's
+// num_vars (lib.rs:360-368) stays in prove.
+struct VarsAssignment {
+  sp_ctx* c = nullptr;
+  DevTable tab;
+  size_t n = 0;
+  VarsAssignment(Ctx& ctx, const Fq* vars, size_t n);
+};
 // TEST/BENCH ONLY: from_bytes_wide(SHAKE256(domain || LE64(seed))[0..64]), the documented seed -> scalar map behind the
 // reproducible RandomTape seeds of tests/ and bench.py. 64 bits of entropy: never a production tape seed.
 Fq seed_scalar(const char* domain, uint64_t seed);
@@ -247,7 +259,13 @@ struct SNARK {  // lib.rs:311-467
   // same, reading the assignment in place (a Rust `&[Scalar]` / a caller-owned buffer): no host-side copy
   static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
                      const Fq* vars, size_t num_vars_given, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript,
-                     const Fq* tape_seed, ProveTimes* times = nullptr);
+                     const Fq* tape_seed, ProveTimes* times = nullptr, const sp_table* vars_resident = nullptr);
+  // same, from an assignment already in HBM
+  static SNARK prove(Ctx& ctx, const Instance& inst, const ComputationCommitment& comm, const ComputationDecommitment& decomm,
+                     const VarsAssignment& vars, const FqVec& inputs, const SNARKGens& gens, Transcript& transcript, const Fq* tape_seed,
+                     ProveTimes* times = nullptr) {
+    return prove(ctx, inst, comm, decomm, nullptr, vars.n, inputs, gens, transcript, tape_seed, times, vars.tab.h);
+  }
   std::vector<uint8_t> serialize() const;  // bincode 1.3 default encoding
 };
 struct NIZK {  // lib.rs:488-587
@@ -258,10 +276,24 @@ struct NIZK {  // lib.rs:488-587
     return prove(ctx, inst, vars.data(), vars.size(), inputs, gens, transcript, tape_seed, times);
   }
   static NIZK prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t num_vars_given, const FqVec& inputs, const NIZKGens& gens,
-                    Transcript& transcript, const Fq* tape_seed, ProveTimes* times = nullptr);
+                    Transcript& transcript, const Fq* tape_seed, ProveTimes* times = nullptr, const sp_table* vars_resident = nullptr);
+  static NIZK prove(Ctx& ctx, const Instance& inst, const VarsAssignment& vars, const FqVec& inputs, const NIZKGens& gens, Transcript& transcript,
+                    const Fq* tape_seed, ProveTimes* times = nullptr) {
+    return prove(ctx, inst, nullptr, vars.n, inputs, gens, transcript, tape_seed, times, vars.tab.h);
+  }
   std::vector<uint8_t> serialize() const;
 };
 
 std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p);
+
+// small_msm.cc: the few-term commitments of the Sigma protocols on the proving thread's core (SPARTAN_SMALL_MSM=device sends
+// them to the GPU instead; byte-identical proofs)
+void small_msm_register(const sp_gens* g, const std::vector<uint8_t>& compressed);
+void small_msm_forget(const sp_gens* g);
+bool small_msm_has(const sp_gens* g);
+bool small_msm_on_host();
+void small_msm_set_mode(int mode);  // 0 device, 1 host, -1 environment (tests)
+bool small_msm_rows(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, size_t rows, uint8_t* out);
+int small_msm_probe(const uint8_t* compressed, size_t npts, const uint64_t* scalars, size_t rows, uint8_t* out);
 
 }  // namespace spz

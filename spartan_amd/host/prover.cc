@@ -115,9 +115,15 @@ DevIndex& DevIndex::operator=(DevIndex&& o) noexcept {
   if (this != &o) { sp_index_free(h); c = o.c; h = o.h; o.h = nullptr; }
   return *this;
 }
-GensStream::~GensStream() { sp_gens_free(g); }
+GensStream::~GensStream() {
+  if (g) small_msm_forget(g);
+  sp_gens_free(g);
+}
 GensStream& GensStream::operator=(GensStream&& o) noexcept {
-  if (this != &o) { sp_gens_free(g); c = o.c; g = o.g; compressed = std::move(o.compressed); o.g = nullptr; }
+  if (this != &o) {
+    if (g) small_msm_forget(g);
+    sp_gens_free(g); c = o.c; g = o.g; compressed = std::move(o.compressed); o.g = nullptr;
+  }
   return *this;
 }
 
@@ -139,6 +145,7 @@ GensStream::GensStream(sp_ctx* c_, const char* label, size_t npoints) : c(c_) {
   shake.squeeze(uniform.data(), uniform.size());
   compressed.resize(32 * npoints);
   SPX(sp_gens_from_uniform(c, uniform.data(), npoints, compressed.data(), &g));  // from_uniform_bytes on the device (:21-30)
+  small_msm_register(g, compressed);
 }
 MultiCommitGens GensStream::multi_commit_gens(size_t n) const {
   REQUIRE(n + 1 <= sp_gens_len(g));
@@ -304,7 +311,9 @@ static CP to_cp(const uint8_t* p) { CP c; memcpy(c.data(), p, 32); return c; }
 static std::vector<CP> msm_rows(sp_ctx* c, const sp_gens* g, const std::vector<uint32_t>& idx, const FqVec& scalars, size_t rows) {
   REQUIRE(scalars.size() == rows * idx.size());
   std::vector<uint8_t> out(32 * rows);
-  SPX(sp_msm_indexed(c, g, idx.data(), idx.size(), U(scalars), rows, out.data()));
+  // few-term commitments: on this core unless told otherwise (small_msm.cc)
+  if (!(idx.size() <= 8 && small_msm_on_host() && small_msm_rows(g, idx.data(), idx.size(), scalars.data(), rows, out.data())))
+    SPX(sp_msm_indexed(c, g, idx.data(), idx.size(), U(scalars), rows, out.data()));
   std::vector<CP> r(rows);
   for (size_t i = 0; i < rows; i++) r[i] = to_cp(&out[32 * i]);
   return r;
@@ -501,7 +510,12 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     for (size_t k = 0; k < nn; k++) rows1[W + k] = d[k];
     rows1[W + nn] = r_delta;
     std::vector<CP> cm1;
-    if (sp_table_len(tabs[0]) >= 4) {
+    bool pending = false;  // the bind and the next evaluation are in flight on the device while this core commits
+    if (sp_table_len(tabs[0]) >= 4 && small_msm_on_host() && small_msm_has(gn.g)) {
+      SPX(sp_sumcheck_bind_eval_start(c, kind, tabs.data(), tabs.size(), U(r_j)));
+      pending = true;
+      try { cm1 = msm_rows(c, gn.g, idx_u, rows1, 2); } catch (...) { (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+    } else if (sp_table_len(tabs[0]) >= 4) {
       uint8_t pts[64];
       SPX(sp_sumcheck_bind_eval_commit(c, kind, tabs.data(), tabs.size(), U(r_j), ev, gn.g, idx_u.data(), W, U(rows1), 2, pts));
       cm1 = {to_cp(pts), to_cp(pts + 32)};
@@ -530,15 +544,30 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     // launch 2: Cy = target*G1 + blind*h ; beta = dp*G1 + r_beta*h ; and the next round's comm_poly (its inputs,
     // the next evaluations and claim = eval, are already known)
     UniPoly next_poly;
-    size_t nrows2 = more ? 3 : 2;
-    FqVec rows2(nrows2 * W, fq_zero());
-    rows2[nn + 1] = target; rows2[nn + 2] = blind;
-    rows2[W + nn + 1] = dp; rows2[W + nn + 2] = r_beta;
-    if (more) {
-      next_poly = make_poly(ev, eval);
-      poly_row(rows2, 2, next_poly, blinds_poly[j + 1]);
+    std::vector<CP> cm2;
+    if (pending) {
+      FqVec rows2(2 * W, fq_zero());
+      rows2[nn + 1] = target; rows2[nn + 2] = blind;
+      rows2[W + nn + 1] = dp; rows2[W + nn + 2] = r_beta;
+      try { cm2 = msm_rows(c, gn.g, idx_u, rows2, 2); } catch (...) { (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+      SPX(sp_sumcheck_bind_eval_collect(c, ev));
+      if (more) {
+        next_poly = make_poly(ev, eval);
+        FqVec row3(W, fq_zero());
+        poly_row(row3, 0, next_poly, blinds_poly[j + 1]);
+        cm2.push_back(msm_rows(c, gn.g, idx_u, row3, 1)[0]);
+      }
+    } else {
+      size_t nrows2 = more ? 3 : 2;
+      FqVec rows2(nrows2 * W, fq_zero());
+      rows2[nn + 1] = target; rows2[nn + 2] = blind;
+      rows2[W + nn + 1] = dp; rows2[W + nn + 2] = r_beta;
+      if (more) {
+        next_poly = make_poly(ev, eval);
+        poly_row(rows2, 2, next_poly, blinds_poly[j + 1]);
+      }
+      cm2 = msm_rows(c, gn.g, idx_u, rows2, nrows2);
     }
-    std::vector<CP> cm2 = msm_rows(c, gn.g, idx_u, rows2, nrows2);
     t.append_point("Cy", cm2[0].data());
     t.append_scalars("a", a);
     t.append_point("delta", delta.data());
@@ -651,11 +680,13 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
 }
 
 // ------------------------------------------------------------------ R1CSProof::prove (r1csproof.rs:144-349)
-// on_rx: called as soon as the first sum-check has fixed rx (SNARK::prove starts work that only depends on rx there)
+// on_rx / on_ry: called as soon as the first / second sum-check has fixed rx / ry (SNARK::prove starts work that only depends
+// on them there)
 static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& input, const R1CSGens& gens,
                             Transcript& t, RandomTape& tape, FqVec* rx_out, FqVec* ry_out, ProveTimes* tm,
                             const std::function<void(const FqVec&)>* on_rx = nullptr,
-                            const std::function<void()>* transcript_prefix = nullptr) { HSPAN("r1cs_prove");
+                            const std::function<void()>* transcript_prefix = nullptr,
+                            const std::function<void(const FqVec&)>* on_ry = nullptr, const sp_table* vars_resident = nullptr) { HSPAN("r1cs_prove");
   double t0 = now_s();
   // lib.rs:360-368 / 519-526: the assignment is zero-padded to the instance's (padded) num_vars — done in the device table
   REQUIRE(nvars_given <= inst.num_vars && input.size() < inst.num_vars && input.size() == inst.num_inputs);
@@ -665,7 +696,12 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   // the transcript has to absorb BEFORE it (the caller's prefix — for a SNARK the 6144 shares of the computation
   // commitment — and the inputs) is hashed while the GPU computes; the order of the transcript operations is the reference's.
   DevTable poly_vars = tab_alloc(c, num_vars);  // zero-filled: implicit padding
-  if (nvars_given) SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
+  if (vars_resident) {  // a VarsAssignment: device-to-device
+    REQUIRE(sp_table_len(vars_resident) == nvars_given);
+    if (nvars_given) SPX(sp_table_copy(c, poly_vars.h, 0, vars_resident, 0, nvars_given));
+  } else if (nvars_given) {
+    SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
+  }
   FqVec blinds_vars = tape.random_vector("poly_blinds", pow2(lv / 2));
   {
     size_t Ls = pow2(lv / 2), Rs = pow2(lv - lv / 2);
@@ -755,6 +791,7 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   P.sc_proof_phase2 = zk_sumcheck_prove(c, 0, claim_phase2, blind_claim_phase2, num_rounds_y, {z.h, poly_ABC.h}, gens.gens_sc.gens_1,
                                         gens.gens_sc.gens_3, t, tape, &ry, &claims2, &blind_claim_postsc2);
   if (tm) tm->sc_phase_two = now_s() - t2;
+  if (on_ry) (*on_ry)(ry);
 
   double t3 = now_s();
   FqVec ry1(ry.begin() + 1, ry.end());
@@ -775,8 +812,14 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   return P;
 }
 
+VarsAssignment::VarsAssignment(Ctx& ctx, const Fq* vars, size_t n_) : c(ctx.h), n(n_) {
+  REQUIRE(vars && n_ > 0);
+  sp_table* t = nullptr;
+  SPX(sp_table_upload(c, vars[0].l, n_, &t));
+  tab = DevTable(c, t);
+}
 NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& inputs, const NIZKGens& gens, Transcript& t,
-                 const Fq* tape_seed, ProveTimes* tm) {  // lib.rs:501-546
+                 const Fq* tape_seed, ProveTimes* tm, const sp_table* vars_resident) {  // lib.rs:501-546
   double t0 = now_s();
   REQUIRE(!inst.digest.empty());  // lib.rs:514 absorbs inst.digest: an empty one would leave the proof unbound to the shape
   RandomTape tape = tape_seed ? RandomTape("proof", *tape_seed) : RandomTape("proof");  // random.rs:11-18
@@ -785,7 +828,7 @@ NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_gi
     t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());
   };
   NIZK P;
-  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, vars, nvars_given, inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm, nullptr, &prefix);
+  P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, vars, nvars_given, inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm, nullptr, &prefix, nullptr, vars_resident);
   if (tm) tm->total = now_s() - t0;
   return P;
 }

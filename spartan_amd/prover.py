@@ -10,12 +10,12 @@ if not os.path.exists(HOST_PATH):
 ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 H = ctypes.CDLL(HOST_PATH)
 for f in ("spz_ctx_new", "spz_instance_new", "spz_instance_synthetic", "spz_snark_gens_new", "spz_nizk_gens_new", "spz_snark_encode",
-          "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw"):
+          "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw", "spz_vars_assignment_new", "spz_snark_prove_resident", "spz_nizk_prove_resident"):
     getattr(H, f).restype = vp
 for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script", "spz_snark_gens_bincode", "spz_commitment_bincode", "spz_decommitment_bincode"):
     getattr(H, f).restype = sz
 H.spz_last_error.restype = ctypes.c_char_p
-for f in ("spz_ctx_free", "spz_instance_free", "spz_snark_gens_free", "spz_nizk_gens_free", "spz_encode_free", "spz_proof_free"):
+for f in ("spz_ctx_free", "spz_instance_free", "spz_snark_gens_free", "spz_nizk_gens_free", "spz_encode_free", "spz_proof_free", "spz_vars_assignment_free"):
     getattr(H, f).argtypes = [vp]
 u64p = ctypes.POINTER(ctypes.c_uint64)
 TIME_NAMES = ["polycommit", "prove_sc_phase_one", "prove_sc_phase_two", "polyeval", "R1CSProof::prove", "eval_sparse_polys",
@@ -157,9 +157,14 @@ class SNARK:
 
     @staticmethod
     def prove(ctx, inst, enc, vars_, inputs, gens, transcript_label, tape_seed, times=None):
+        """vars_: the assignment as Montgomery limbs (a ctypes uint64 array, read in place) or a VarsAssignment (already in HBM)"""
         tm = (ctypes.c_double * 10)()
-        p = _chk(H.spz_snark_prove(ctx.h, inst.h, gens.h, enc.h, vars_, sz(len(vars_) // 4), inputs, sz(inst.num_inputs), transcript_label,
-                                   tape_seed, tm), "SNARK::prove")
+        if isinstance(vars_, VarsAssignment):
+            p = _chk(H.spz_snark_prove_resident(ctx.h, inst.h, gens.h, enc.h, vars_.h, inputs, sz(inst.num_inputs), transcript_label, tape_seed, tm),
+                     "SNARK::prove")
+        else:
+            p = _chk(H.spz_snark_prove(ctx.h, inst.h, gens.h, enc.h, vars_, sz(len(vars_) // 4), inputs, sz(inst.num_inputs), transcript_label,
+                                       tape_seed, tm), "SNARK::prove")
         if times is not None:
             times.update(dict(zip(TIME_NAMES, list(tm))))
         return _proof_bytes(p)
@@ -169,11 +174,25 @@ class NIZK:
     @staticmethod
     def prove(ctx, inst, vars_, inputs, gens, transcript_label, tape_seed, times=None):
         tm = (ctypes.c_double * 10)()
-        p = _chk(H.spz_nizk_prove(ctx.h, inst.h, gens.h, vars_, sz(len(vars_) // 4), inputs, sz(inst.num_inputs), transcript_label, tape_seed, tm),
-                 "NIZK::prove")
+        if isinstance(vars_, VarsAssignment):
+            p = _chk(H.spz_nizk_prove_resident(ctx.h, inst.h, gens.h, vars_.h, inputs, sz(inst.num_inputs), transcript_label, tape_seed, tm), "NIZK::prove")
+        else:
+            p = _chk(H.spz_nizk_prove(ctx.h, inst.h, gens.h, vars_, sz(len(vars_) // 4), inputs, sz(inst.num_inputs), transcript_label, tape_seed, tm),
+                     "NIZK::prove")
         if times is not None:
             times.update(dict(zip(TIME_NAMES, list(tm))))
         return _proof_bytes(p)
+
+
+class VarsAssignment:
+    """VarsAssignment::new (lib.rs:56-105) with the scalars uploaded once: proofs over it start from the copy in HBM"""
+    def __init__(self, ctx, vars_):
+        self.n = len(vars_) // 4
+        self.h = _chk(H.spz_vars_assignment_new(ctx.h, vars_, sz(self.n)), "VarsAssignment::new")
+
+    def free(self):
+        if self.h:
+            H.spz_vars_assignment_free(self.h); self.h = None
 
 
 class Encoded:

@@ -199,7 +199,13 @@ def test_sumcheck_eval_bind_matches_oracle(ctx, orc, kind, ntabs, ell):
         for k in range(ntabs):
             orc.orc_bound_top(host[k], sz(length), r)
         length //= 2
-        if length >= 2 and (ell % 2 == 0 or length > 4):
+        if length >= 4 and ell == 13 and length % 3 == 2:
+            capi.sumcheck_bind_eval_start(ctx, kind, tabs, r)   # the same round in two halves (the ZK sum-check commits in between)
+            with pytest.raises(capi.SpartanHipError):
+                capi.sumcheck_bind_eval_start(ctx, kind, tabs, r)   # one pending round per context
+            got = capi.sumcheck_bind_eval_collect(ctx)
+            first = False
+        elif length >= 2 and (ell % 2 == 0 or length > 4):
             got = capi.sumcheck_bind_eval(ctx, kind, tabs, r)   # fused path
             first = False
         else:

@@ -127,18 +127,24 @@ def test_instance_new_matches_synthetic_and_rejects_bad_input(P, ctx, orc):
     gens.free(); inst.free(); ref.free(); orc.orc_instance_free(oi)
 
 
-@pytest.mark.parametrize("s", [16, 20, 22])
+@pytest.mark.parametrize("s", [16, 20, 22, 24])
 def test_snark_full_size_properties(P, ctx, orc, s):
-    """BASELINE sizes (configs[1] 2^16, configs[2] 2^20, configs[4] 2^22), where the oracle prover is too slow to run in a test:
-    size-independent properties — README proof lengths, determinism, and the oracle's restated VERIFIER accepts the
-    GPU proof bytes against the GPU computation commitment (and rejects a corrupted proof)."""
+    """BASELINE sizes (configs[1] 2^16, configs[2] 2^20, configs[4] 2^22) and 2^24 — the largest instance whose generator
+    tables fit one GPU's HBM (15-bit windows for the 4097-point stream, 12-bit for the 16386-point one: 181 GB; 236 GB in use at
+    the peak of the proof) — where the oracle prover is too slow to run in a test: size-independent properties — README proof
+    lengths, determinism, and the oracle's restated VERIFIER accepts the GPU proof bytes against the GPU computation commitment
+    (and rejects a corrupted proof)."""
     N = 1 << s
     inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
     gens = P.SNARKGens(ctx, N, N, 10, N)
+    if s == 24:
+        assert (gens.window_bits(0), gens.window_bits(1)) == (15, 12)
     enc = P.SNARK.encode(ctx, inst, gens)
     tape = P.seed_scalar(b"tape", s)
     proof = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
-    assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == proof
+    va = P.VarsAssignment(ctx, inst.vars)   # the same proof from an assignment already in HBM
+    assert P.SNARK.prove(ctx, inst, enc, va, inst.inputs, gens, b"snark_example", tape) == proof
+    va.free()
     from tests.test_oracle_pins import sat_proof_len
     if s == 20:
         assert sat_proof_len(20) == 47024 and len(proof) == 47024 + 96 + 133720  # README.md:362,374 + 3 inst_evals
@@ -361,3 +367,36 @@ def test_host_and_device_point_encoding_give_the_same_proof(P, orc, monkeypatch)
     oe = vp(orc.orc_snark_encode(oi, og))
     op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", P.seed_scalar(b"tape", seed), None))
     assert proofs[0] == proofs[1] == oracle_bytes(orc, op)
+
+
+def test_small_commitments_on_host_core_or_device_and_resident_assignment_give_the_same_proof(P, ctx, orc):
+    """The 2..5-term commitments of the Sigma protocols run on the proving thread's core by default (small_msm.cc) and on
+    the GPU with SPARTAN_SMALL_MSM=device; the assignment may be a host buffer or a VarsAssignment already in HBM. Four
+    combinations, one proof — the oracle's — for SNARK and NIZK."""
+    s, seed = 10, 33
+    N = 1 << s
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=seed)
+    inst.set_digest(b"digest-10")
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    ngens = P.NIZKGens(ctx, N, N, 10)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    va = P.VarsAssignment(ctx, inst.vars)
+    tape = P.seed_scalar(b"tape", seed)
+    snark, nizk = [], []
+    try:
+        for mode in (1, 0):
+            P.H.spz_set_small_msm_mode(ctypes.c_int(mode))
+            for v in (inst.vars, va):
+                snark.append(P.SNARK.prove(ctx, inst, enc, v, inst.inputs, gens, b"snark_example", tape))
+                nizk.append(P.NIZK.prove(ctx, inst, v, inst.inputs, ngens, b"nizk_example", tape))
+    finally:
+        P.H.spz_set_small_msm_mode(ctypes.c_int(-1))
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
+    assert all(p == oracle_bytes(orc, op) for p in snark)
+    ong = vp(orc.orc_nizk_gens_new(sz(N), sz(N), sz(10)))
+    onp = vp(orc.orc_nizk_prove(oi, ong, b"digest-10", sz(9), b"nizk_example", tape, None))
+    assert all(p == oracle_bytes(orc, onp) for p in nizk)
+    va.free(); ngens.free(); enc.free(); gens.free(); inst.free()
