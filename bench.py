@@ -387,13 +387,20 @@ def main():
             madds = nm[1] * nwin
             e = {"shape": f'{sh["rows"]} x {sh["cols"]}', "what": nm[0], "launch_ms": round(lms, 4), "window_bits": wb_eval if nm[2] else wb_sat, "mixed_additions": madds,
                  "achieved_G_per_s": round(madds / lms / 1e6, 2)}
+            if sh["background"]:   # k_msm_rows_bg holds SPARTAN_BG_EIGHTHS/8 of the CUs (one persistent 1024-thread workgroup each)
+                e["cu_share"] = int(os.environ.get("SPARTAN_BG_EIGHTHS", "4")) / 8
             if ceil:
                 e["frac"] = round(madds / lms / 1e6 / ceil["pt_madd_G_per_s"], 3)
+                if sh["background"] and e["cu_share"] > 0:
+                    e["frac_of_its_cus"] = round(e["frac"] / e["cu_share"], 3)
             alu_shapes.append(e)
         roofline["alu"] = {"unit": "G mixed additions/s (7 F_p multiplications + 8 additions each)", "ceiling": ceil["pt_madd_G_per_s"] if ceil else None,
                            "ceiling_source": "bench/ubench_fpmul --json on this GPU, this run: dependent pt_madd chains at full occupancy" if ceil else "bench/ubench_fpmul not built",
                            "additions_per_scalar": {"gens_r1cs_sat": nwin_of[False], "gens_r1cs_eval": nwin_of[True]}, "shapes": alu_shapes,
-                           "frac": max([e.get("frac", 0) for e in alu_shapes if "background" not in e["what"]] or [None])}
+                           "frac": max([e.get("frac", 0) for e in alu_shapes if "background" not in e["what"]] or [None]),
+                           # family-wide: every mixed addition of the step over the CU-time it was given
+                           "frac_family": (round(sum(e["mixed_additions"] for e in alu_shapes) / sum(e["launch_ms"] * e.get("cu_share", 1.0) for e in alu_shapes) / 1e6 / ceil["pt_madd_G_per_s"], 3)
+                                           if ceil and alu_shapes else None)}
         # F_q streaming kernels (the HBM-shaped part): multiplications/s against the fq_mul chain ceiling, bytes/s against HBM
         fq = {}
         for name in ("sumcheck_eval", "sumcheck_bind_eval", "vecmat", "dot"):

@@ -3,12 +3,17 @@
 /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B
 requests at 64 B, i.e. reports half the bytes of a wide (16 B/lane) coalesced stream -> doubled. All kernels here load
 16 B per lane (ulonglong2). WRITE_SIZE is uncalibrated on gfx950 (reported as is).
-usage: python profiles/pmc_summarize.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv"""
-import csv, json, sys, collections
+usage: python profiles/pmc_summarize.py <FETCH_SIZE pass>.csv <WRITE_SIZE pass>.csv [name of the committed text summary]
+Writes profiles/pmc_traffic.json with the digest of the kernel sources it was collected with (bench.kernel_source_digest):
+bench.py reports `roofline.traffic` only when that digest matches the sources it is running."""
+import csv, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed",
           "k_msm_reduce": "msm_reduce_compress", "k_pt_encode": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
           "k_cubic_bind_eval_batched": "sumcheck_bind_eval", "k_sc_bind_eval": "sumcheck_bind_eval", "k_sc_eval": "sumcheck_eval",
-          "k_cubic_eval_batched": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand"}
+          "k_cubic_eval_batched": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand",
+          "k_cubic_bind2_eval": "sumcheck_bind_eval", "k_cubic_bind_eval_tiny": "sumcheck_bind_eval", "k_sc_bind_eval_tiny": "sumcheck_bind_eval",
+          "k_cubic_eval_tiny": "sumcheck_eval", "k_vecmat": "vecmat", "k_dot_many": "dot", "k_dot3": "dot", "k_dot": "dot"}
 def load(path, counter):
     tot = collections.defaultdict(float); n = collections.Counter()
     for row in csv.DictReader(open(path)):
@@ -26,5 +31,12 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
         fam_bytes[FAMILY[k]] += 2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024
         fam_n[FAMILY[k]] += nf[k]
 out = {fam: fam_bytes[fam] / max(fam_n[fam], 1) for fam in fam_bytes}
+# msm_rows_fixed per launch SHAPE is what the bench line's dominant-kernel entry averages over: keep the two kernels apart too
+for k in ("k_msm_rows", "k_msm_rows_bg"):
+    if k in f:
+        out[k] = (2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024) / nf[k]
+from bench import kernel_source_digest
+out["kernel_source_digest"] = kernel_source_digest()
+out["source"] = sys.argv[3] if len(sys.argv) > 3 else "pmc_traffic.json"
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print("\nper-family HBM bytes per launch (profiles/pmc_traffic.json):", json.dumps(out))
