@@ -92,15 +92,24 @@ impl SumcheckInstanceProof {
   }
 }
 
+// The C++ driver additionally advances TWO rounds per call while the tables are short (<= 512 entries, the latency-bound
+// tail: ~290 of the 361 rounds of a 2^20 proof): sp_sumcheck_eval_coeffs_batched / sp_sumcheck_bind2_eval_batched return,
+// next to the evaluations of a round, the coefficients (M0, M3, T1, T2 at t = 0, 2, 3) of the cubic in the NEXT challenge
+// that the following round's evaluations are; the caller derives r_j, evaluates that cubic on the host, derives r_{j+1},
+// and only then goes back to the device with both challenges (spartan_amd/host/spark.inc: prove_cubic_batched, evals_from_coeffs).
+// Same field values, same transcript operations, half the round trips. The one-round form above is the same proof.
+
 // ZKSumcheckInstanceProof::prove_quad (:428-586) and ::prove_cubic_with_additive_term (:588-776): the round body becomes
-//   round 0:  sp_sumcheck_eval(kind, tabs) -> evals -> UniPoly -> comm_poly via sp_msm_indexed (gens_n ++ [h])
-//   round j:  sp_sumcheck_bind_eval_commit(kind, tabs, r_j, evals_next, gens, idx, cols, S, rows = 2, out_points)
-//             = bound_poly_var_top on every table (:485-486 / :673-676) fused with the next round's evaluations
-//               (:460-469 / :624-652), plus comm_eval and the DotProductProof's delta of THIS round on a second stream
-//               (their scalars are known as soon as r_j is); then sp_msm_indexed for (Cy, beta, next comm_poly).
+//   round 0:  sp_sumcheck_eval(kind, tabs) -> evals -> UniPoly -> comm_poly  (reference code: poly.commit(...))
+//   round j:  sp_sumcheck_bind_eval_start(kind, tabs, r_j)        // bound_poly_var_top on every table (:485-486 / :673-676)
+//                                                                 // fused with the next round's evaluations (:460-469 / :624-652)
+//             ... the round's Sigma-protocol commitments, UNCHANGED reference code on the CPU (comm_eval, DotProductProof::prove's
+//                 delta, Cy, beta: 2..5-term commitments under gens_1 / gens_n — dalek's multiscalar_mul on a handful of points) ...
+//             sp_sumcheck_bind_eval_collect(evals_next)           // the device finished long ago
+//             comm_poly of round j+1 from evals_next              // reference code
 // kind 0 = A*B (prove_quad), kind 2 = A*(B*C - D) (prove_cubic_with_additive_term); tabs in that order.
-// Every commitment is a row of scalars over the generator index list (gens_n.G ..., gens_n.h, gens_1.G[0], gens_1.h) of
-// ONE device generator stream: `delta = b3*X + b5*h` style commitments over derived bases (nizk/mod.rs:197-205) are
-// rewritten over the original generators ((b3*x)*G + (b3*rX + b5)*h), and `gens_1.scale(r)` (nizk/mod.rs:479-480) becomes a
-// scalar factor r on that column — same group elements, hence the same 32 compressed bytes.
-// The complete C++ rendering of both provers, line-by-line against sumcheck.rs, is spartan_amd/host/prover.cc:469-587.
+// Why the few-term commitments stay on the CPU: each is a chain of ~100 dependent point additions plus one inverse square
+// root that the transcript waits for; a host core finishes it in ~15 us, a lone wavefront in ~60 us plus the round trip
+// (measured: DESIGN.md section 4). The C++ driver does exactly this with its own window tables for those generators
+// (spartan_amd/host/small_msm.cc); sp_sumcheck_bind_eval_commit / sp_msm_indexed keep the all-device variant available.
+// The complete C++ rendering of both provers, line-by-line against sumcheck.rs, is spartan_amd/host/prover.cc (zk_sumcheck_prove).

@@ -24,7 +24,13 @@ SP_HD Fp fp_INVSQRT_A_MINUS_D() { return Fp{{0x99c8fdaa805d40eaULL, 0x9d2f16175a
 struct Pt {  // extended coordinates: x = X/Z, y = Y/Z, T = XY/Z
   Fp X, Y, Z, T;
 };
-struct Niels {  // affine point prepared for mixed addition (96 B; padding entries to a 128-byte line was measured: no gain)
+#ifndef SP_NIELS_ALIGN
+#define SP_NIELS_ALIGN 32
+#endif
+// affine point prepared for mixed addition: 96 B. SP_NIELS_ALIGN=128 pads an entry to one 128-byte line — measured at 2^20 with 15-bit
+// windows: the 4098-point stream's launches 3.05 -> 3.45 ms and 5.48 -> 6.10 ms (tables 110 -> 146 GB), the 1025-point stream's unchanged:
+// the gathers pay for the size of the table set (address translation, DRAM pages), not for the sectors an entry straddles
+struct alignas(SP_NIELS_ALIGN) Niels {
   Fp yp, ym, t2d;  // y+x, y-x, 2*d*x*y
 };
 
