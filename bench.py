@@ -437,7 +437,7 @@ def main():
                        "inputs": "instance, generators, computation commitment and the satisfying assignment resident in HBM (VarsAssignment); inputs io on the host",
                        "pcie_inclusive": {"ms_per_step": round(dt_host * 1e3, 3), "value": N * world / dt_host if not sharded else N / dt_host, "steps": k_host,
                                           "note": "same proof, assignment passed as a host buffer (uploaded inside SNARK::prove)"},
-                       "host_cores_busy": world, "host_note": "each proving thread spins on its completion flag and runs Merlin, the 2..5-term Sigma-protocol commitments and ~150 point encodes: one host core per GPU, flat out"},
+                       "host_cores_busy": world, "host_note": "each proving thread spins on its completion flag and runs Merlin, the 2..5-term Sigma-protocol commitments and ~150 point encodes: one host core per GPU, flat out; a helper thread computes the tape-only halves of the ZK sum-checks' commitments ahead of the rounds (~0.5 ms of a second core per proof)"},
             "roofline": roofline,
             "kernel_ms_per_step": {n: round(v["ms"], 4) for n, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])},
             "gpu_busy_ms_per_step": round(gpu_ms_total, 3),

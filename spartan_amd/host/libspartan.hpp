@@ -294,6 +294,11 @@ bool small_msm_has(const sp_gens* g);
 bool small_msm_on_host();
 void small_msm_set_mode(int mode);  // 0 device, 1 host, -1 environment (tests)
 bool small_msm_rows(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, size_t rows, uint8_t* out);
+struct HostPt { uint64_t w[16]; };  // an extended point (csrc/curve.hpp: Pt), opaque to the driver
+// one row, left as a point: the tape-only half of a commitment, computed ahead of time (ZkAhead in prover.cc)
+bool small_msm_point(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, HostPt* out);
+// row r = sum_k scalars[r][k] * P[idx[k]] + *addend[r] (a null addend adds nothing), encoded
+bool small_msm_rows_plus(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, size_t rows, const HostPt* const* addend, uint8_t* out);
 int small_msm_probe(const uint8_t* compressed, size_t npts, const uint64_t* scalars, size_t rows, uint8_t* out);
 
 }  // namespace spz

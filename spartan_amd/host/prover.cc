@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 
 namespace spz {
 using namespace sp;
@@ -453,6 +455,28 @@ static ProductProof product_prove(sp_ctx* c, const MultiCommitGens& g, Transcrip
   return p;
 }
 
+// The tape-only halves of a ZK sum-check's commitments, computed ahead of the rounds by a helper thread while the proving
+// thread is in its first evaluation: the DotProductProof's delta = commit(d_j, r_delta_j) is complete (nothing but the tape
+// enters it), and of comm_eval, beta and comm_poly the blind terms blinds_evals[j]*h, r_beta_j*h, blinds_poly[j]*h_n are.
+// The tape is read in the reference's order: inside the round loop nothing but DotProductProof::prove draws from it
+// (d_vec, r_delta, r_beta: nizk/mod.rs:330-334), so drawing the rounds' values one after the other up front is the same stream.
+struct ZkAhead {
+  std::vector<FqVec> d;
+  FqVec r_delta, r_beta;
+  std::vector<CP> delta;
+  std::vector<HostPt> be_h, rb_h, bp_hn;
+  std::atomic<size_t> done{0};
+  std::atomic<bool> failed{false};
+  std::thread th;
+  ~ZkAhead() { if (th.joinable()) th.join(); }
+  void wait(size_t j) const {
+    while (done.load(std::memory_order_acquire) <= j) {
+      if (failed.load(std::memory_order_acquire)) throw Error("zk_sumcheck: look-ahead commitment failed");
+      __builtin_ia32_pause();
+    }
+  }
+};
+
 // ------------------------------------------------------------------ sumcheck.rs: the two ZK provers share everything but `kind`
 // kind 2: prove_cubic_with_additive_term (:588-776), tables (A,B,C,D), comb A*(B*C-D), gens_n = gens_4
 // kind 0: prove_quad (:428-586), tables (A,B), comb A*B, gens_n = gens_3
@@ -464,21 +488,62 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
   Fq claim_per_round = claim;
   ZKSumcheckInstanceProof out;
   FqVec r;
-  // One generator index list serves every commitment of a round: (gn.G..., gn.h, g1.G, g1.h). Commitments that
-  // do not depend on each other are computed as rows of one launch; each round needs two launches.
+  // One generator index list serves every commitment of a round: (gn.G..., gn.h, g1.G, g1.h).
   std::vector<uint32_t> idx_u = gn.G;
   idx_u.push_back(gn.h);
   idx_u.push_back(g1.G[0]);
   idx_u.push_back(g1.h);
   size_t nn = gn.n(), W = idx_u.size();
+  // The round's 2..5-term commitments: on this core (small_msm.cc) while the device binds and evaluates, or — with
+  // SPARTAN_SMALL_MSM=device — two launches per round on the device
+  const bool on_host = small_msm_on_host() && small_msm_has(gn.g) && gn.g == g1.g;
+  ZkAhead ahead;
+  if (on_host) {
+    ahead.d.resize(num_rounds); ahead.r_delta.resize(num_rounds); ahead.r_beta.resize(num_rounds);
+    for (size_t j = 0; j < num_rounds; j++) {
+      ahead.d[j] = tape.random_vector("d_vec", nn);  // DotProductProof randomness (nizk/mod.rs:330-332), rounds in order
+      ahead.r_delta[j] = tape.random_scalar("r_delta");
+      ahead.r_beta[j] = tape.random_scalar("r_beta");
+    }
+    ahead.delta.resize(num_rounds); ahead.be_h.resize(num_rounds); ahead.rb_h.resize(num_rounds); ahead.bp_hn.resize(num_rounds);
+    ahead.th = std::thread([&ahead, &blinds_poly, &blinds_evals, &idx_u, &gn, &g1, nn, W, num_rounds]() {
+      try {
+        const uint32_t ih1 = g1.h, ihn = gn.h;
+        for (size_t j = 0; j < num_rounds; j++) {
+          bool ok = small_msm_point(gn.g, &ihn, 1, &blinds_poly[j], &ahead.bp_hn[j]) && small_msm_point(gn.g, &ih1, 1, &blinds_evals[j], &ahead.be_h[j]);
+          FqVec row(W, fq_zero());
+          for (size_t k = 0; k < nn; k++) row[k] = ahead.d[j][k];
+          row[nn] = ahead.r_delta[j];
+          ok = ok && small_msm_rows(gn.g, idx_u.data(), W, row.data(), 1, ahead.delta[j].data());
+          ok = ok && small_msm_point(gn.g, &ih1, 1, &ahead.r_beta[j], &ahead.rb_h[j]);
+          if (!ok) { ahead.failed.store(true, std::memory_order_release); return; }
+          ahead.done.store(j + 1, std::memory_order_release);
+        }
+      } catch (...) {
+        ahead.failed.store(true, std::memory_order_release);
+      }
+    });
+  }
+  // rows of scalars over idx_u -> encoded commitments; addend[r] (host mode): a point computed ahead
+  auto commit_rows = [&](const FqVec& rows, size_t nrows, const HostPt* const* addend) {
+    std::vector<CP> cm(nrows);
+    if (on_host) {
+      std::vector<uint8_t> o(32 * nrows);
+      REQUIRE(small_msm_rows_plus(gn.g, idx_u.data(), W, rows.data(), nrows, addend, o.data()));
+      for (size_t k = 0; k < nrows; k++) cm[k] = to_cp(&o[32 * k]);
+      return cm;
+    }
+    return msm_rows(c, gn.g, idx_u, rows, nrows);
+  };
   auto make_poly = [&](const uint64_t* ev, const Fq& cl) {
     Fq e0, e2, e3;
     memcpy(e0.l, ev, 32); memcpy(e2.l, ev + 4, 32); memcpy(e3.l, ev + 8, 32);
     return kind == 0 ? UniPoly::from_evals({e0, cl - e0, e2}) : UniPoly::from_evals({e0, cl - e0, e2, e3});
   };
-  auto poly_row = [&](FqVec& rows, size_t row, const UniPoly& poly, const Fq& blind) {
+  // comm_poly = commit(poly.coeffs, blinds_poly[j]) under gens_n; in host mode the blind term comes from `ahead`
+  auto poly_row = [&](FqVec& rows, size_t row, const UniPoly& poly, size_t j) {
     for (size_t k = 0; k < nn; k++) rows[row * W + k] = poly.coeffs[k];
-    rows[row * W + nn] = blind;
+    rows[row * W + nn] = on_host ? fq_zero() : blinds_poly[j];
   };
   uint64_t ev[12];
   SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev));
@@ -488,8 +553,10 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
   {  // comm_claim_per_round (sumcheck.rs:448 / 611) and the first comm_poly (:473 / 661)
     FqVec rows0(2 * W, fq_zero());
     rows0[nn + 1] = claim_per_round; rows0[nn + 2] = blind_claim;
-    poly_row(rows0, 1, poly, blinds_poly[0]);
-    std::vector<CP> cm = msm_rows(c, gn.g, idx_u, rows0, 2);
+    poly_row(rows0, 1, poly, 0);
+    if (on_host) ahead.wait(0);
+    const HostPt* add0[2] = {nullptr, on_host ? &ahead.bp_hn[0] : nullptr};
+    std::vector<CP> cm = commit_rows(rows0, 2, add0);
     comm_claim_per_round = cm[0];
     comm_poly = cm[1];
   }
@@ -501,29 +568,47 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     bool more = j + 1 < num_rounds;
     // ---- round tail (sumcheck.rs:491-583 / 681-772)
     Fq eval = poly.evaluate(r_j);
-    FqVec d = tape.random_vector("d_vec", nn);  // DotProductProof randomness (nizk/mod.rs:330-332)
-    Fq r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_beta");
-    // launch 1: comm_eval = eval*G1 + blinds_evals[j]*h ; delta = <d, Gn> + r_delta*hn. Its scalars are known as soon as
-    // r_j is, like the bind: both go out together (sp_sumcheck_bind_eval_commit), one completion wait for the pair
-    FqVec rows1(2 * W, fq_zero());
-    rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
-    for (size_t k = 0; k < nn; k++) rows1[W + k] = d[k];
-    rows1[W + nn] = r_delta;
-    std::vector<CP> cm1;
-    bool pending = false;  // the bind and the next evaluation are in flight on the device while this core commits
-    if (sp_table_len(tabs[0]) >= 4 && small_msm_on_host() && small_msm_has(gn.g)) {
-      SPX(sp_sumcheck_bind_eval_start(c, kind, tabs.data(), tabs.size(), U(r_j)));
-      pending = true;
-      try { cm1 = msm_rows(c, gn.g, idx_u, rows1, 2); } catch (...) { (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
-    } else if (sp_table_len(tabs[0]) >= 4) {
-      uint8_t pts[64];
-      SPX(sp_sumcheck_bind_eval_commit(c, kind, tabs.data(), tabs.size(), U(r_j), ev, gn.g, idx_u.data(), W, U(rows1), 2, pts));
-      cm1 = {to_cp(pts), to_cp(pts + 32)};
-    } else {
-      SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
-      cm1 = msm_rows(c, gn.g, idx_u, rows1, 2);
+    FqVec d;
+    Fq r_delta, r_beta;
+    if (on_host) { d = ahead.d[j]; r_delta = ahead.r_delta[j]; r_beta = ahead.r_beta[j]; }
+    else {
+      d = tape.random_vector("d_vec", nn);  // DotProductProof randomness (nizk/mod.rs:330-332)
+      r_delta = tape.random_scalar("r_delta"); r_beta = tape.random_scalar("r_beta");
     }
-    CP comm_eval = cm1[0], delta = cm1[1];
+    // comm_eval = eval*G1 + blinds_evals[j]*h ; delta = <d, Gn> + r_delta*hn: their scalars are known as soon as r_j is, like the bind
+    CP comm_eval, delta;
+    bool pending = false;  // the bind and the next evaluation are in flight on the device while this core commits
+    if (on_host) {
+      if (sp_table_len(tabs[0]) >= 4) {
+        SPX(sp_sumcheck_bind_eval_start(c, kind, tabs.data(), tabs.size(), U(r_j)));
+        pending = true;
+      } else {
+        SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
+      }
+      try {
+        ahead.wait(j);
+        FqVec row(W, fq_zero());
+        row[nn + 1] = eval;
+        const HostPt* add[1] = {&ahead.be_h[j]};
+        comm_eval = commit_rows(row, 1, add)[0];
+        delta = ahead.delta[j];
+      } catch (...) { if (pending) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+    } else {
+      FqVec rows1(2 * W, fq_zero());
+      rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
+      for (size_t k = 0; k < nn; k++) rows1[W + k] = d[k];
+      rows1[W + nn] = r_delta;
+      std::vector<CP> cm1;
+      if (sp_table_len(tabs[0]) >= 4) {  // one call: the round's r-dependent commitments on a second stream, one wait
+        uint8_t pts[64];
+        SPX(sp_sumcheck_bind_eval_commit(c, kind, tabs.data(), tabs.size(), U(r_j), ev, gn.g, idx_u.data(), W, U(rows1), 2, pts));
+        cm1 = {to_cp(pts), to_cp(pts + 32)};
+      } else {
+        SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
+        cm1 = msm_rows(c, gn.g, idx_u, rows1, 2);
+      }
+      comm_eval = cm1[0]; delta = cm1[1];
+    }
     t.append_point("comm_claim_per_round", comm_claim_per_round.data());
     t.append_point("comm_eval", comm_eval.data());
     FqVec w = t.challenge_vector("combine_two_claims_to_one", 2);
@@ -541,21 +626,27 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     t.append_protocol_name("dot product proof");
     t.append_point("Cx", comm_poly.data());  // Cx = commit(x, blind_x): same inputs and generators as comm_poly
     Fq dp = dot_host(a, d);
-    // launch 2: Cy = target*G1 + blind*h ; beta = dp*G1 + r_beta*h ; and the next round's comm_poly (its inputs,
-    // the next evaluations and claim = eval, are already known)
+    // Cy = target*G1 + blind*h ; beta = dp*G1 + r_beta*h ; and the next round's comm_poly (its inputs are the next
+    // evaluations and claim = eval)
     UniPoly next_poly;
     std::vector<CP> cm2;
-    if (pending) {
-      FqVec rows2(2 * W, fq_zero());
-      rows2[nn + 1] = target; rows2[nn + 2] = blind;
-      rows2[W + nn + 1] = dp; rows2[W + nn + 2] = r_beta;
-      try { cm2 = msm_rows(c, gn.g, idx_u, rows2, 2); } catch (...) { (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
-      SPX(sp_sumcheck_bind_eval_collect(c, ev));
+    if (on_host) {
+      try {
+        FqVec rows2(2 * W, fq_zero());
+        rows2[nn + 1] = target; rows2[nn + 2] = blind;
+        rows2[W + nn + 1] = dp;
+        const HostPt* add2[2] = {nullptr, &ahead.rb_h[j]};
+        cm2 = commit_rows(rows2, 2, add2);
+      } catch (...) { if (pending) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+      if (pending) SPX(sp_sumcheck_bind_eval_collect(c, ev));
       if (more) {
+        REQUIRE(pending);  // a further round means the tables had >= 4 entries: the next evaluations came with the bind
         next_poly = make_poly(ev, eval);
         FqVec row3(W, fq_zero());
-        poly_row(row3, 0, next_poly, blinds_poly[j + 1]);
-        cm2.push_back(msm_rows(c, gn.g, idx_u, row3, 1)[0]);
+        poly_row(row3, 0, next_poly, j + 1);
+        ahead.wait(j + 1);
+        const HostPt* add3[1] = {&ahead.bp_hn[j + 1]};
+        cm2.push_back(commit_rows(row3, 1, add3)[0]);
       }
     } else {
       size_t nrows2 = more ? 3 : 2;
@@ -564,7 +655,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
       rows2[W + nn + 1] = dp; rows2[W + nn + 2] = r_beta;
       if (more) {
         next_poly = make_poly(ev, eval);
-        poly_row(rows2, 2, next_poly, blinds_poly[j + 1]);
+        poly_row(rows2, 2, next_poly, j + 1);
       }
       cm2 = msm_rows(c, gn.g, idx_u, rows2, nrows2);
     }

@@ -141,6 +141,43 @@ bool small_msm_rows(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq
   }
   return true;
 }
+static_assert(sizeof(HostPt) == sizeof(Pt), "HostPt is Pt");
+static std::shared_ptr<StreamTables> stream_of(const sp_gens* g) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = g_reg.find(g);
+  return it == g_reg.end() ? nullptr : it->second;
+}
+bool small_msm_point(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, HostPt* out) {
+  auto st = stream_of(g);
+  if (!st || cols > 16) return false;
+  Pt acc = pt_identity();
+  for (size_t k = 0; k < cols; k++)
+    if (!fq_is_zero(scalars[k])) accumulate(acc, scalars[k], table_of(*st, idx[k]));
+  memcpy(out, &acc, sizeof(Pt));
+  return true;
+}
+bool small_msm_rows_plus(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, size_t rows, const HostPt* const* addend, uint8_t* out) {
+  auto st = stream_of(g);
+  if (!st || cols > 16) return false;
+  const Niels* tabs[16];
+  for (size_t k = 0; k < cols; k++) tabs[k] = nullptr;
+  for (size_t r = 0; r < rows; r++) {
+    Pt acc = pt_identity();
+    for (size_t k = 0; k < cols; k++) {
+      const Fq& sc = scalars[r * cols + k];
+      if (fq_is_zero(sc)) continue;
+      if (!tabs[k]) tabs[k] = table_of(*st, idx[k]);
+      accumulate(acc, sc, tabs[k]);
+    }
+    if (addend && addend[r]) {
+      Pt a;
+      memcpy(&a, addend[r], sizeof(Pt));
+      acc = pt_add(acc, a);
+    }
+    pt_compress(acc, out + 32 * r);
+  }
+  return true;
+}
 // test hook (no device): commitments of rows x npts scalars under npts compressed points
 int small_msm_probe(const uint8_t* compressed, size_t npts, const uint64_t* scalars, size_t rows, uint8_t* out) {
   if (npts == 0 || npts > 16) return SP_EINVAL;
