@@ -627,7 +627,7 @@ static std::list<GensCacheEntry> g_gens_cache;
 static int choose_wbits(size_t n) {
   if (const char* e = getenv("SPARTAN_MSM_WBITS")) {
     int v = atoi(e);
-    if (v >= 8 && v <= 15) return v;
+    if (v >= 4 && v <= 15) return v;
   }
   double budget = 112.0;
   if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }

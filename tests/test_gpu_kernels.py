@@ -108,7 +108,7 @@ def test_commit_rows_launch_plans_match_oracle(ctx, orc, gens301, rows, cols, bl
     assert got == bytes(want)
 
 
-@pytest.mark.parametrize("wbits", [8, 10, 12, 13, 14, 15])
+@pytest.mark.parametrize("wbits", [5, 6, 8, 10, 12, 13, 14, 15])
 def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
     """the window width is a property of the generator set, chosen at upload (core.hip choose_wbits; SPARTAN_MSM_WBITS forces
     it): every width gives the same commitments through every launch plan (one-launch small, windowed trees, row strips, the
