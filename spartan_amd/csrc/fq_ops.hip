@@ -80,24 +80,6 @@ __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ 
   if (nb > 0) v = fq_mul(v, tb[t & ((1 << nb) - 1)]);
   st_fq(out + i, v);
 }
-__global__ void __launch_bounds__(256) k_eq_expand_serial(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
-  __shared__ Fq r[40];
-  if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
-  __syncthreads();
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >> ell) return;
-  Fq acc = fq_one();
-#pragma unroll 1
-  for (size_t k = 0; k < ell; k++) {
-    Fq rk = r[k];
-    bool bit = (i >> (ell - 1 - k)) & 1;  // r[0] <-> most significant index bit
-    Fq f = fq_sub(fq_one(), rk);
-#pragma unroll
-    for (int w = 0; w < 4; w++) f.l[w] = bit ? rk.l[w] : f.l[w];
-    acc = fq_mul(acc, f);
-  }
-  st_fq(out + i, acc);
-}
 
 // Long tables: chi(r)[i] = chi(r_hi)[i >> lo] * chi(r_lo)[i & (2^lo - 1)] — two short tables (kernel above) and ONE
 // multiplication per entry in a streaming kernel with a few hundred bytes of code, instead of the 59 KB unrolled kernel
@@ -357,11 +339,10 @@ int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* 
 
 extern "C" {
 
+// (a one-chain-per-entry kernel, ell multiplications deep, measured the same per proof as this 4+4 product form: removed)
 static void launch_eq_small(sp_ctx* c, const Fq* dr, size_t ell, Fq* out) {
-  static const bool serial = getenv("SPARTAN_EQ_SERIAL") != nullptr;  // A/B switch: the one-chain-per-entry kernel
   size_t len = (size_t)1 << ell;
-  if (serial) hipLaunchKernelGGL(k_eq_expand_serial, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, dr, ell, out);
-  else hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, dr, ell, out);
+  hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, dr, ell, out);
 }
 int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   if (!c || !r || !out || ell == 0 || ell > 40) return SP_EINVAL;
