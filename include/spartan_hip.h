@@ -99,7 +99,8 @@ typedef struct sp_job sp_job;
 int32_t sp_commit_rows_dev_begin(sp_ctx* ctx, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
                                  sp_job** out);
 /* Foreground variant (rows > 8, blinds allowed): queued on the context's main stream at full width; the caller may do HOST
- * work, but no other call on this context, until sp_job_wait. */
+ * work, and may sp_job_wait OTHER jobs of the context (a background one that finishes earlier), but makes no other call on
+ * this context until it has waited for this job. */
 int32_t sp_commit_rows_dev_start(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows,
                                  size_t cols, const uint64_t* blinds, sp_job** out);
 int32_t sp_job_wait(sp_job* job, uint8_t* out /*32*rows*/);
