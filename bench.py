@@ -354,10 +354,10 @@ def main():
         f = fam[dom]
         avg_ms = f["ms"] / f["launches"]
         ach = (f["alg_bytes"] / f["launches"]) / (avg_ms * 1e-3) / 1e9
-        pmc, pmc_note = None, "no PMC file for these kernel sources: collect with profiles/pmc_summarize.py"
+        pmc, pmc_note = None, "no PMC file for these kernel sources and this instance size: collect with profiles/collect_r2.sh + profiles/pmc_summarize.py"
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("kernel_source_digest") == kernel_source_digest() and dom in pj:
+            if pj.get("kernel_source_digest") == kernel_source_digest() and pj.get("log2_cons", 20) == s and dom in pj:
                 pmc, pmc_note = pj[dom], "HBM bytes per launch from rocprofv3 --pmc (separate passes), same kernel sources: profiles/" + pj.get("source", "pmc_traffic.json")
         except (OSError, ValueError):
             pass

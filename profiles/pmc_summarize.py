@@ -38,5 +38,6 @@ for k in ("k_msm_rows", "k_msm_rows_bg"):
 from bench import kernel_source_digest
 out["kernel_source_digest"] = kernel_source_digest()
 out["source"] = sys.argv[3] if len(sys.argv) > 3 else "pmc_traffic.json"
+out["log2_cons"] = 20  # collected on bench.py's default workload (profiles/collect_r2.sh)
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print("\nper-family HBM bytes per launch (profiles/pmc_traffic.json):", json.dumps(out))
