@@ -255,6 +255,14 @@ int32_t sp_sumcheck_eval_coeffs_batched(sp_ctx* ctx, sp_table* const* A, sp_tabl
                                         uint64_t* out_evals, uint64_t* out_coeffs);
 int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t r0[4],
                                        const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads);
+/* The same call (r0 == NULL: no bind, as sp_sumcheck_eval_coeffs_batched; r1 == NULL: one bind) that ALSO hands over the tables
+ * once they are short: when the tables the outputs describe have 2, 4 or 8 entries (and ninst <= 21), out_tables receives them,
+ * [ninst][3: A, B, C][n] Montgomery limbs, and the caller can finish the last <= 3 rounds of the sum-check (sumcheck.rs:287-419:
+ * evaluations, binds, final claims) on its own core — ~20 us of field arithmetic against two more round trips. Otherwise
+ * out_tables[0] is set to all ones and nothing else is written there. The device tables are left at that length. */
+int32_t sp_sumcheck_bind2_eval_tables_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r0,
+                                              const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs,
+                                              uint64_t* out_heads, uint64_t* out_tables /* 4*ninst*3*8 */);
 /* Resident form of the two calls above for the latency-bound tail of a sum-check: tables of at most
  * sp_sumcheck_session_max_len() (512) entries, ~270 of the ~400 batched rounds of a 2^20 proof. ONE kernel stays on the
  * device for all remaining rounds, one workgroup per instance with that instance's tables held in LDS; each round is a

@@ -190,8 +190,10 @@ __device__ __forceinline__ Fq line_at(const Fq& u, const Fq& v, int t) {  // the
   for (int w = 0; w < 4; w++) r.l[w] = t == 0 ? u.l[w] : (t == 1 ? x2.l[w] : x3.l[w]);
   return r;
 }
+// dump != nullptr (only when the outputs describe tables of at most 8 entries): the tables themselves go out as well,
+// dump[(instance * 3 + table) * 8 + z] — the caller finishes the last <= 3 rounds of the sum-check on its own core.
 __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
-                                                          Fq* __restrict__ partials, DoneSig sig) {
+                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig) {
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
   __shared__ Fq red[18][8];
@@ -224,12 +226,17 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
         const size_t z = g + (size_t)p * ng;
         if (k < 2) st_fq(ptr[k] + z, v);
         else if (t.c_out) st_fq(t.c_out + z, v);  // C may be shared between instances: bound out of place, once
+        if (dump) st_fq(dump + ((size_t)blockIdx.y * 3 + k) * 8 + z, v);
         bnd[grp][k * 4 + (np == 2 && p == 1 ? 2 : p)] = v;  // a two-entry table is the pair (x0, x2)
       }
     }
   } else if (live && lane < 12) {
     const int k = lane >> 2, p = lane & 3;
-    if ((size_t)p < np) bnd[grp][k * 4 + (np == 2 && p == 1 ? 2 : p)] = ld_fq(ptr[k] + g + (size_t)p * ng);
+    if ((size_t)p < np) {
+      const Fq v = ld_fq(ptr[k] + g + (size_t)p * ng);
+      if (dump) st_fq(dump + ((size_t)blockIdx.y * 3 + k) * 8 + g + (size_t)p * ng, v);
+      bnd[grp][k * 4 + (np == 2 && p == 1 ? 2 : p)] = v;
+    }
   }
   __syncthreads();
   // 18 triple products per group: lane = 6 t' + kind, kind 0/1 = the two entry pairs of this round, 2..5 = M0, M3, T1, T2
@@ -533,8 +540,9 @@ __global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict_
   signal_done(sig);
 }
 // shared by the two entry points below: launch k_cubic_bind2_eval, bring the 18 sums per instance to the host
+constexpr size_t TAIL_OFF = 12288, TAIL_MAX_INST = 21;  // the <= 8-entry tables of <= 21 instances behind the 18 sums per instance in the result page
 static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int nbind, const uint64_t* r0, const uint64_t* r1,
-                            const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads) {
+                            const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads, uint64_t* out_tables = nullptr) {
   if (!c || !A || !B || !C || ninst == 0 || ninst > 64) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   size_t len = A[0] ? A[0]->len : 0;
@@ -563,12 +571,14 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 18 * (nblk + 1) * ninst));
   bool host = 32 * 18 * nblk * ninst <= HOST_SUM_BYTES;
   Fq* partials = host ? (Fq*)hres(c) : (Fq*)c->scratch;
+  const bool tail = out_tables && n2 >= 2 && n2 <= 8 && ninst <= TAIL_MAX_INST && host && nblk == 1;
+  Fq* dump = tail ? (Fq*)(hres(c) + TAIL_OFF) : nullptr;
   Fq z = fq_zero();
   DoneSig sig = sig_make(c, host ? nblk * ninst : ninst);  // raised by the last kernel of the trip
   {
     ProfScope ps(c, do_bind ? PF_SC_BIND_EVAL : PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, (do_bind ? 36.0 + 36.0 : 36.0) * (double)ng * (double)ninst);
     hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple2*)c->hmap, dweights, len, nbind,
-                       r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials, host ? sig : sig_none());
+                       r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials, dump, host ? sig : sig_none());
   }
   std::vector<Fq> sums(18 * ninst);
   if (!host) {
@@ -589,6 +599,15 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
       }
   }
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  if (out_tables) {  // [ninst][3][n2], or nothing (first word all ones) when the tables are longer than 8 or there are too many instances
+    if (tail) {
+      const Fq* d = (const Fq*)(hres(c) + TAIL_OFF);
+      for (size_t i = 0; i < ninst; i++)
+        for (int k = 0; k < 3; k++) memcpy(out_tables + 4 * ((i * 3 + k) * n2), d + (i * 3 + k) * 8, 32 * n2);
+    } else {
+      out_tables[0] = ~0ULL;
+    }
+  }
   if (do_bind) {
     for (size_t k = 0; k < ninst; k++) { A[k]->len = n2; B[k]->len = n2; }
     for (sp_table* t : distinctC) table_swap_to_alt(t, n2);
@@ -624,6 +643,12 @@ int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* 
 int32_t sp_sumcheck_eval_coeffs_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* weights,
                                         uint64_t* out_evals, uint64_t* out_coeffs) {
   return bind2_launch(c, A, B, C, ninst, 0, nullptr, nullptr, weights, out_evals, out_coeffs, nullptr);
+}
+int32_t sp_sumcheck_bind2_eval_tables_batched(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r0,
+                                              const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads,
+                                              uint64_t* out_tables) {
+  if (!out_tables || (r1 && !r0)) return SP_EINVAL;
+  return bind2_launch(c, A, B, C, ninst, r0 ? (r1 ? 2 : 1) : 0, r0, r1, weights, out_evals, out_coeffs, out_heads, out_tables);
 }
 int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out) {
   if (!c || !chi || !tabs || !out || nt == 0 || nt > 64) return SP_EINVAL;

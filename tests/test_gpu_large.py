@@ -504,3 +504,46 @@ def test_two_rounds_per_launch_match_reference_arithmetic(ctx, ell):
     assert from_mont_bulk(tA[1].download(n // 2), n // 2) == A[1] and from_mont_bulk(tCpar.download(n // 2), n // 2) == Cpar
     for t in tA + tB + tCseq + [tCpar]:
         t.free()
+
+
+@pytest.mark.parametrize("ell,nbind", [(5, 2), (4, 2), (3, 2), (4, 1), (3, 1), (2, 1), (3, 0), (2, 0), (1, 0), (6, 2)])
+def test_short_tables_are_handed_over_with_the_round(ctx, ell, nbind):
+    """sp_sumcheck_bind2_eval_tables_batched: the call of the two-rounds-per-trip path that also returns the tables once they have
+    at most 8 entries, so that the host driver finishes the last <= 3 rounds of prove_cubic_batched on its own core
+    (spark.inc, finish_on_host). The tables handed over are the bound tables of the reference arithmetic; with longer tables
+    (ell = 6 -> 16 entries) nothing is handed over and the first word says so."""
+    from spartan_amd import capi
+    n = 1 << ell
+    rng = random.Random(9900 + 10 * ell + nbind)
+    npar, nseq = 3, 2
+    ni = npar + nseq
+    A = [fast_scalars(rng, n) for _ in range(ni)]
+    B = [fast_scalars(rng, n) for _ in range(ni)]
+    Cpar = fast_scalars(rng, n)
+    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
+    tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
+    tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
+    hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
+    hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
+    w = fast_scalars(rng, ni)
+    rs = [rng.getrandbits(251) for _ in range(nbind)]
+    for r in rs:
+        A = [bind(a, r) for a in A]; B = [bind(b, r) for b in B]; Cpar = bind(Cpar, r); Cseq = [bind(c, r) for c in Cseq]
+    m = n >> nbind
+    Cs = [Cpar] * npar + Cseq
+    ev = (ctypes.c_uint64 * 12)(); co = (ctypes.c_uint64 * 48)(); heads = (ctypes.c_uint64 * (4 * (2 * ni + 1 + nseq)))()
+    tables = (ctypes.c_uint64 * (4 * ni * 3 * 8))()
+    rc = capi.lib.sp_sumcheck_bind2_eval_tables_batched(ctx.h, hA, hB, hC, sz(ni), fq1(rs[0]) if nbind >= 1 else None, fq1(rs[1]) if nbind == 2 else None,
+                                                        mont_bulk(w), ev if m >= 2 else None, co if m >= 4 else None, heads if m == 1 else None, tables)
+    assert rc == 0
+    if m >= 2:   # the weighted sums of the round, as without the hand-over
+        want = [sum(w[k] * cubic_evals(A[k], B[k], Cs[k])[t] for k in range(ni)) % Q for t in range(3)]
+        assert from_mont_bulk(ev, 3) == want
+    if 2 <= m <= 8:
+        got = from_mont_bulk(tables, ni * 3 * m)
+        for k in range(ni):
+            assert got[(3 * k) * m:(3 * k + 1) * m] == A[k] and got[(3 * k + 1) * m:(3 * k + 2) * m] == B[k] and got[(3 * k + 2) * m:(3 * k + 3) * m] == Cs[k], k
+    else:
+        assert tables[0] == 0xFFFFFFFFFFFFFFFF
+    for t in tA + tB + [tCpar] + tCseq:
+        t.free()
