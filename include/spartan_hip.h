@@ -149,7 +149,8 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* ctx, int kind, sp_table* const* tab
 /* DensePolynomial::bound (dense_mlpoly.rs:206-213): out[i] = sum_j L[j]*Z[j*R+i], Z viewed as Lsz x (len/Lsz). */
 int32_t sp_vecmat(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z, uint64_t* out);
 /* The same with the result left on the device as a new table (PolyEvalProof::prove only commits to it and feeds it to the
- * inner-product argument: it never has to visit the host). */
+ * inner-product argument: it never has to visit the host). L is copied before the call returns; the multiplication is queued,
+ * not waited for — the table is ready for every later call on ctx (stream order). */
 int32_t sp_vecmat_dev(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z, sp_table** out);
 /* compute_dotproduct / inner_product (nizk/mod.rs:435-438, bullet.rs:233-243) over n elements. */
 int32_t sp_dot(sp_ctx* ctx, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]);
@@ -288,6 +289,9 @@ void sp_sumcheck_session_abort(sp_session* s);
 int32_t sp_dot_many(sp_ctx* ctx, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out /*4*nt*/);
 /* DotProductCircuit::evaluate (product_tree.rs:84-88): sum l[i]*r[i]*w[i] over n elements from the given offsets. */
 int32_t sp_dot3(sp_ctx* ctx, const sp_table* l, const sp_table* r, const sp_table* w, size_t off, size_t n, uint64_t out[4]);
+/* nt of them in one launch and one wait (the six claim_eval_dotp_left/right of ProductLayerProof::prove, sparse_mlpoly.rs:1084-1101):
+ * out[4k..4k+4) = sum_{i<n} l_k[i] r_k[i] w_k[i]. */
+int32_t sp_dot3_many(sp_ctx* ctx, const sp_table* const* l, const sp_table* const* r, const sp_table* const* w, size_t nt, size_t n, uint64_t* out);
 
 #ifdef __cplusplus
 }

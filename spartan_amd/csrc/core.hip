@@ -53,6 +53,28 @@ int32_t ensure_pinned(sp_ctx* c, size_t need) {
   c->pinned_cap = want;
   return SP_OK;
 }
+// A staging pair of its own for calls that queue a host vector and return without waiting (sp_vecmat_dev): the buffers of
+// stage_in are rewritten by the next call, which may come before this copy has run. The event guards the pair's own reuse.
+int32_t vm_stage(sp_ctx* c, const void* src, size_t bytes, const void** dev) {
+  if (c->vm_ev) HIPCHK(hipEventSynchronize(c->vm_ev));  // the previous copy out of vm_pinned (long done in practice)
+  else HIPCHK(hipEventCreateWithFlags(&c->vm_ev, hipEventDisableTiming));
+  if (c->vm_cap < bytes) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->vm_pinned) HIPCHK(hipHostFree(c->vm_pinned));
+    if (c->vm_dstage) HIPCHK(hipFree(c->vm_dstage));
+    c->vm_pinned = c->vm_dstage = nullptr;
+    c->vm_cap = 0;
+    size_t want = bytes * 2 + 4096;
+    HIPCHK(hipHostMalloc((void**)&c->vm_pinned, want, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->vm_dstage, want));
+    c->vm_cap = want;
+  }
+  memcpy(c->vm_pinned, src, bytes);
+  HIPCHK(hipMemcpyAsync(c->vm_dstage, c->vm_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->vm_ev, c->stream));
+  *dev = c->vm_dstage;
+  return SP_OK;
+}
 void prof_drain(sp_ctx* c) {
   if (c->pending.empty()) return;
   (void)hipStreamSynchronize(c->stream);
@@ -528,6 +550,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->sess_dev) (void)hipFree(c->sess_dev);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
+  if (c->vm_pinned) (void)hipHostFree(c->vm_pinned);
+  if (c->vm_dstage) (void)hipFree(c->vm_dstage);
+  if (c->vm_ev) (void)hipEventDestroy(c->vm_ev);
   if (c->sync_ev) (void)hipEventDestroy(c->sync_ev);
   if (c->side_ev) (void)hipEventDestroy(c->side_ev);
   if (c->stream_side) (void)hipStreamDestroy(c->stream_side);

@@ -623,19 +623,18 @@ int32_t sp_vecmat_dev(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* 
   if (!c || !L || !Z || !out || Lsz == 0 || Z->len % Lsz) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   size_t R = Z->len / Lsz;
-  SPCHK(ensure_dstage(c, 32 * Lsz));
-  SPCHK(stage_in(c, 0, L, 32 * Lsz));
+  const void* dL = nullptr;
+  SPCHK(vm_stage(c, L, 32 * Lsz, &dL));  // queued, not waited for: the caller goes on (the chi vector of the other half, the transcript)
   size_t jchunk = vecmat_jchunk(Lsz, R), nchunks = (Lsz + jchunk - 1) / jchunk;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nchunks * R + R)));
   SPCHK(table_new(c, R, false, out));
   Fq* partial = (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R, nullptr, (double)Z->len);
-    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)c->dstage, Lsz,
+    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)dL, Lsz,
                        (const Fq*)Z->d, R, jchunk, partial);
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, (*out)->d);
   }
-  SPCHK(sync_spin(c));  // the staging buffers behind L are reusable
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]) {

@@ -77,6 +77,9 @@ struct sp_ctx {
   volatile uint32_t* done_flag;
   uint32_t done_seq;
   uint32_t* done_counter = nullptr;  // DoneSig::counter
+  uint8_t *vm_pinned = nullptr, *vm_dstage = nullptr;  // sp_vecmat_dev's own staging pair for L: the call does not wait (core.hip: vm_stage)
+  size_t vm_cap = 0;
+  hipEvent_t vm_ev = nullptr;
   struct { bool active; int kind; size_t nblk; bool on_host; uint32_t seq; } pend_eval = {false, 0, 0, false, 0};  // sp_sumcheck_bind_eval_start .. _collect
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
 
@@ -185,6 +188,7 @@ void prof_drain(sp_ctx* c);
 int32_t stage_in(sp_ctx* c, size_t off, const void* src, size_t bytes);   // host -> c->dstage (+off), async
 int32_t ensure_dstage(sp_ctx* c, size_t need);
 int32_t fetch_out(sp_ctx* c, const void* dsrc, void* hdst, size_t bytes);  // device -> host, synchronous
+int32_t vm_stage(sp_ctx* c, const void* src, size_t bytes, const void** dev);  // host -> device copy queued on the main stream, no wait; own buffers
 // Completion signalled by the LAST KERNEL of a round trip itself instead of by a flag kernel queued behind it (~4 us of
 // dispatch per trip, ~500 trips per proof): every workgroup fences its results to system scope and counts itself in; the
 // last one stores the sequence number the host is spinning on. flag == nullptr: no signal (the kernel is not the last).

@@ -313,6 +313,17 @@ __global__ void __launch_bounds__(256) k_dot3(const Fq* __restrict__ l, const Fq
   if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
 }
 
+// grid (nblk, nt): partials[t*nblk + blk] = partial sum_i l_t[i] r_t[i] w_t[i]; ptrs = [l_0..l_{nt-1} | r_0.. | w_0..]
+__global__ void __launch_bounds__(256) k_dot3_many(const Fq* const* __restrict__ ptrs, size_t nt, size_t n, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  const Fq *l = ptrs[blockIdx.y], *r = ptrs[nt + blockIdx.y], *w = ptrs[2 * nt + blockIdx.y];
+  Fq acc[1] = {fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fq_add(acc[0], fq_mul(fq_mul(ld_fq(l + i), ld_fq(r + i)), ld_fq(w + i)));
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc[0]);
+}
+
 static Fq limbs(const uint64_t* p) {
   Fq x;
   memcpy(x.l, p, 32);
@@ -672,6 +683,31 @@ int32_t sp_dot_many(sp_ctx* c, const sp_table* chi, sp_table* const* tabs, size_
     hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, (Fq*)hres(c), sig_none());
   }
   SPCHK(fetch_small(c, out, 32 * nt));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_dot3_many(sp_ctx* c, const sp_table* const* l, const sp_table* const* r, const sp_table* const* w, size_t nt, size_t n, uint64_t* out) {
+  if (!c || !l || !r || !w || !out || nt == 0 || nt > 64 || n == 0 || 24 * nt > HMAP_GEN) return SP_EINVAL;
+  std::vector<const Fq*> ptrs(3 * nt);
+  for (size_t k = 0; k < nt; k++) {
+    if (!l[k] || !r[k] || !w[k] || l[k]->cap < n || r[k]->cap < n || w[k]->cap < n) return SP_EINVAL;
+    ptrs[k] = l[k]->d; ptrs[nt + k] = r[k]->d; ptrs[2 * nt + k] = w[k]->d;
+  }
+  HIPCHK(hipSetDevice(c->dev));
+  stage_small(c, 0, ptrs.data(), 8 * ptrs.size());
+  size_t nblk = grid_for(n, 1024);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nblk + 1) * nt));
+  Fq* partials = (Fq*)c->scratch;
+  DoneSig sig = sig_make(c, nt);
+  {
+    ProfScope ps(c, PF_DOT, 96.0 * (double)n * (double)nt, nullptr, 2.0 * (double)n * (double)nt);
+    hipLaunchKernelGGL(k_dot3_many, dim3((unsigned)nblk, (unsigned)nt), dim3(256), 0, c->stream, (const Fq* const*)c->hmap, nt, n, partials);
+  }
+  {
+    ProfScope ps(c, PF_REDUCE, 32.0 * (double)(nblk * nt));
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)nt), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 1, (Fq*)hres(c), sig);
+  }
+  SPCHK(sig_wait(c, sig));
+  memcpy(out, hres(c), 32 * nt);
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_dot3(sp_ctx* c, const sp_table* l, const sp_table* r, const sp_table* w, size_t off, size_t n, uint64_t out[4]) {

@@ -755,10 +755,10 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
   size_t Ls = pow2(r.size() / 2), Rs = pow2(r.size() - r.size() / 2);
   REQUIRE(poly.len() == Ls * Rs);
   FqVec Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
-  FqVec Rv = eq_evals_host(FqVec(r.begin() + r.size() / 2, r.end()));
   sp_table* lz = nullptr;
-  SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device
+  SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device; queued, not waited for
   DevTable LZ(c, lz);
+  FqVec Rv = eq_evals_host(FqVec(r.begin() + r.size() / 2, r.end()));  // while the device multiplies
   Fq LZ_blind = fq_zero();
   if (blinds_opt) {
     REQUIRE(blinds_opt->size() == Ls);

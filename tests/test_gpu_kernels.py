@@ -375,3 +375,21 @@ def test_background_commit_overlaps_and_matches(ctx, orc, gens40):
     assert orc.orc_commit_rows(g[32 * 2:32 * (2 + cols)], sz(cols), g[32 * 39:], mont_array(Z[:4 * cols]), sz(4), sz(cols), None, want) == 0
     assert got[:128] == bytes(want)
     t.free(); ta.free(); tb.free()
+
+
+def test_dot3_many_matches_reference_arithmetic(ctx):
+    """sp_dot3_many: the six DotProductCircuit::evaluate of ProductLayerProof::prove (product_tree.rs:84-88) in one launch"""
+    from spartan_amd import capi
+    rng = random.Random(606)
+    nt, n = 6, 3000
+    vals = [[rand_scalars(rng, n) for _ in range(3)] for _ in range(nt)]
+    tabs = [[capi.Table.upload(ctx, mont_array(v), n) for v in trip] for trip in vals]
+    L = (vp * nt)(*[t[0].h for t in tabs]); R = (vp * nt)(*[t[1].h for t in tabs]); W = (vp * nt)(*[t[2].h for t in tabs])
+    out = (ctypes.c_uint64 * (4 * nt))()
+    assert capi.lib.sp_dot3_many(ctx.h, L, R, W, sz(nt), sz(n), out) == 0
+    got = from_mont_array(out, nt)
+    for k in range(nt):
+        assert got[k] == sum(a * b * c for a, b, c in zip(*vals[k])) % Q, k
+    for trip in tabs:
+        for t in trip:
+            t.free()
