@@ -718,10 +718,13 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
     for (size_t k = 0; k < lg_n; k++) {
       CP L, R;
       SPX(sp_ipa_round_lr(ipa, U(v1[k]), U(v2[k]), L.data(), R.data()));
+      Fq u, u_inv;
+      { HSPAN("ipa_transcript");
       t.append_point("L", L.data());
       t.append_point("R", R.data());
-      Fq u = t.challenge_scalar("u");
-      Fq u_inv = fq_invert(u);
+      u = t.challenge_scalar("u"); }
+      { HSPAN("ipa_invert");
+      u_inv = fq_invert(u); }
       SPX(sp_ipa_round_fold(ipa, U(u), U(u_inv)));
       blind_hat = blind_hat + v1[k] * u * u + v2[k] * u_inv * u_inv;
       p.bullet.L_vec.push_back(L);
