@@ -820,11 +820,8 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
       P.comm_vars = poly_commit(c, poly_vars, lv, gens.gens_pc, &blinds_vars);
     }
   }
-  append_poly_commitment(t, "poly_commitment", P.comm_vars);
-  if (tm) tm->polycommit = now_s() - t0;
-
-  double t1 = now_s();
-  // z = vars | 1 | input | 0...  (:177-185), built on the device
+  // z = vars | 1 | input | 0...  (:177-185) and Az, Bz, Cz (:187-196) do not depend on the transcript: they are queued now and
+  // the device builds them while this core absorbs the commitment
   DevTable z = tab_alloc(c, 2 * num_vars);
   SPX(sp_table_copy(c, z.h, 0, poly_vars.h, 0, num_vars));
   {
@@ -833,9 +830,6 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
     tail.insert(tail.end(), input.begin(), input.end());
     SPX(sp_table_write(c, z.h, num_vars, U(tail), tail.size()));
   }
-  size_t num_rounds_x = log_2(inst.num_cons), num_rounds_y = log_2(2 * num_vars);
-  FqVec tau = t.challenge_vector("challenge_tau", num_rounds_x);
-  DevTable poly_tau = tab_eq(c, tau);
   sp_table *tAz, *tBz, *tCz;
   SPX(sp_sparse_mulvec(c, inst.dA, z.h, &tAz));
   DevTable poly_Az(c, tAz);
@@ -843,6 +837,13 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   DevTable poly_Bz(c, tBz);
   SPX(sp_sparse_mulvec(c, inst.dC, z.h, &tCz));
   DevTable poly_Cz(c, tCz);
+  append_poly_commitment(t, "poly_commitment", P.comm_vars);
+  if (tm) tm->polycommit = now_s() - t0;
+
+  double t1 = now_s();
+  size_t num_rounds_x = log_2(inst.num_cons), num_rounds_y = log_2(2 * num_vars);
+  FqVec tau = t.challenge_vector("challenge_tau", num_rounds_x);
+  DevTable poly_tau = tab_eq(c, tau);
   FqVec rx, claims1;
   Fq blind_claim_postsc1;
   P.sc_proof_phase1 = zk_sumcheck_prove(c, 2, fq_zero(), fq_zero(), num_rounds_x, {poly_tau.h, poly_Az.h, poly_Bz.h, poly_Cz.h},
