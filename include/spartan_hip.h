@@ -200,6 +200,9 @@ int32_t sp_ipa_round_fold(sp_ipa* ipa, const uint64_t u[4], const uint64_t u_inv
 int32_t sp_ipa_finish(sp_ipa* ipa, uint64_t a_hat[4], uint64_t b_hat[4], uint8_t* g_hat);
 /* commit(d, r) under {G: g_hat, h: H}: d * g_hat + r * H, compressed (nizk/mod.rs:496-501 `delta`). */
 int32_t sp_ipa_commit_ghat(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint8_t out[32]);
+/* sp_ipa_finish (without g_hat) and sp_ipa_commit_ghat in one round trip: the commitment under g_hat does not depend on
+ * a_hat, b_hat (nizk/mod.rs:498-503 forms y_hat = a_hat * b_hat afterwards). */
+int32_t sp_ipa_finish_commit(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint64_t a_hat[4], uint64_t b_hat[4], uint8_t delta_out[32]);
 void sp_ipa_free(sp_ipa* ipa);
 
 /* ---- SPARK: sparse-polynomial evaluation proof building blocks (src/sparse_mlpoly.rs, src/product_tree.rs) ---- */

@@ -116,6 +116,12 @@ __global__ void __launch_bounds__(256) k_ipa_ghat_row(const Fq* __restrict__ s, 
   }
 }
 
+// a_hat, b_hat (the vectors at length 1) into the host-mapped result page
+__global__ void k_ipa_heads(const Fq* __restrict__ a, const Fq* __restrict__ b, Fq* __restrict__ out, DoneSig sig) {
+  if (threadIdx.x == 0) { st_fq(out, ld_fq(a)); st_fq(out + 1, ld_fq(b)); }
+  signal_done(sig);
+}
+
 static Fq limbs(const uint64_t* p) {
   Fq x;
   memcpy(x.l, p, 32);
@@ -244,9 +250,32 @@ int32_t sp_ipa_finish(sp_ipa* ipa, uint64_t a_hat[4], uint64_t b_hat[4], uint8_t
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
   SPCHK(ipa_flush_fold(ipa));
-  SPCHK(fetch_out(c, ipa->a, a_hat, 32));
-  SPCHK(fetch_out(c, ipa->b, b_hat, 32));
+  DoneSig sig = sig_make(c, 1);
+  hipLaunchKernelGGL(k_ipa_heads, dim3(1), dim3(64), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (Fq*)hres(c), sig);
+  SPCHK(sig_wait(c, sig));  // one trip for both
+  memcpy(a_hat, hres(c), 32);
+  memcpy(b_hat, hres(c) + 32, 32);
   if (g_hat) SPCHK(msm_launch(c, ipa->g, ipa->s, ipa->n0, 1, ipa->n0, ipa->g_off, nullptr, nullptr, 0, g_hat));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+// sp_ipa_finish and sp_ipa_commit_ghat in one trip: delta = commit(d, r) under {g_hat, h} does not depend on a_hat, b_hat
+// (nizk/mod.rs:498-503 computes y_hat from them only afterwards), so its launches go out first and the two scalars ride along.
+int32_t sp_ipa_finish_commit(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint64_t a_hat[4], uint64_t b_hat[4], uint8_t delta_out[32]) {
+  if (!ipa || !d || !r || !a_hat || !b_hat || !delta_out || ipa->n_cur != 1) return SP_EINVAL;
+  sp_ctx* c = ipa->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  SPCHK(ipa_flush_fold(ipa));
+  // between the partial sums (< HOST_SUM_BYTES) and the row sums (last KiB) of the result page: msm_launch leaves it alone
+  Fq* ab = (Fq*)(hres(c) + HOST_SUM_BYTES);
+  hipLaunchKernelGGL(k_ipa_heads, dim3(1), dim3(64), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, ab, sig_none());
+  {
+    ProfScope ps(c, PF_IPA, 64.0 * (double)ipa->n0);
+    hipLaunchKernelGGL(k_ipa_ghat_row, dim3((unsigned)grid_for(ipa->n0, 64)), dim3(256), 0, c->stream, (const Fq*)ipa->s, ipa->n0, limbs(d),
+                       limbs(r), ipa->rows);
+  }
+  SPCHK(msm_launch(c, ipa->g, ipa->rows, ipa->n0 + 2, 1, ipa->n0 + 2, 0, ipa->idx, nullptr, 0, delta_out));  // waits for the stream
+  memcpy(a_hat, ab, 32);
+  memcpy(b_hat, ab + 1, 32);
   return SP_OK;
 }
 int32_t sp_ipa_commit_ghat(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint8_t out[32]) {

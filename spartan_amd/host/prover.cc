@@ -731,10 +731,9 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
       p.bullet.R_vec.push_back(R);
     }
     Fq a_hat, b_hat;
-    SPX(sp_ipa_finish(ipa, a_hat.l, b_hat.l, nullptr));
-    Fq y_hat = a_hat * b_hat;
     CP delta;
-    SPX(sp_ipa_commit_ghat(ipa, U(d), U(r_delta), delta.data()));  // commit(d, r_delta) under {g_hat, h}
+    SPX(sp_ipa_finish_commit(ipa, U(d), U(r_delta), a_hat.l, b_hat.l, delta.data()));  // a_hat, b_hat and commit(d, r_delta) under {g_hat, h}: one trip
+    Fq y_hat = a_hat * b_hat;
     t.append_point("delta", delta.data());
     CP beta = msm_rows(c, g1.g, {g1.G[0], g1.h}, {d * r, r_beta}, 1)[0];  // commit(d, r_beta) under gens_1.scale(r)
     t.append_point("beta", beta.data());
