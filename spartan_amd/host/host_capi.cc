@@ -100,6 +100,23 @@ void* spz_instance_synthetic(void* ctx, size_t num_cons, size_t num_vars, size_t
   });
 }
 // UniPoly::from_evals / compress / evaluate (unipoly.rs) on n = 3 or 4 evaluations; scalars as Montgomery limbs. Test hook.
+// host arithmetic of the batched cubic sum-check (spark.inc): the cubic in the next challenge, and the last rounds on short tables
+void spz_cubic_coeffs_probe(const uint64_t S[48], const uint64_t r[4], uint64_t ev[12]) {
+  Fq s[12], rr, e[3];
+  memcpy(s, S, sizeof s); memcpy(rr.l, r, 32);
+  cubic_coeffs_probe(s, rr, e);
+  memcpy(ev, e, sizeof e);
+}
+// tab: [ni][3][m] in, bound in place; evs: 3 per round (log2 m rounds); returns the number of rounds
+int spz_cubic_tail_probe(uint64_t* tab, size_t ni, size_t m, const uint64_t* coeffs, const uint64_t* challenges, uint64_t* evs) {
+  size_t rounds = 0;
+  for (size_t x = m; x > 1; x /= 2) rounds++;
+  FqVec t = limbs_vec(tab, ni * 3 * m), cf = limbs_vec(coeffs, ni), ch = limbs_vec(challenges, rounds), e;
+  cubic_tail_probe(t, ni, m, cf, ch, &e);
+  memcpy(tab, t.data(), 32 * t.size());
+  memcpy(evs, e.data(), 32 * e.size());
+  return (int)rounds;
+}
 int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint64_t* coeffs, uint64_t* compressed, uint64_t eval_at_r[4]) {
   try {
     FqVec e(n), c, cc;

@@ -138,3 +138,74 @@ def test_small_commitments_on_the_host_core_match_oracle(orc):
         for r in range(rows):
             assert orc.orc_pt_msm(mont_array(S[r * 5:(r + 1) * 5]), g, sz(5), want) == 1
             assert bytes(got[32 * r:32 * r + 32]) == bytes(want), (kind, r)
+
+
+def _cubic_evals(A, B, C):
+    h = len(A) // 2
+    out = []
+    for t in (0, 2, 3):
+        acc = 0
+        for z in range(h):
+            a = (A[z] + t * (A[h + z] - A[z])) % Q; b = (B[z] + t * (B[h + z] - B[z])) % Q; c = (C[z] + t * (C[h + z] - C[z])) % Q
+            acc += a * b * c
+        out.append(acc % Q)
+    return out
+
+
+def _bind(T, r):
+    h = len(T) // 2
+    return [(T[z] + r * (T[h + z] - T[z])) % Q for z in range(h)]
+
+
+def test_last_rounds_of_the_batched_sumcheck_on_the_host():
+    """spark.inc cubic_tail_rounds: the <= 3 last rounds of prove_cubic_batched (sumcheck.rs:287-419) that the driver runs on its
+    own core once the device has handed over the short tables — evaluations at t = 0, 2, 3 combined with the batching
+    coefficients, binds, final values — against the reference arithmetic, for every hand-over length."""
+    import ctypes, random
+    from spartan_amd import prover
+    rng = random.Random(4242)
+    for m in (8, 4, 2):
+        ni = 5
+        tabs = [[[rng.randrange(Q) for _ in range(m)] for _ in range(3)] for _ in range(ni)]
+        coeffs = [rng.randrange(Q) for _ in range(ni)]
+        rounds = m.bit_length() - 1
+        ch = [rng.randrange(Q) for _ in range(rounds)]
+        flat = [x for inst in tabs for t in inst for x in t]
+        buf = mont_array(flat); evs = (ctypes.c_uint64 * (4 * 3 * rounds))()
+        assert prover.H.spz_cubic_tail_probe(buf, sz(ni), sz(m), mont_array(coeffs), mont_array(ch), evs) == rounds
+        got_ev = from_mont_array(evs, 3 * rounds)
+        cur = tabs
+        for k in range(rounds):
+            want = [sum(coeffs[i] * _cubic_evals(*cur[i])[t] for i in range(ni)) % Q for t in range(3)]
+            assert got_ev[3 * k:3 * k + 3] == want, (m, k)
+            cur = [[_bind(T, ch[k]) for T in inst] for inst in cur]
+        out = from_mont_array(buf, ni * 3 * m)
+        for i in range(ni):
+            for t in range(3):
+                assert out[(i * 3 + t) * m] == cur[i][t][0], (m, i, t)
+
+
+def test_cubic_in_the_next_challenge_on_the_host():
+    """spark.inc evals_from_coeffs: E(t; r) = (1-r)^3 M0 + (1-r)^2 r M1 + (1-r) r^2 M2 + r^3 M3 with M1 = (T1-T2)/2 - M3,
+    M2 = (T1+T2)/2 - M0 is the evaluation of the round after a bind at r (two rounds per trip): checked by building
+    M0, M3, T1, T2 from random tables in Python and comparing with the evaluations of the tables actually bound at r."""
+    import ctypes, random
+    from spartan_amd import prover
+    rng = random.Random(77)
+    n = 16
+    A, B, C = ([rng.randrange(Q) for _ in range(n)] for _ in range(3))
+    q = n // 4
+    line = lambda u, v, t: (u + t * (v - u)) % Q
+    S = []
+    for t in (0, 2, 3):
+        M0 = M3 = T1 = T2 = 0
+        for i in range(q):
+            P = [line(T[i], T[i + q], t) for T in (A, B, C)]            # entries (i, i+q) of the low half: the pair the bind mixes with ...
+            U = [line(T[i + 2 * q], T[i + 3 * q], t) for T in (A, B, C)]  # ... the pair of the high half
+            M0 += P[0] * P[1] * P[2]; M3 += U[0] * U[1] * U[2]
+            T1 += (P[0] + U[0]) * (P[1] + U[1]) * (P[2] + U[2]); T2 += (P[0] - U[0]) * (P[1] - U[1]) * (P[2] - U[2])
+        S += [M0 % Q, M3 % Q, T1 % Q, T2 % Q]
+    r = rng.randrange(Q)
+    ev = (ctypes.c_uint64 * 12)()
+    prover.H.spz_cubic_coeffs_probe(mont_array(S), mont_array([r]), ev)
+    assert from_mont_array(ev, 3) == _cubic_evals(_bind(A, r), _bind(B, r), _bind(C, r))
