@@ -97,7 +97,9 @@ impl SumcheckInstanceProof {
 // next to the evaluations of a round, the coefficients (M0, M3, T1, T2 at t = 0, 2, 3) of the cubic in the NEXT challenge
 // that the following round's evaluations are; the caller derives r_j, evaluates that cubic on the host, derives r_{j+1},
 // and only then goes back to the device with both challenges (spartan_amd/host/spark.inc: prove_cubic_batched, evals_from_coeffs).
-// Same field values, same transcript operations, half the round trips. The one-round form above is the same proof.
+// Same field values, same transcript operations, half the round trips. Once the tables have at most 8 entries the call's
+// `_tables_` variant (sp_sumcheck_bind2_eval_tables_batched) also returns the tables themselves and the driver runs the last
+// <= 3 rounds with the reference's own loop body on the CPU (spark.inc: cubic_tail_rounds). The one-round form above is the same proof.
 
 // ZKSumcheckInstanceProof::prove_quad (:428-586) and ::prove_cubic_with_additive_term (:588-776): the round body becomes
 //   round 0:  sp_sumcheck_eval(kind, tabs) -> evals -> UniPoly -> comm_poly  (reference code: poly.commit(...))
