@@ -232,7 +232,7 @@ def strong_scaling_leg(P, ctx, dist, rank, world, s, steps, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-cons", type=int, default=20, help="log2 of num_cons = num_vars = num_nz_entries (BASELINE: 20)")
     ap.add_argument("--cpu-log2-cons", type=int, default=17, help="size of the bounded CPU-baseline sample (2^17: ~15 s of one core)")
