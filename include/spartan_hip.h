@@ -70,8 +70,8 @@ int sp_msm_window_bits(void);
  * of one SHAKE stream (gens_3/gens_4/gens_pc of R1CSGens, src/r1csproof.rs:48-73) share one sp_gens.
  * Upload builds signed c-bit fixed-base window tables (ceil(254/c) windows x 2^(c-1) affine entries of 96 B per point):
  * generators are public parameters reused across proofs, so this is setup cost. c is the widest of 15/14/13/12/10/8 whose
- * tables fit the HBM budget of the set (SPARTAN_MSM_TABLE_GB, default 112; SPARTAN_MSM_WBITS forces a width): 15 bits — 17
- * additions per committed scalar, 26 MiB per point — for the generators of a 2^20 instance, 13 bits for a 2^22 one.
+ * tables fit the HBM budget of the set (SPARTAN_MSM_TABLE_GB, default 128; SPARTAN_MSM_WBITS forces a width): 15 bits — 17
+ * additions per committed scalar, 26 MiB per point — for the generators of a 2^20 instance, 15 and 14 bits for a 2^22 one.
  * SP_ENOMEM if not even 8-bit tables fit. */
 int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n, sp_gens** out);
 /* MultiCommitGens::new body (commitments.rs:21-30): n blocks of 64 uniform bytes from the caller's

@@ -645,16 +645,17 @@ static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
 
 // Window width of a generator set: the widest c whose tables (n points x ceil(254/c) windows x 2^(c-1) entries x 96 B) fit the
-// budget — SPARTAN_MSM_TABLE_GB (default 112) per set, and never more than the free device memory less a 24 GB reserve.
+// budget — SPARTAN_MSM_TABLE_GB (default 128) per set, and never more than the free device memory less a 24 GB reserve.
 // 288 GB of HBM3E is what makes this a knob: at 2^20 both generator streams get 15-bit windows (17 additions per scalar,
-// 27 + 110 GB of tables), at 2^22 the 8194-point evaluation stream falls back to 13 bits (20 additions, 64 GB), and a set too
+// 27 + 110 GB of tables), at 2^22 the 8194-point evaluation stream gets 14 bits (19 additions, 122 GB next to the other stream's
+// 55 GB; measured 72.8 -> 70.8 ms per proof against 13 bits), at 2^24 15 and 12 bits (110 + 71 GB), and a set too
 // large for 8-bit tables is refused. SPARTAN_MSM_WBITS forces a width (the tests use it to cover several).
 static int choose_wbits(size_t n) {
   if (const char* e = getenv("SPARTAN_MSM_WBITS")) {
     int v = atoi(e);
     if (v >= 4 && v <= 15) return v;
   }
-  double budget = 112.0;
+  double budget = 128.0;
   if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
