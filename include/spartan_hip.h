@@ -45,6 +45,10 @@ void sp_ctx_destroy(sp_ctx* ctx);
 /* Waits until everything queued on the context has run (calls that return results already do; calls that only enqueue —
  * sp_eq_expand, sp_gather, sp_hash_layer, sp_table_copy ... — do not). */
 int32_t sp_ctx_sync(sp_ctx* ctx);
+int sp_ctx_device(const sp_ctx* ctx); /* the device_id the context was created on */
+/* Completed device round trips of the context so far (every wait for a result counts one): the difference around a proof is its
+ * number of Fiat-Shamir steps that went to the GPU (bench.py reports it as fs_trips_per_proof). */
+uint64_t sp_ctx_trips(const sp_ctx* ctx);
 /* HIP-event timing of every kernel family on the context's stream (bench.py's roofline numbers). */
 int32_t sp_prof_enable(sp_ctx* ctx, int on);
 int32_t sp_prof_reset(sp_ctx* ctx);
@@ -69,15 +73,17 @@ int sp_msm_window_bits(void);
  * MultiCommitGens::new(m, label) is the list of its m+1 stream points with h = P[m]; gens that are prefixes
  * of one SHAKE stream (gens_3/gens_4/gens_pc of R1CSGens, src/r1csproof.rs:48-73) share one sp_gens.
  * Upload builds signed c-bit fixed-base window tables (ceil(254/c) windows x 2^(c-1) affine entries of 96 B per point):
- * generators are public parameters reused across proofs, so this is setup cost. c is the widest of 15/14/13/12/10/8 whose
- * tables fit the HBM budget of the set (SPARTAN_MSM_TABLE_GB, default 128; SPARTAN_MSM_WBITS forces a width): 15 bits — 17
- * additions per committed scalar, 26 MiB per point — for the generators of a 2^20 instance, 15 and 14 bits for a 2^22 one.
- * SP_ENOMEM if not even 8-bit tables fit. */
+ * generators are public parameters reused across proofs, so this is setup cost. c is chosen per set by PROOF time, not launch
+ * time: 15 bits (17 additions per committed scalar, 26 MiB per point) while the set's tables stay under SPARTAN_MSM_WIDE_GB
+ * (default 32), otherwise the widest of 14/13/12/10/8 that fits SPARTAN_MSM_TABLE_GB (default 128); SPARTAN_MSM_WBITS forces a
+ * width. 2^20: 15 bits for the 1025-point stream (27 GB), 14 for the 4098-point one (61 GB). SP_ENOMEM (with a message on
+ * stderr) if not even 8-bit tables fit in free device memory. */
 int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n, sp_gens** out);
 /* MultiCommitGens::new body (commitments.rs:21-30): n blocks of 64 uniform bytes from the caller's
  * SHAKE256 stream -> from_uniform_bytes on the device. compressed_out (32*n) may be NULL. */
 int32_t sp_gens_from_uniform(sp_ctx* ctx, const uint8_t* uniform /*64*n*/, size_t n, uint8_t* compressed_out, sp_gens** out);
 size_t sp_gens_len(const sp_gens* g);
+size_t sp_gens_table_bytes(const sp_gens* g); /* HBM held by the window tables of this set */
 int sp_gens_window_bits(const sp_gens* g); /* the width c the tables of this set were built with */
 void sp_gens_free(sp_gens* g);
 
@@ -108,6 +114,36 @@ int32_t sp_job_wait(sp_job* job, uint8_t* out /*32*rows*/);
  * src/nizk/mod.rs, the per-round L/R of src/nizk/bullet.rs:83-97 re-expressed over the ORIGINAL generators):
  * out[i] = compress( sum_j S[i*cols+j] * P[idx[j]] ). */
 int32_t sp_msm_indexed(sp_ctx* ctx, const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, uint8_t* out);
+
+/* ---- few-term commitments on the CALLING THREAD's core (Scalar::commit / UniPoly::commit of the Sigma protocols,
+ * src/commitments.rs:73-93; src/nizk/mod.rs; the rounds of the zero-knowledge sum-checks, src/sumcheck.rs:471-583, 661-772).
+ * A 2..5-term commitment is a chain of ~100 dependent point additions and one inverse square root that the transcript waits
+ * for: ~15 us on the core that is waiting anyway, ~60 us + a round trip on a lone wavefront. These entry points compute
+ * them on the host from signed 10-bit window tables of the generators involved (built lazily, 1.25 MiB per generator,
+ * from the encodings the sp_gens was created from) with the same point arithmetic the kernels compile. No GPU work, no
+ * context: any thread may call them. sp_msm_indexed is the device form of the same commitments (same bytes).
+ *   out[r] = compress( sum_k S[r*cols+k] * P[idx[k]]  (+ *addend[r] when addend and addend[r] are non-NULL) ),  cols <= 16. */
+typedef struct sp_host_point { uint64_t w[16]; } sp_host_point; /* an extended point in the library's own form; opaque to callers */
+int32_t sp_host_commit_small(const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, size_t rows, const sp_host_point* const* addend,
+                             uint8_t* out /*32*rows*/);
+/* One row left as a point (not encoded): a partial commitment to be added to a later one through `addend`. */
+int32_t sp_host_commit_point(const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, sp_host_point* out);
+/* The same arithmetic without a device or an sp_gens (CPU tests): npts encoded points, rows x npts scalars. */
+int32_t sp_host_commit_probe(const uint8_t* compressed /*32*npts*/, size_t npts, const uint64_t* S, size_t rows, uint8_t* out);
+/* Look-ahead for the zero-knowledge sum-checks. Inside their round loop nothing but DotProductProof::prove draws from the
+ * random tape (d_vec, r_delta, r_beta: nizk/mod.rs:330-334), so a caller can take the draws of all rounds up front, in the
+ * reference's order, and have a helper thread compute everything that depends on the tape alone while the rounds run:
+ * with idx_u = (gens_n.G[0..nn), gens_n.h, gens_1.G[0], gens_1.h) (W = nn + 3 entries), for round j
+ *   delta_j = compress( <d_j, gens_n.G> + r_delta_j * gens_n.h )            the DotProductProof's delta, complete
+ *   bp_hn_j = blinds_poly[j] * gens_n.h,  be_h_j = blinds_evals[j] * gens_1.h,  rb_h_j = r_beta_j * gens_1.h
+ * the blind terms of comm_poly, comm_eval and beta, to be passed as `addend` to sp_host_commit_small.
+ * begin copies its inputs and starts the thread; wait blocks until round j is done (rounds complete in order);
+ * free joins the thread. d is [rounds][nn]; the other vectors [rounds]. */
+typedef struct sp_zk_ahead sp_zk_ahead;
+int32_t sp_host_zk_ahead_begin(const sp_gens* g, const uint32_t* idx_u, size_t W, size_t nn, size_t rounds, const uint64_t* blinds_poly,
+                               const uint64_t* blinds_evals, const uint64_t* d, const uint64_t* r_delta, const uint64_t* r_beta, sp_zk_ahead** out);
+int32_t sp_host_zk_ahead_wait(sp_zk_ahead* a, size_t j, uint8_t delta[32], sp_host_point* be_h, sp_host_point* rb_h, sp_host_point* bp_hn);
+void sp_host_zk_ahead_free(sp_zk_ahead* a);
 
 /* ---- device tables (DensePolynomial.Z, src/dense_mlpoly.rs:14-18) ----------------------------------- */
 int32_t sp_table_alloc(sp_ctx* ctx, size_t len, sp_table** out);          /* zero-filled */
@@ -267,27 +303,6 @@ int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table
 int32_t sp_sumcheck_bind2_eval_tables_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r0,
                                               const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs,
                                               uint64_t* out_heads, uint64_t* out_tables /* 4*ninst*3*8 */);
-/* Resident form of the two calls above for the latency-bound tail of a sum-check: tables of at most
- * sp_sumcheck_session_max_len() (512) entries, ~270 of the ~400 batched rounds of a 2^20 proof. ONE kernel stays on the
- * device for all remaining rounds, one workgroup per instance with that instance's tables held in LDS; each round is a
- * mailbox exchange (the challenge goes in, the 3*ninst evaluations come out) instead of a launch, a pass over HBM and a
- * completion wait — the transcript stays with the caller. Same arithmetic, same table contents afterwards.
- *   begin : tables as for sp_sumcheck_eval_batched (equal current length, 2 <= length <= max_len). first_eval != 0: also
- *           evaluates the round on the tables as they are -> out_evals[12*ninst] (what sp_sumcheck_eval_batched returns).
- *   round : sp_sumcheck_bind_eval_batched at r (current length >= 4).
- *   finish: the last round, current length 2: binds every table at r and returns the remaining entries,
- *           out_heads = A_0, B_0, A_1, B_1, ..., then each distinct C table in order of first appearance
- *           (sp_table_bind_top_heads on that list). Ends the session and frees it, also on error.
- *   abort : ends a session early (error paths); the tables hold the state after the last completed round.
- * Between begin and finish/abort no other call may be made on the context, and the tables' device contents are undefined
- * (the current values live in LDS). A session that hears nothing from its caller for 2 s writes its tables back and ends. */
-size_t sp_sumcheck_session_max_len(void);
-typedef struct sp_session sp_session;
-int32_t sp_sumcheck_session_begin(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int first_eval,
-                                  uint64_t* out_evals, sp_session** out);
-int32_t sp_sumcheck_session_round(sp_session* s, const uint64_t r[4], uint64_t* out_evals);
-int32_t sp_sumcheck_session_finish(sp_session* s, const uint64_t r[4], uint64_t* out_heads);
-void sp_sumcheck_session_abort(sp_session* s);
 /* out[k] = <chi, T_k> for k < nt (the ~23 DensePolynomial::evaluate calls of HashLayerProof::prove share chi). */
 int32_t sp_dot_many(sp_ctx* ctx, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out /*4*nt*/);
 /* DotProductCircuit::evaluate (product_tree.rs:84-88): sum l[i]*r[i]*w[i] over n elements from the given offsets. */

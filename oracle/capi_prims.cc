@@ -55,4 +55,22 @@ size_t orc_merlin_script(const char* tlabel, size_t nops, const int* kinds, cons
   }
   return o;
 }
+// the 203-byte transcript state after the same kind of script (challenges are drawn and dropped)
+void orc_merlin_state(const char* tlabel, size_t nops, const int* kinds, const char* const* labels, const uint8_t* const* datas, const size_t* lens,
+                      uint8_t out_state[203]) {
+  Transcript t(tlabel);
+  uint8_t sink[256];
+  for (size_t i = 0; i < nops; i++) {
+    if (kinds[i] == 0) t.append_message(labels[i], datas[i], lens[i]);
+    else if (kinds[i] == 1) t.challenge_bytes(labels[i], sink, lens[i] < sizeof sink ? lens[i] : sizeof sink);
+    else { uint64_t x; memcpy(&x, datas[i], 8); t.append_u64(labels[i], x); }
+  }
+  t.export_state(out_state);
+}
+void orc_merlin_challenge_from_state(uint8_t state[203], const char* label, uint8_t* out, size_t n) {
+  Transcript t("x");
+  t.import_state(state);
+  t.challenge_bytes(label, out, n);
+  t.export_state(state);
+}
 }

@@ -94,6 +94,30 @@ void* orc_snark_prove(void* inst, void* gens, void* enc, const char* transcript_
   p->bytes = ser_snark(p->snark); fill_times(tm, times10);
   return p;
 }
+// SNARK::prove / NIZK::prove continuing a caller-owned transcript (lib.rs:339-347, 501-509): state in, state out
+void* orc_snark_prove_t(void* inst, void* gens, void* enc, uint8_t transcript_state[203], const uint64_t tape_seed[4]) {
+  InstH* I = (InstH*)inst; ProofH* p = new ProofH; p->is_snark = true;
+  Transcript t("x"); t.import_state(transcript_state); ProveTimes tm; memset(&tm, 0, sizeof tm);
+  p->snark = snark_prove(I->inst, ((EncH*)enc)->comm, ((EncH*)enc)->decomm, I->vars, I->inputs, ((SnarkGensH*)gens)->g, t, limbs(tape_seed), &tm);
+  p->bytes = ser_snark(p->snark);
+  t.export_state(transcript_state);
+  return p;
+}
+void* orc_nizk_prove_t(void* inst, void* gens, const uint8_t* digest, size_t digest_len, uint8_t transcript_state[203], const uint64_t tape_seed[4]) {
+  InstH* I = (InstH*)inst; ProofH* p = new ProofH; p->is_snark = false;
+  Transcript t("x"); t.import_state(transcript_state); ProveTimes tm; memset(&tm, 0, sizeof tm);
+  std::vector<uint8_t> d(digest, digest + digest_len);
+  p->nizk = nizk_prove(I->inst, d, I->vars, I->inputs, ((NizkGensH*)gens)->g, t, limbs(tape_seed), &tm);
+  p->bytes = ser_nizk(p->nizk);
+  t.export_state(transcript_state);
+  return p;
+}
+int orc_snark_verify_t(void* proof, void* inst, void* gens, void* enc, uint8_t transcript_state[203]) {
+  Transcript t("x"); t.import_state(transcript_state);
+  int ok = snark_verify(((ProofH*)proof)->snark, ((EncH*)enc)->comm, ((InstH*)inst)->inputs, t, ((SnarkGensH*)gens)->g) ? 1 : 0;
+  t.export_state(transcript_state);
+  return ok;
+}
 int orc_snark_verify(void* proof, void* inst, void* gens, void* enc, const char* transcript_label) {
   Transcript t(transcript_label);
   return snark_verify(((ProofH*)proof)->snark, ((EncH*)enc)->comm, ((InstH*)inst)->inputs, t, ((SnarkGensH*)gens)->g) ? 1 : 0;

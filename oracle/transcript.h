@@ -41,6 +41,11 @@ struct Strobe128 {
 struct Transcript {  // merlin::Transcript
   Strobe128 s;
   explicit Transcript(const char* label) : s("Merlin v1.0") { append_message("dom-sep", (const uint8_t*)label, strlen(label)); }
+  // merlin 3.0.0: Transcript { strobe: Strobe128 { state: [u8; 200], pos, pos_begin, cur_flags } } — 203 bytes say everything.
+  // The reference's provers take `transcript: &mut Transcript` (src/lib.rs:339-347): a caller may have absorbed anything
+  // before; these two let a test start the oracle from such a state and read the state the proof leaves behind.
+  void import_state(const uint8_t in[203]) { memcpy(s.st, in, 200); s.pos = in[200]; s.pos_begin = in[201]; s.cur_flags = in[202]; }
+  void export_state(uint8_t out[203]) const { memcpy(out, s.st, 200); out[200] = s.pos; out[201] = s.pos_begin; out[202] = s.cur_flags; }
   void append_message(const char* label, const uint8_t* msg, size_t n) {
     uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
     s.meta_ad((const uint8_t*)label, strlen(label), false);

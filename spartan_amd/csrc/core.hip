@@ -4,7 +4,7 @@
 #include <mutex>
 
 const char* kProfNames[PF_COUNT] = {"gens_table_build", "msm_rows_fixed", "msm_windows_fixed", "msm_reduce_pass", "msm_reduce_compress", "eq_expand", "sumcheck_eval",
-                                    "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "sumcheck_session", "misc"};
+                                    "table_bind", "sumcheck_bind_eval", "vecmat", "dot", "fq_reduce", "sparse", "ipa", "spark", "misc"};
 
 int32_t ensure(void** p, size_t* cap, size_t need) {
   if (*cap >= need) return SP_OK;
@@ -376,6 +376,182 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
     else ((Pt10*)out)[row * gridDim.x + blockIdx.x] = r;
   }
 }
+// ---- one inner-product round in ONE launch (BulletReductionProof::prove, src/nizk/bullet.rs:72-100) ---------------------
+// L = <a_L, G_R>, R = <a_R, G_L> over the ORIGINAL generators (spartan_hip.h: the folded generators are never built): row 0
+// pairs scalar a'[i] s'[p] with generator p n_cur + h + i, row 1 scalar a'[h + i] s'[p] with generator p n_cur + i, for
+// p < n0 / n_cur, i < h = n_cur / 2. The c_L Q + blind_L H part of each row (two terms) is added by the calling thread from
+// its host-side window tables while this kernel runs (ipa.hip), so every column here is a plain generator column.
+// Blocks [0, 2 nblk): 256 (column, window) lookups of one row each, summed in the LDS tree; the block that arrives last at
+// its row's counter adds the row's nblk partial sums and writes the row sum to the host-mapped page — what used to be three
+// launches (scalar rows, lookups + tree, reduction) and a flag kernel. With `fold` set the vectors are those of the previous
+// round and the fold of bullet.rs:105-109 by (u, u^-1) is applied on the way (a' = a_L u + u^-1 a_R, s'[2p] = s[p] u^-1,
+// s'[2p+1] = s[p] u: 3 multiplications per lookup, redundantly per window, instead of a launch of their own).
+// Blocks [2 nblk, 2 nblk + nd) work off the critical path: they materialise a', b', s' for the next round and form the eight
+// quarter dot products from which the NEXT round's c_L, c_R follow once its challenge is known:
+//   c_L'' = <a'_LL,b'_LR> + u^2 <a'_LL,b'_RR> + u^-2 <a'_RL,b'_LR> + <a'_RL,b'_RR>
+//   c_R'' = <a'_LR,b'_LL> + u^2 <a'_LR,b'_RL> + u^-2 <a'_RR,b'_LL> + <a'_RR,b'_RL>        (quarters of a', b' in index order LL, LR, RL, RR)
+// so no round waits for a dot product over the whole vectors (bullet.rs:80-81).
+struct IpaRoundArgs {
+  const Fq *a, *b, *s;         // vectors before the pending fold (a, b: 2 n_cur entries when fold; s: n0 / (2 n_cur) entries), else current
+  Fq *a_new, *b_new, *s_new;   // the vectors of this round, written when fold != 0
+  size_t n_cur, n0, g_off;
+  int fold;
+  Fq u, u_inv;
+  Pt10* part;                  // [2][nblk]
+  uint32_t* counters;          // [2], zero between launches
+  Pt* sums_out;                // host page: the two row sums
+  Fq* dots_out;                // host page: [nd][8] partial quarter dot products
+  unsigned nblk, nd;
+};
+__device__ __forceinline__ Fq ipa_fold_a(const Fq* __restrict__ a, size_t x, size_t n_cur, int fold, const Fq& u, const Fq& u_inv) {
+  Fq v = ld_fq(a + x);
+  return fold ? fq_add(fq_mul(v, u), fq_mul(u_inv, ld_fq(a + n_cur + x))) : v;  // a' = a_L u + u^-1 a_R
+}
+__device__ __forceinline__ Fq ipa_fold_b(const Fq* __restrict__ b, size_t x, size_t n_cur, int fold, const Fq& u, const Fq& u_inv) {
+  Fq v = ld_fq(b + x);
+  return fold ? fq_add(fq_mul(v, u_inv), fq_mul(u, ld_fq(b + n_cur + x))) : v;  // b' = b_L u^-1 + u b_R
+}
+__global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* __restrict__ table, MsmGeom geom, DoneSig sig) {
+  __shared__ Pt10 sm[256];
+  __shared__ Fe10 xch[256];
+  __shared__ unsigned ticket;
+  const int t = threadIdx.x;
+  const size_t h = A.n_cur / 2;
+  if (blockIdx.x >= 2 * A.nblk) {
+    // ---- the next round's vectors and quarter dot products
+    Fq* const red = reinterpret_cast<Fq*>(sm);  // [8][64]
+    const size_t qlen = A.n_cur >= 4 ? A.n_cur / 4 : 1;
+    const unsigned db = blockIdx.x - 2 * A.nblk;
+    const size_t z = (size_t)db * 64 + (t >> 2);
+    const int k = t & 3;
+    const size_t x = z + (size_t)k * qlen;
+    const bool live = z < qlen && x < A.n_cur;
+    Fq av = fq_zero(), bv = fq_zero();
+    if (live) {
+      av = ipa_fold_a(A.a, x, A.n_cur, A.fold, A.u, A.u_inv);
+      bv = ipa_fold_b(A.b, x, A.n_cur, A.fold, A.u, A.u_inv);
+      if (A.fold) { st_fq(A.a_new + x, av); st_fq(A.b_new + x, bv); }
+    }
+    if (A.fold)
+      for (size_t p = (size_t)db * 256 + t; p < A.n0 / A.n_cur; p += (size_t)A.nd * 256)
+        st_fq(A.s_new + p, fq_mul(ld_fq(A.s + p / 2), (p & 1) ? A.u : A.u_inv));  // s'[2p] = s[p] u^-1, s'[2p+1] = s[p] u
+    // lane k of an index multiplies its a' with two of the b' of the index: exchange the b' through LDS
+    Fq* const bx = reinterpret_cast<Fq*>(xch);  // [64][4]
+    bx[(t >> 2) * 4 + k] = bv;
+    __syncthreads();
+    Fq e0 = fq_zero(), e1 = fq_zero();
+    if (live && A.n_cur >= 4) {
+      e0 = fq_mul(av, bx[(t >> 2) * 4 + ((k & 1) ? 0 : 1)]);
+      e1 = fq_mul(av, bx[(t >> 2) * 4 + ((k & 1) ? 2 : 3)]);
+    }
+    // dot d = 2 * slot(k) + {0, 1} with slot: k = 0 (a_LL) -> d0, d1 | k = 2 (a_RL) -> d2, d3 | k = 1 (a_LR) -> d4, d5 | k = 3 (a_RR) -> d6, d7
+    const int slot = k == 0 ? 0 : (k == 2 ? 1 : (k == 1 ? 2 : 3));
+    __syncthreads();
+    red[(2 * slot) * 64 + (t >> 2)] = e0;
+    red[(2 * slot + 1) * 64 + (t >> 2)] = e1;
+    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+      for (int v = t; v < 8 * st; v += 256) {
+        const int d = v / st, i = v % st;
+        red[d * 64 + i] = fq_add(red[d * 64 + i], red[d * 64 + i + st]);
+      }
+      __syncthreads();
+    }
+    if (t < 8) st_fq(A.dots_out + (size_t)db * 8 + t, red[t * 64]);
+    signal_done(sig);
+    return;
+  }
+  // ---- lookups of one row + tree
+  const unsigned row = blockIdx.x / A.nblk, blk = blockIdx.x % A.nblk;
+  const size_t cols = A.n0 / 2, P = cols * (size_t)geom.nwin;
+  const size_t p = (size_t)blk * 256 + t;
+  Pt10 acc = pt10_identity();
+  if (p < P) {
+    const size_t q = p % cols;
+    const int w = (int)(p / cols);
+    const size_t pb = q / h, i = q % h;
+    const size_t gen = A.g_off + pb * A.n_cur + (row == 0 ? h + i : i);
+    Fq av = ipa_fold_a(A.a, row == 0 ? i : h + i, A.n_cur, A.fold, A.u, A.u_inv);
+    Fq sv = A.fold ? fq_mul(ld_fq(A.s + pb / 2), (pb & 1) ? A.u : A.u_inv) : ld_fq(A.s + pb);
+    Fq sc = fq_mul(av, sv);
+    if (!fq_is_zero(sc)) {
+      int d = msm_digit(fq_from_mont(sc), w, geom);
+      if (d != 0) {
+        Niels n = table[msm_tidx(geom, gen, w, d < 0 ? -d : d)];
+        Fp dx = fp_sub(n.yp, n.ym), sy = fp_add(n.yp, n.ym);
+        Fp X = fp_add(dx, dx), T = fp_mul(dx, sy);
+        if (d < 0) { X = fp_neg(X); T = fp_neg(T); }
+        acc = Pt10{fe10_load(X), fe10_load(fp_add(sy, sy)), Fe10{{4, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, fe10_load(T)};
+      }
+    }
+  }
+  sm[t] = acc;
+  __syncthreads();
+  pt10_tree_quad(sm, xch, P - (size_t)blk * 256);
+  if (t == 0) {
+    A.part[(size_t)row * A.nblk + blk] = sm[0];
+    __threadfence();  // the partial sum is visible device-wide before this block counts itself in
+    ticket = atomicAdd(A.counters + row, 1u);
+  }
+  __syncthreads();
+  if (ticket == A.nblk - 1) {  // last block of the row: add the row's partial sums
+    __threadfence();
+    Pt10 r = pt10_identity();
+    bool any = false;
+    for (size_t k2 = t; k2 < A.nblk; k2 += 256) {
+      Pt10 q2 = A.part[(size_t)row * A.nblk + k2];
+      r = any ? pt10_add(r, q2) : q2;
+      any = true;
+    }
+    __syncthreads();
+    sm[t] = r;
+    __syncthreads();
+    pt10_tree_quad(sm, xch, A.nblk < 256 ? A.nblk : 256);
+    if (t == 0) {
+      Pt10 z = sm[0];
+      A.sums_out[row] = Pt{fe10_to_fp(z.X), fe10_to_fp(z.Y), fe10_to_fp(z.Z), fe10_to_fp(z.T)};
+      A.counters[row] = 0;
+    }
+  }
+  signal_done(sig);
+}
+// c_L = <a_L, b_R>, c_R = <a_R, b_L> of the FIRST round (bullet.rs:80-81), one block; later rounds get theirs from the quarter
+// dot products of the round before (k_ipa_round)
+__global__ void __launch_bounds__(256) k_ipa_c0(const Fq* __restrict__ a, const Fq* __restrict__ b, size_t n, Fq* __restrict__ out) {
+  __shared__ Fq sm[256];
+  const size_t h = n / 2;
+  Fq c[2] = {fq_zero(), fq_zero()};
+  for (size_t i = threadIdx.x; i < h; i += 256) {
+    c[0] = fq_add(c[0], fq_mul(ld_fq(a + i), ld_fq(b + h + i)));
+    c[1] = fq_add(c[1], fq_mul(ld_fq(a + h + i), ld_fq(b + i)));
+  }
+  block_sum_fq<2>(c, sm);
+  if (threadIdx.x == 0) { st_fq(out, c[0]); st_fq(out + 1, c[1]); }
+}
+extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out) {
+  const size_t P = (A->n0 / 2) * (size_t)g->geom.nwin;
+  A->nblk = (unsigned)((P + 255) / 256);
+  const size_t qlen = A->n_cur >= 4 ? A->n_cur / 4 : 1;
+  A->nd = (unsigned)((qlen + 63) / 64);
+  if ((size_t)A->nd * 8 * 32 > 8192) return SP_EINVAL;  // the dot-product partials share the host page with the two row sums
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, sizeof(Pt10) * 2 * (size_t)A->nblk + 256));
+  A->part = (Pt10*)c->scratch;
+  A->sums_out = (Pt*)hres(c);
+  A->dots_out = (Fq*)(hres(c) + 1024);
+  DoneSig sig = sig_make(c, 2 * (size_t)A->nblk + A->nd);
+  {
+    ProfScope ps(c, PF_IPA, 32.0 * 3 * (double)A->n0 + 160.0 * 2 * (double)A->nblk, nullptr, (double)(2 * P));
+    hipLaunchKernelGGL(k_ipa_round, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
+  }
+  *sig_out = sig;
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+extern "C" int32_t ipa_c0_launch(sp_ctx* c, const Fq* a, const Fq* b, size_t n, Fq* out) {
+  ProfScope ps(c, PF_IPA, 64.0 * (double)n);
+  hipLaunchKernelGGL(k_ipa_c0, dim3(1), dim3(256), 0, c->stream, a, b, n, out);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+
 // reduction pass: grid (rows, nchunks); block sums `chunk` consecutive partials of its row into one point.
 // Reductions run on the radix-2^25.5 serial-chain arithmetic (fe10.hpp): few waves, latency-bound.
 __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt10* __restrict__ out) {
@@ -489,8 +665,6 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->pinned = nullptr;
   c->pinned_cap = 0;
   c->hmap = nullptr;
-  c->sess_cmd = c->sess_slots = c->sess_dev = nullptr;
-  c->sess_seq = 0;
   c->done_flag = nullptr;
   c->sync_epoch = 0;
   c->eq_next = 0;
@@ -545,9 +719,6 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->dstage) (void)hipFree(c->dstage);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->hmap) (void)hipHostFree(c->hmap);
-  if (c->sess_cmd) (void)hipHostFree(c->sess_cmd);
-  if (c->sess_slots) (void)hipHostFree(c->sess_slots);
-  if (c->sess_dev) (void)hipFree(c->sess_dev);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
   if (c->vm_pinned) (void)hipHostFree(c->vm_pinned);
@@ -560,6 +731,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+int sp_ctx_device(const sp_ctx* c) { return c ? c->dev : -1; }
+uint64_t sp_ctx_trips(const sp_ctx* c) { return c ? c->sync_epoch : 0; }
 int32_t sp_ctx_sync(sp_ctx* c) {
   if (!c) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
@@ -644,29 +817,43 @@ struct GensCacheEntry {
 static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
 
-// Window width of a generator set: the widest c whose tables (n points x ceil(254/c) windows x 2^(c-1) entries x 96 B) fit the
-// budget — SPARTAN_MSM_TABLE_GB (default 128) per set, and never more than the free device memory less a 24 GB reserve.
-// 288 GB of HBM3E is what makes this a knob: at 2^20 both generator streams get 15-bit windows (17 additions per scalar,
-// 27 + 110 GB of tables), at 2^22 the 8194-point evaluation stream gets 14 bits (19 additions, 122 GB next to the other stream's
-// 55 GB; measured 72.8 -> 70.8 ms per proof against 13 bits), at 2^24 15 and 12 bits (110 + 71 GB), and a set too
-// large for 8-bit tables is refused. SPARTAN_MSM_WBITS forces a width (the tests use it to cover several).
+// Window width of a generator set. The table of a set is n points x ceil(254/c) windows x 2^(c-1) entries x 96 B; wider
+// windows mean fewer mixed additions per committed scalar (17 at 15 bits, 19 at 14, 20 at 13) and every LAUNCH is shortest at
+// the widest width — but the PROOF is not: the gathers of a 110 GB table set miss L2 94 % of the time and slow the
+// latency-bound kernels that run next to a background commit ("the derefs window"); swept at 2^20
+// (profiles/r2_window_width_sweep.txt) the proof is fastest with 14 bits for the 4098-point evaluation stream (61 GB) and
+// 15 bits for the 1025-point one (27 GB). So the width is chosen by proof time, not by launch time:
+//   * 15 bits while the set's table stays under SPARTAN_MSM_WIDE_GB (default 32),
+//   * otherwise the widest of 14/13/12/10/8 that fits the budget SPARTAN_MSM_TABLE_GB (default 128 per set),
+//   * and never more than the free device memory less a reserve for the proof's own tables (24 GB, applied only to
+//     tables that are themselves large: a 1.5 MB table set must not be refused because another process holds the HBM).
+// 2^22: 15 / 14 bits (55 + 122 GB); 2^24: 14 / 12 bits. SPARTAN_MSM_WBITS forces a width (the tests use it to cover several).
+// Returns 0 when not even 8-bit tables fit in free memory.
 static int choose_wbits(size_t n) {
   if (const char* e = getenv("SPARTAN_MSM_WBITS")) {
     int v = atoi(e);
     if (v >= 4 && v <= 15) return v;
   }
-  double budget = 128.0;
+  double budget = 128.0, wide = 32.0;
   if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }
+  if (const char* e = getenv("SPARTAN_MSM_WIDE_GB")) { double v = atof(e); if (v > 0) wide = v; }
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-    double avail = (double)free_b / 1e9 - 24.0;
-    if (avail < budget) budget = avail;
-  }
+  double free_gb = 1e9;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) free_gb = (double)free_b / 1e9;
   for (int cbits : {15, 14, 13, 12, 10, 8}) {
     MsmGeom g = msm_geom(cbits);
-    if ((double)n * (double)g.pt_entries * sizeof(Niels) / 1e9 <= budget) return cbits;
+    double gb = (double)n * (double)g.pt_entries * sizeof(Niels) / 1e9;
+    if (cbits == 15 && gb > wide) continue;
+    if (gb > budget) continue;
+    double reserve = gb >= 1.0 ? 24.0 : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
+    if (gb + reserve <= free_gb || (cbits == 8 && gb * 1.05 <= free_gb)) return cbits;
   }
   return 0;
+}
+const uint8_t* gens_compressed_bytes(const sp_gens* g, size_t* n) {
+  const GensCacheEntry* e = (const GensCacheEntry*)g->cache_entry;
+  *n = e->n;
+  return e->mode == 0 ? e->in.data() : e->comp.data();  // the list is never modified while a handle on it exists
 }
 static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint8_t* comp_out, sp_gens** out) {
   if (!c || !in || !out || n == 0) return SP_EINVAL;
@@ -678,7 +865,11 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     if (e.dev == c->dev && e.mode == mode && e.n == n && memcmp(e.in.data(), in, in_bytes) == 0) { hit = &e; break; }
   if (!hit) {
     int wbits = choose_wbits(n);
-    if (wbits == 0) return SP_ENOMEM;
+    if (wbits == 0) {
+      fprintf(stderr, "spartan_hip: no window-table width fits: %zu generators need at least %.2f GB of free device memory (8-bit windows)\n", n,
+              (double)n * (double)msm_geom(8).pt_entries * sizeof(Niels) / 1e9);
+      return SP_ENOMEM;
+    }
     MsmGeom geom = msm_geom(wbits);
     // scratch layout: [in bytes][pad][Pt n][comp 32n][bad int]
     size_t off_pts = (in_bytes + 255) & ~(size_t)255;
@@ -733,6 +924,7 @@ int32_t sp_gens_from_uniform(sp_ctx* c, const uint8_t* uniform, size_t n, uint8_
   return gens_build(c, uniform, 1, n, compressed_out, out);
 }
 size_t sp_gens_len(const sp_gens* g) { return g ? g->n : 0; }
+size_t sp_gens_table_bytes(const sp_gens* g) { return g ? g->n * g->geom.pt_entries * sizeof(Niels) : 0; }
 void sp_gens_free(sp_gens* g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->dev);
@@ -742,6 +934,7 @@ void sp_gens_free(sp_gens* g) {
     std::lock_guard<std::mutex> lk(g_gens_mu);
     GensCacheEntry* e = (GensCacheEntry*)g->cache_entry;
     if (--e->refs == 0) {
+      host_commit_forget(e);
       (void)hipFree(e->table);
       for (auto it = g_gens_cache.begin(); it != g_gens_cache.end(); ++it)
         if (&*it == e) { g_gens_cache.erase(it); break; }

@@ -33,7 +33,6 @@ enum ProfFamily {
   PF_SPARSE,
   PF_IPA,
   PF_SPARK,
-  PF_SESSION,
   PF_MISC,
   PF_COUNT
 };
@@ -83,12 +82,6 @@ struct sp_ctx {
   struct { bool active; int kind; size_t nblk; bool on_host; uint32_t seq; } pend_eval = {false, 0, 0, false, 0};  // sp_sumcheck_bind_eval_start .. _collect
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
 
-  // resident sum-check sessions (session.hip): command mailbox + per-workgroup result slots in coherent host memory, the
-  // republished command in device memory; sess_seq numbers every command of the context's lifetime
-  void* sess_cmd;
-  void* sess_slots;
-  void* sess_dev;
-  uint64_t sess_seq;
 
   // size-class pool of device buffers: per-proof tables are recycled instead of hipMalloc/hipFree'd
   std::map<size_t, std::vector<void*>> pool;
@@ -125,6 +118,9 @@ struct sp_table {
   Fq* alt;         // second pool buffer for out-of-place binds of tables shared between kernel instances
   size_t alt_bytes;
 };
+// the 32-byte encodings of a generator set's points (kept by the process-wide table cache, core.hip); *n = number of points
+extern "C" const uint8_t* gens_compressed_bytes(const sp_gens* g, size_t* n);
+void host_commit_forget(const void* cache_entry);  // host_commit.hip: drop the host-side window tables of a freed set
 int32_t table_ensure_alt(sp_table* t, size_t elems);
 void table_swap_to_alt(sp_table* t, size_t new_len);
 

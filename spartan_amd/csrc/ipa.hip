@@ -15,8 +15,32 @@ struct sp_ipa {
   Fq fu, fu_inv;
   uint32_t* idx;              // device: n0+2 generator indices (all generators, Q, H)
   uint32_t* idx_lr;           // device: [2][n0/2+2] per-row generator lists of the current round
+  uint32_t* counters;         // device: [2] row tickets of k_ipa_round (zero between launches)
   size_t bytes;
+  // one-launch rounds (k_ipa_round, core.hip): c_L, c_R of the first round (k_ipa_c0) and the eight quarter dot products the
+  // last round left behind, from which the next c_L, c_R follow once the fold challenge is recorded
+  Fq c0[2], dots[8];
+  bool have_c0, have_dots;
 };
+// core.hip
+struct IpaRoundArgs {
+  const Fq *a, *b, *s;
+  Fq *a_new, *b_new, *s_new;
+  size_t n_cur, n0, g_off;
+  int fold;
+  Fq u, u_inv;
+  Pt10* part;
+  uint32_t* counters;
+  Pt* sums_out;
+  Fq* dots_out;
+  unsigned nblk, nd;
+};
+extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out);
+extern "C" int32_t ipa_c0_launch(sp_ctx* c, const Fq* a, const Fq* b, size_t n, Fq* out);
+static bool ipa_fused() {
+  static const bool on = getenv("SPARTAN_IPA_UNFUSED") == nullptr;  // A/B switch: three launches + flag kernel per round (the round-2 path)
+  return on;
+}
 
 // L = <a_L, G_R> + c_L Q + blind_L H and R = <a_R, G_L> + c_R Q + blind_R H (bullet.rs:83-97) over the ORIGINAL generators:
 // generator j = p*n_cur + i belongs to L when i >= h (scalar a[i-h]*s[p]) and to R when i < h (scalar a[h+i]*s[p]), so
@@ -150,7 +174,7 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
   ipa->q_scale = q_scale ? limbs(q_scale) : fq_one();
   size_t fq_count = 6 * n + 2 * (n + 2);
   uint8_t* base = nullptr;
-  ipa->bytes = 32 * fq_count + 4 * (n + 2) + 4 * (n + 4);
+  ipa->bytes = 32 * fq_count + 4 * (n + 2) + 4 * (n + 4) + 64;
   ipa->a = nullptr;
   ipa->base = nullptr;
   int32_t prc = pool_alloc(c, ipa->bytes, (void**)&base);
@@ -161,6 +185,8 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
   ipa->fold_pending = false;
   ipa->idx = (uint32_t*)(ipa->rows + 2 * (n + 2));
   ipa->idx_lr = ipa->idx + (n + 2);
+  ipa->counters = ipa->idx_lr + (n + 4);
+  ipa->have_c0 = ipa->have_dots = false;
   std::vector<uint32_t> idx(n + 2);
   for (size_t j = 0; j < n; j++) idx[j] = (uint32_t)(g_off + j);
   idx[n] = (uint32_t)q_idx;
@@ -170,11 +196,17 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
                        : hipMemcpyAsync(ipa->a, a, 32 * n, hipMemcpyHostToDevice, c->stream);
   if (e != hipSuccess || hipMemcpyAsync(ipa->b, b, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
       hipMemcpyAsync(ipa->s, &one, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      hipMemcpyAsync(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemsetAsync(ipa->counters, 0, 64, c->stream) != hipSuccess) {
     sp_ipa_free(ipa);
     return SP_EHIP;
   }
   int32_t rc = SP_OK;
+  // c_L, c_R of the first round ride along with whatever this call waits for: into the result page, clear of the row sums
+  Fq* c0_dst = (Fq*)(hres(c) + HOST_SUM_BYTES + 128);
+  const bool want_c0 = ipa_fused() && n >= 2 && !c->device_encode;
+  if (want_c0) rc = ipa_c0_launch(c, ipa->a, ipa->b, n, c0_dst);
+  if (rc != SP_OK) { sp_ipa_free(ipa); return rc; }
   if (commit_a) {  // waits for the stream: the host buffers above are released too
     rc = ensure_dstage(c, 32);
     if (rc == SP_OK) rc = stage_in(c, 0, blind_a, 32);
@@ -183,6 +215,7 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
     rc = SP_EHIP;
   }
   if (rc != SP_OK) { sp_ipa_free(ipa); return rc; }
+  if (want_c0) { memcpy(ipa->c0, c0_dst, 64); ipa->have_c0 = true; }
   *out = ipa;
   return SP_OK;
 }
@@ -201,10 +234,72 @@ int32_t sp_ipa_set_scale(sp_ipa* ipa, const uint64_t q_scale[4]) {
   ipa->q_scale = limbs(q_scale);
   return SP_OK;
 }
+// One launch per round: the kernel looks up and sums the generator columns of both rows and prepares the next round, while
+// the calling thread forms c_L Q + blind_L H and c_R Q + blind_R H (two terms each) from its host-side window tables.
+static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
+  sp_ctx* c = ipa->ctx;
+  Fq cL, cR;
+  if (ipa->fold_pending && ipa->have_dots) {
+    const Fq u2 = fq_mul(ipa->fu, ipa->fu), ui2 = fq_mul(ipa->fu_inv, ipa->fu_inv);
+    const Fq* d = ipa->dots;
+    cL = fq_add(fq_add(d[0], fq_mul(u2, d[1])), fq_add(fq_mul(ui2, d[2]), d[3]));
+    cR = fq_add(fq_add(d[4], fq_mul(u2, d[5])), fq_add(fq_mul(ui2, d[6]), d[7]));
+  } else if (!ipa->fold_pending && ipa->have_c0) {
+    cL = ipa->c0[0]; cR = ipa->c0[1];
+  } else {
+    return SP_EINVAL;  // caller falls back to the three-launch path
+  }
+  ipa->have_c0 = ipa->have_dots = false;
+  IpaRoundArgs A;
+  A.a = ipa->a; A.b = ipa->b; A.s = ipa->s; A.a_new = ipa->a2; A.b_new = ipa->b2; A.s_new = ipa->s2;
+  A.n_cur = ipa->n_cur; A.n0 = ipa->n0; A.g_off = ipa->g_off;
+  A.fold = ipa->fold_pending ? 1 : 0;
+  A.u = ipa->fu; A.u_inv = ipa->fu_inv;
+  A.counters = ipa->counters;
+  DoneSig sig;
+  SPCHK(ipa_round_launch(c, ipa->g, &A, &sig));
+  if (ipa->fold_pending) {  // the kernel leaves the folded vectors in the ping-pong buffers
+    std::swap(ipa->a, ipa->a2); std::swap(ipa->b, ipa->b2); std::swap(ipa->s, ipa->s2);
+    ipa->fold_pending = false;
+  }
+  // meanwhile, on this core: the two-term tails of both rows
+  const uint32_t qh[2] = {(uint32_t)ipa->q_idx, (uint32_t)ipa->h_idx};
+  uint64_t S[8];
+  sp_host_point tails[2];
+  int32_t hrc = SP_OK;
+  for (int r = 0; r < 2 && hrc == SP_OK; r++) {
+    Fq cq = fq_mul(r == 0 ? cL : cR, ipa->q_scale);
+    memcpy(S, cq.l, 32);
+    memcpy(S + 4, r == 0 ? blind_L : blind_R, 32);
+    hrc = sp_host_commit_point(ipa->g, qh, 2, S, &tails[r]);
+  }
+  SPCHK(sig_wait(c, sig));
+  if (hipGetLastError() != hipSuccess) return SP_EHIP;
+  SPCHK(hrc);
+  const Pt* sums = (const Pt*)hres(c);
+  for (int r = 0; r < 2; r++) {
+    Pt tail;
+    memcpy(&tail, &tails[r], sizeof(Pt));
+    pt_compress(pt_add(sums[r], tail), r == 0 ? L_out : R_out);
+  }
+  if (ipa->n_cur >= 4) {
+    const Fq* dp = (const Fq*)(hres(c) + 1024);
+    for (int k = 0; k < 8; k++) {
+      Fq acc = dp[k];
+      for (unsigned b = 1; b < A.nd; b++) acc = fq_add(acc, dp[(size_t)b * 8 + k]);
+      ipa->dots[k] = acc;
+    }
+    ipa->have_dots = true;
+  }
+  return SP_OK;
+}
 int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
   if (!ipa || !blind_L || !blind_R || !L_out || !R_out || ipa->n_cur < 2) return SP_EINVAL;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
+  if (ipa_fused() && !c->device_encode && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0)))
+    return ipa_round_fused(ipa, blind_L, blind_R, L_out, R_out);
+  ipa->have_c0 = ipa->have_dots = false;
   {
     ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);
     hipLaunchKernelGGL(k_ipa_prepare, dim3((unsigned)((ipa->n0 + 511) / 512 + 1)), dim3(512), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n_cur,
@@ -233,6 +328,7 @@ static int32_t ipa_flush_fold(sp_ipa* ipa) {
   }
   std::swap(ipa->s, ipa->s2);
   ipa->fold_pending = false;
+  ipa->have_dots = false;  // they described the vectors before this fold
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_ipa_round_fold(sp_ipa* ipa, const uint64_t u[4], const uint64_t u_inv[4]) {

@@ -150,13 +150,11 @@ size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
   if (out && cap >= v.size()) memcpy(out, v.data(), v.size());
   return v.size();
 }
-// few-term commitments (small_msm.cc): where they run (0 device, 1 this core, -1 SPARTAN_SMALL_MSM), and a device-free probe
+// few-term commitments: where they run (0 device, 1 this core through sp_host_commit_small, -1 SPARTAN_SMALL_MSM)
 void spz_set_small_msm_mode(int mode) { small_msm_set_mode(mode); }
-int spz_small_msm_probe(const uint8_t* compressed, size_t npts, const uint64_t* scalars, size_t rows, uint8_t* out) {
-  return small_msm_probe(compressed, npts, scalars, rows, out);
-}
 // window width of the fixed-base tables of a generator stream (0: gens_r1cs_sat, 1: gens_r1cs_eval)
 int spz_snark_gens_window_bits(void* g, int which) { return sp_gens_window_bits(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
+size_t spz_snark_gens_table_bytes(void* g, int which) { return sp_gens_table_bytes(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
 // bincode of SNARKGens / ComputationCommitment (wire formats)
 size_t spz_snark_gens_bincode(void* g, uint8_t* out, size_t cap) {
   std::vector<uint8_t> b = ((SNARKGens*)g)->serialize();
@@ -213,6 +211,50 @@ void* spz_snark_prove(void* ctx, void* inst, void* gens, void* enc, const uint64
     fill_times(tm, times10);
     ProofH* h = new ProofH;
     h->bytes = p.serialize();
+    return h;
+  });
+}
+// SNARK::prove / NIZK::prove on a CALLER-OWNED transcript (src/lib.rs:339-347, 501-509: `transcript: &mut Transcript`): the
+// 203 bytes of the merlin transcript (STROBE state, pos, pos_begin, cur_flags) come in, the proof is produced on their
+// continuation, and the state after the proof goes back so the caller's transcript can carry on — whatever it had absorbed
+// before. `assignment` (a spz_vars_assignment_new handle) or `vars` (host scalars), one of them. This is the entry the Rust
+// crate's SNARK::prove / NIZK::prove call under `--features gpu` (rust_shim/seams/lib.rs).
+void* spz_snark_prove_t(void* ctx, void* inst, void* gens, void* enc, void* assignment, const uint64_t* vars, size_t nvars, const uint64_t* inputs,
+                        size_t ninputs, uint8_t transcript_state[203], const uint64_t tape_seed[4], double* times10) {
+  return guard([&]() -> void* {
+    if (!transcript_state || (!assignment && !vars)) throw Error("spz_snark_prove_t: bad arguments");
+    Transcript t(Transcript::FromState(), transcript_state);
+    Fq seed;
+    if (tape_seed) memcpy(seed.l, tape_seed, 32);
+    ProveTimes tm;
+    EncH* e = (EncH*)enc;
+    SNARK p = assignment ? SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, *(VarsAssignment*)assignment, limbs_vec(inputs, ninputs),
+                                        *(SNARKGens*)gens, t, tape_seed ? &seed : nullptr, &tm)
+                         : SNARK::prove(*(Ctx*)ctx, *(Instance*)inst, e->comm, e->decomm, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs),
+                                        *(SNARKGens*)gens, t, tape_seed ? &seed : nullptr, &tm);
+    fill_times(tm, times10);
+    ProofH* h = new ProofH;
+    h->bytes = p.serialize();
+    t.export_state(transcript_state);
+    return h;
+  });
+}
+void* spz_nizk_prove_t(void* ctx, void* inst, void* gens, void* assignment, const uint64_t* vars, size_t nvars, const uint64_t* inputs, size_t ninputs,
+                       uint8_t transcript_state[203], const uint64_t tape_seed[4], double* times10) {
+  return guard([&]() -> void* {
+    if (!transcript_state || (!assignment && !vars)) throw Error("spz_nizk_prove_t: bad arguments");
+    Transcript t(Transcript::FromState(), transcript_state);
+    Fq seed;
+    if (tape_seed) memcpy(seed.l, tape_seed, 32);
+    ProveTimes tm;
+    NIZK p = assignment ? NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, *(VarsAssignment*)assignment, limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t,
+                                      tape_seed ? &seed : nullptr, &tm)
+                        : NIZK::prove(*(Ctx*)ctx, *(Instance*)inst, (const sp::Fq*)vars, nvars, limbs_vec(inputs, ninputs), *(NIZKGens*)gens, t,
+                                      tape_seed ? &seed : nullptr, &tm);
+    fill_times(tm, times10);
+    ProofH* h = new ProofH;
+    h->bytes = p.serialize();
+    t.export_state(transcript_state);
     return h;
   });
 }
@@ -285,6 +327,24 @@ size_t spz_merlin_script(const char* tlabel, size_t nops, const int* kinds, cons
     else { uint64_t x; memcpy(&x, datas[i], 8); t.append_u64(labels[i], x); }
   }
   return o;
+}
+// the 203-byte state of a merlin transcript after `Transcript::new(tlabel)` and a script of messages (kinds as above; no challenges)
+void spz_merlin_state(const char* tlabel, size_t nops, const int* kinds, const char* const* labels, const uint8_t* const* datas, const size_t* lens,
+                      uint8_t out_state[203]) {
+  Transcript t(tlabel);
+  uint8_t sink[256];
+  for (size_t i = 0; i < nops; i++) {
+    if (kinds[i] == 0) t.append_message(labels[i], datas[i], lens[i]);
+    else if (kinds[i] == 1) t.challenge_bytes(labels[i], sink, lens[i] < sizeof sink ? lens[i] : sizeof sink);
+    else { uint64_t x; memcpy(&x, datas[i], 8); t.append_u64(labels[i], x); }
+  }
+  t.export_state(out_state);
+}
+// continue a transcript from a state: one challenge of n bytes (checks import/export round trips in the CPU tests)
+void spz_merlin_challenge_from_state(uint8_t state[203], const char* label, uint8_t* out, size_t n) {
+  Transcript t(Transcript::FromState(), state);
+  t.challenge_bytes(label, out, n);
+  t.export_state(state);
 }
 void spz_tape_draws(const uint64_t seed[4], const char* label, size_t n, uint64_t* out) {
   Fq s;

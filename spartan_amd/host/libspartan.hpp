@@ -8,7 +8,7 @@
 // All table-sized field/group work of the prover runs on the GPU through sp_* calls; the host keeps what the
 // reference keeps next to its Transcript — Fiat–Shamir, O(log n)-sized scalar bookkeeping, serialization — and the
 // 2..5-term commitments of the Sigma protocols, whose dependent chains a host core finishes before a lone wavefront
-// would (small_msm.cc).
+// would (the library's host-side engine, sp_host_*).
 #pragma once
 #include <array>
 #include <cstdint>
@@ -59,6 +59,7 @@ struct ShardStats { size_t gathers = 0, bytes = 0; };  // exchanges since the la
 ShardStats commit_shard_stats(Ctx& c, bool reset);
 // internal to the driver (prover.cc <-> shard.cc)
 bool commit_shard_active(sp_ctx* c);
+bool commit_shard_shared_seed(sp_ctx* c, Fq* seed);  // multi-rank transports only: rank 0's OS-entropy draw, handed to every rank
 void commit_shard_forget(sp_ctx* c);
 bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,
                          uint8_t* out);
@@ -288,19 +289,10 @@ struct NIZK {  // lib.rs:488-587
 
 std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p);
 
-// small_msm.cc: the few-term commitments of the Sigma protocols on the proving thread's core (SPARTAN_SMALL_MSM=device sends
-// them to the GPU instead; byte-identical proofs)
-void small_msm_register(const sp_gens* g, const std::vector<uint8_t>& compressed);
-void small_msm_forget(const sp_gens* g);
-bool small_msm_has(const sp_gens* g);
+// Where the few-term commitments of the Sigma protocols run: on the proving thread's core through the library's host-side
+// engine (sp_host_commit_small / sp_host_zk_ahead_*, csrc/host_commit.hip — the default) or on the GPU (sp_msm_indexed;
+// SPARTAN_SMALL_MSM=device). Byte-identical proofs either way.
 bool small_msm_on_host();
 void small_msm_set_mode(int mode);  // 0 device, 1 host, -1 environment (tests)
-bool small_msm_rows(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, size_t rows, uint8_t* out);
-struct HostPt { uint64_t w[16]; };  // an extended point (csrc/curve.hpp: Pt), opaque to the driver
-// one row, left as a point: the tape-only half of a commitment, computed ahead of time (ZkAhead in prover.cc)
-bool small_msm_point(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, HostPt* out);
-// row r = sum_k scalars[r][k] * P[idx[k]] + *addend[r] (a null addend adds nothing), encoded
-bool small_msm_rows_plus(const sp_gens* g, const uint32_t* idx, size_t cols, const Fq* scalars, size_t rows, const HostPt* const* addend, uint8_t* out);
-int small_msm_probe(const uint8_t* compressed, size_t npts, const uint64_t* scalars, size_t rows, uint8_t* out);
 
 }  // namespace spz

@@ -117,13 +117,9 @@ DevIndex& DevIndex::operator=(DevIndex&& o) noexcept {
   if (this != &o) { sp_index_free(h); c = o.c; h = o.h; o.h = nullptr; }
   return *this;
 }
-GensStream::~GensStream() {
-  if (g) small_msm_forget(g);
-  sp_gens_free(g);
-}
+GensStream::~GensStream() { sp_gens_free(g); }
 GensStream& GensStream::operator=(GensStream&& o) noexcept {
   if (this != &o) {
-    if (g) small_msm_forget(g);
     sp_gens_free(g); c = o.c; g = o.g; compressed = std::move(o.compressed); o.g = nullptr;
   }
   return *this;
@@ -147,7 +143,6 @@ GensStream::GensStream(sp_ctx* c_, const char* label, size_t npoints) : c(c_) {
   shake.squeeze(uniform.data(), uniform.size());
   compressed.resize(32 * npoints);
   SPX(sp_gens_from_uniform(c, uniform.data(), npoints, compressed.data(), &g));  // from_uniform_bytes on the device (:21-30)
-  small_msm_register(g, compressed);
 }
 MultiCommitGens GensStream::multi_commit_gens(size_t n) const {
   REQUIRE(n + 1 <= sp_gens_len(g));
@@ -313,9 +308,9 @@ static CP to_cp(const uint8_t* p) { CP c; memcpy(c.data(), p, 32); return c; }
 static std::vector<CP> msm_rows(sp_ctx* c, const sp_gens* g, const std::vector<uint32_t>& idx, const FqVec& scalars, size_t rows) {
   REQUIRE(scalars.size() == rows * idx.size());
   std::vector<uint8_t> out(32 * rows);
-  // few-term commitments: on this core unless told otherwise (small_msm.cc)
-  if (!(idx.size() <= 8 && small_msm_on_host() && small_msm_rows(g, idx.data(), idx.size(), scalars.data(), rows, out.data())))
-    SPX(sp_msm_indexed(c, g, idx.data(), idx.size(), U(scalars), rows, out.data()));
+  // few-term commitments: on this core unless told otherwise (the library's host-side engine, csrc/host_commit.hip)
+  if (idx.size() <= 8 && small_msm_on_host()) SPX(sp_host_commit_small(g, idx.data(), idx.size(), U(scalars), rows, nullptr, out.data()));
+  else SPX(sp_msm_indexed(c, g, idx.data(), idx.size(), U(scalars), rows, out.data()));
   std::vector<CP> r(rows);
   for (size_t i = 0; i < rows; i++) r[i] = to_cp(&out[32 * i]);
   return r;
@@ -455,25 +450,39 @@ static ProductProof product_prove(sp_ctx* c, const MultiCommitGens& g, Transcrip
   return p;
 }
 
-// The tape-only halves of a ZK sum-check's commitments, computed ahead of the rounds by a helper thread while the proving
-// thread is in its first evaluation: the DotProductProof's delta = commit(d_j, r_delta_j) is complete (nothing but the tape
-// enters it), and of comm_eval, beta and comm_poly the blind terms blinds_evals[j]*h, r_beta_j*h, blinds_poly[j]*h_n are.
-// The tape is read in the reference's order: inside the round loop nothing but DotProductProof::prove draws from it
-// (d_vec, r_delta, r_beta: nizk/mod.rs:330-334), so drawing the rounds' values one after the other up front is the same stream.
+// Where the few-term commitments run (libspartan.hpp)
+static std::atomic<int> g_small_mode{-1};  // -1: read SPARTAN_SMALL_MSM on first use; 0: device; 1: host
+void small_msm_set_mode(int mode) { g_small_mode.store(mode, std::memory_order_relaxed); }
+bool small_msm_on_host() {
+  int m = g_small_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("SPARTAN_SMALL_MSM");
+    m = (e && strcmp(e, "device") == 0) ? 0 : 1;
+    g_small_mode.store(m, std::memory_order_relaxed);
+  }
+  return m == 1;
+}
+
+// The tape-only halves of a ZK sum-check's commitments, computed ahead of the rounds by the library's helper thread
+// (sp_host_zk_ahead_*, csrc/host_commit.hip) while the proving thread is in its first evaluation: the DotProductProof's
+// delta = commit(d_j, r_delta_j) is complete (nothing but the tape enters it), and of comm_eval, beta and comm_poly the blind
+// terms blinds_evals[j]*h, r_beta_j*h, blinds_poly[j]*h_n are. The tape is read in the reference's order: inside the round loop
+// nothing but DotProductProof::prove draws from it (d_vec, r_delta, r_beta: nizk/mod.rs:330-334), so drawing the rounds'
+// values one after the other up front is the same stream.
 struct ZkAhead {
   std::vector<FqVec> d;
   FqVec r_delta, r_beta;
-  std::vector<CP> delta;
-  std::vector<HostPt> be_h, rb_h, bp_hn;
-  std::atomic<size_t> done{0};
-  std::atomic<bool> failed{false};
-  std::thread th;
-  ~ZkAhead() { if (th.joinable()) th.join(); }
-  void wait(size_t j) const {
-    while (done.load(std::memory_order_acquire) <= j) {
-      if (failed.load(std::memory_order_acquire)) throw Error("zk_sumcheck: look-ahead commitment failed");
-      __builtin_ia32_pause();
+  sp_zk_ahead* h = nullptr;
+  struct Round { CP delta; sp_host_point be_h, rb_h, bp_hn; };
+  std::vector<Round> got;      // rounds fetched so far (they complete in order)
+  ~ZkAhead() { sp_host_zk_ahead_free(h); }
+  const Round& wait(size_t j) {
+    while (got.size() <= j) {
+      Round r;
+      SPX(sp_host_zk_ahead_wait(h, got.size(), r.delta.data(), &r.be_h, &r.rb_h, &r.bp_hn));
+      got.push_back(r);
     }
+    return got[j];
   }
 };
 
@@ -496,7 +505,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
   size_t nn = gn.n(), W = idx_u.size();
   // The round's 2..5-term commitments: on this core (small_msm.cc) while the device binds and evaluates, or — with
   // SPARTAN_SMALL_MSM=device — two launches per round on the device
-  const bool on_host = small_msm_on_host() && small_msm_has(gn.g) && gn.g == g1.g;
+  const bool on_host = small_msm_on_host() && gn.g == g1.g;
   ZkAhead ahead;
   if (on_host) {
     ahead.d.resize(num_rounds); ahead.r_delta.resize(num_rounds); ahead.r_beta.resize(num_rounds);
@@ -505,31 +514,17 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
       ahead.r_delta[j] = tape.random_scalar("r_delta");
       ahead.r_beta[j] = tape.random_scalar("r_beta");
     }
-    ahead.delta.resize(num_rounds); ahead.be_h.resize(num_rounds); ahead.rb_h.resize(num_rounds); ahead.bp_hn.resize(num_rounds);
-    ahead.th = std::thread([&ahead, &blinds_poly, &blinds_evals, &idx_u, &gn, &g1, nn, W, num_rounds]() {
-      try {
-        const uint32_t ih1 = g1.h, ihn = gn.h;
-        for (size_t j = 0; j < num_rounds; j++) {
-          bool ok = small_msm_point(gn.g, &ihn, 1, &blinds_poly[j], &ahead.bp_hn[j]) && small_msm_point(gn.g, &ih1, 1, &blinds_evals[j], &ahead.be_h[j]);
-          FqVec row(W, fq_zero());
-          for (size_t k = 0; k < nn; k++) row[k] = ahead.d[j][k];
-          row[nn] = ahead.r_delta[j];
-          ok = ok && small_msm_rows(gn.g, idx_u.data(), W, row.data(), 1, ahead.delta[j].data());
-          ok = ok && small_msm_point(gn.g, &ih1, 1, &ahead.r_beta[j], &ahead.rb_h[j]);
-          if (!ok) { ahead.failed.store(true, std::memory_order_release); return; }
-          ahead.done.store(j + 1, std::memory_order_release);
-        }
-      } catch (...) {
-        ahead.failed.store(true, std::memory_order_release);
-      }
-    });
+    FqVec dflat;
+    for (auto& v : ahead.d) dflat.insert(dflat.end(), v.begin(), v.end());
+    SPX(sp_host_zk_ahead_begin(gn.g, idx_u.data(), W, nn, num_rounds, U(blinds_poly), U(blinds_evals), U(dflat), U(ahead.r_delta), U(ahead.r_beta), &ahead.h));
+    ahead.got.reserve(num_rounds);  // references into it are handed out
   }
   // rows of scalars over idx_u -> encoded commitments; addend[r] (host mode): a point computed ahead
-  auto commit_rows = [&](const FqVec& rows, size_t nrows, const HostPt* const* addend) {
+  auto commit_rows = [&](const FqVec& rows, size_t nrows, const sp_host_point* const* addend) {
     std::vector<CP> cm(nrows);
     if (on_host) {
       std::vector<uint8_t> o(32 * nrows);
-      REQUIRE(small_msm_rows_plus(gn.g, idx_u.data(), W, rows.data(), nrows, addend, o.data()));
+      SPX(sp_host_commit_small(gn.g, idx_u.data(), W, U(rows), nrows, addend, o.data()));
       for (size_t k = 0; k < nrows; k++) cm[k] = to_cp(&o[32 * k]);
       return cm;
     }
@@ -554,8 +549,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     FqVec rows0(2 * W, fq_zero());
     rows0[nn + 1] = claim_per_round; rows0[nn + 2] = blind_claim;
     poly_row(rows0, 1, poly, 0);
-    if (on_host) ahead.wait(0);
-    const HostPt* add0[2] = {nullptr, on_host ? &ahead.bp_hn[0] : nullptr};
+    const sp_host_point* add0[2] = {nullptr, on_host ? &ahead.wait(0).bp_hn : nullptr};
     std::vector<CP> cm = commit_rows(rows0, 2, add0);
     comm_claim_per_round = cm[0];
     comm_poly = cm[1];
@@ -586,12 +580,12 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         SPX(sp_table_bind_top(c, tabs.data(), tabs.size(), U(r_j)));
       }
       try {
-        ahead.wait(j);
+        const ZkAhead::Round& aj = ahead.wait(j);
         FqVec row(W, fq_zero());
         row[nn + 1] = eval;
-        const HostPt* add[1] = {&ahead.be_h[j]};
+        const sp_host_point* add[1] = {&aj.be_h};
         comm_eval = commit_rows(row, 1, add)[0];
-        delta = ahead.delta[j];
+        delta = aj.delta;
       } catch (...) { if (pending) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
     } else {
       FqVec rows1(2 * W, fq_zero());
@@ -635,7 +629,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         FqVec rows2(2 * W, fq_zero());
         rows2[nn + 1] = target; rows2[nn + 2] = blind;
         rows2[W + nn + 1] = dp;
-        const HostPt* add2[2] = {nullptr, &ahead.rb_h[j]};
+        const sp_host_point* add2[2] = {nullptr, &ahead.wait(j).rb_h};
         cm2 = commit_rows(rows2, 2, add2);
       } catch (...) { if (pending) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
       if (pending) SPX(sp_sumcheck_bind_eval_collect(c, ev));
@@ -644,8 +638,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         next_poly = make_poly(ev, eval);
         FqVec row3(W, fq_zero());
         poly_row(row3, 0, next_poly, j + 1);
-        ahead.wait(j + 1);
-        const HostPt* add3[1] = {&ahead.bp_hn[j + 1]};
+        const sp_host_point* add3[1] = {&ahead.wait(j + 1).bp_hn};
         cm2.push_back(commit_rows(row3, 1, add3)[0]);
       }
     } else {
@@ -916,6 +909,8 @@ NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_gi
                  const Fq* tape_seed, ProveTimes* tm, const sp_table* vars_resident) {  // lib.rs:501-546
   double t0 = now_s();
   REQUIRE(!inst.digest.empty());  // lib.rs:514 absorbs inst.digest: an empty one would leave the proof unbound to the shape
+  Fq shared_seed;  // lock-step ranks of a sharded proof must share one tape: rank 0 draws it (shard.cc)
+  if (!tape_seed && commit_shard_shared_seed(ctx.h, &shared_seed)) tape_seed = &shared_seed;
   RandomTape tape = tape_seed ? RandomTape("proof", *tape_seed) : RandomTape("proof");  // random.rs:11-18
   std::function<void()> prefix = [&]() {
     t.append_protocol_name("Spartan NIZK proof");

@@ -70,6 +70,7 @@ void hip_ok(hipError_t e, const char* what) {
 struct ShardState {
   int mode = 0;  // 0 none, 1 callback, 2 rccl, 3 virtual
   int rank = 0, world = 1;
+  int dev = 0;  // the GPU of the owning context: every HIP/RCCL object of this state is created with it current
   CommitGatherFn gather = nullptr;
   void* user = nullptr;
   ncclComm_p comm = nullptr;
@@ -83,6 +84,7 @@ std::mutex g_mu;
 std::map<sp_ctx*, ShardState> g_state;
 
 void release(ShardState& s) {
+  if (s.comm || s.dbuf || s.stream) (void)hipSetDevice(s.dev);
   for (sp_ctx* v : s.vctx) sp_ctx_destroy(v);
   s.vctx.clear();
   if (s.comm && rccl().CommDestroy) (void)rccl().CommDestroy(s.comm);
@@ -127,8 +129,10 @@ void set_commit_shard_rccl(Ctx& c, int rank, int world, const uint8_t unique_id[
   need_rccl();
   ShardState s;
   s.mode = 2; s.rank = rank; s.world = world;
+  s.dev = sp_ctx_device(c.h);
   ncclUniqueId_t id;
   memcpy(id.internal, unique_id, 128);
+  hip_ok(hipSetDevice(s.dev), "hipSetDevice");  // the communicator and its stream belong to the context's GPU, whatever the calling thread had current
   hip_ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
   try {
     nccl_ok(rccl().CommInitRank(&s.comm, world, id, rank), "ncclCommInitRank");
@@ -144,8 +148,7 @@ void set_commit_shard_virtual(Ctx& c, int nshards) {
   if (nshards <= 1) return;
   ShardState s;
   s.mode = 3; s.rank = 0; s.world = nshards;
-  int dev = 0;
-  hip_ok(hipGetDevice(&dev), "hipGetDevice");
+  int dev = s.dev = sp_ctx_device(c.h);
   for (int k = 1; k < nshards; k++) {
     sp_ctx* v = nullptr;
     if (sp_ctx_create(dev, &v) != SP_OK) { release(s); throw Error("set_commit_shard_virtual: sp_ctx_create failed"); }
@@ -163,6 +166,45 @@ ShardStats commit_shard_stats(Ctx& c, bool reset) {
   return r;
 }
 
+// A RandomTape seed shared by the lock-step ranks of a sharded proof. With the production setting (no caller seed) every
+// rank would seed its tape from its own OS entropy: each would blind its row slice with its own tape, the gathered
+// commitment would mix blinds of different tapes and the ranks' transcripts would diverge. So rank 0 draws the seed and the
+// transport that moves the commitments moves it to the others (callback: one gather; RCCL: one all-gather of 32 bytes).
+// The seed fixes every blind of the proof: it is secret, single-use, and never leaves the node's ranks.
+// Returns false when no multi-rank transport is configured (single GPU, virtual shards): the caller seeds as usual.
+bool commit_shard_shared_seed(sp_ctx* c, Fq* seed) {
+  ShardState* sp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_state.find(c);
+    if (it == g_state.end() || (it->second.mode != 1 && it->second.mode != 2) || it->second.world <= 1) return false;
+    sp = &it->second;
+  }
+  ShardState& s = *sp;
+  size_t W = (size_t)s.world;
+  std::vector<uint8_t> buf(32 * W, 0);
+  if (s.rank == 0) { Fq x = RandomTape::os_random_scalar(); memcpy(buf.data(), x.l, 32); }
+  if (s.mode == 1) {
+    if (s.gather(s.user, buf.data(), 32 * W, 32 * (size_t)s.rank, 32) != 0) throw Error("commit shard gather failed (tape seed)");
+  } else {
+    hip_ok(hipSetDevice(s.dev), "hipSetDevice");
+    size_t need = 32 + 32 * W;
+    if (s.dbuf_bytes < need) {
+      if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
+      s.dbuf = nullptr;
+      hip_ok(hipMalloc((void**)&s.dbuf, need), "hipMalloc");
+      s.dbuf_bytes = need;
+    }
+    hip_ok(hipMemcpyAsync(s.dbuf, buf.data() + 32 * (size_t)s.rank, 32, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+    nccl_ok(rccl().AllGather(s.dbuf, s.dbuf + 32, 32, 1 /*ncclUint8*/, s.comm, s.stream), "ncclAllGather");
+    hip_ok(hipMemcpyAsync(buf.data(), s.dbuf + 32, 32 * W, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+    hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+  }
+  memcpy(seed->l, buf.data(), 32);  // rank 0's draw
+  s.stats.gathers++; s.stats.bytes += 32 * W;
+  return true;
+}
+
 // DensePolynomial::commit_inner over the shards of the context; returns false when the commitment is not sharded (no
 // sharding configured, or too few rows per shard) and the caller takes the single-GPU path.
 bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,
@@ -172,7 +214,7 @@ bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_state.find(c);
     if (it == g_state.end() || it->second.mode == 0) return false;
-    sp = &it->second;  // entries are only removed by the owning thread (set_* / ~Ctx)
+    sp = &it->second;  // entries are only removed by the owning thread (set_* / ~Ctx); shard configuration and sharded proving of one context are single-threaded, like the context itself
   }
   ShardState& s = *sp;
   size_t W = (size_t)s.world;
@@ -209,6 +251,7 @@ bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx
   } else {
     // RCCL: all-gather of the compressed commitments on device buffers (32*per bytes from each rank, rank order)
     size_t need = 32 * per + 32 * Ls;
+    hip_ok(hipSetDevice(s.dev), "hipSetDevice");
     if (s.dbuf_bytes < need) {
       if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
       s.dbuf = nullptr;

@@ -81,6 +81,16 @@ class Strobe128 {  // STROBE v1.0.2, the subset Merlin uses (AD, meta-AD, PRF), 
   void meta_ad(const uint8_t* d, size_t n, bool more) { begin_op(FLAG_M | FLAG_A, more); absorb(d, n); }
   void ad(const uint8_t* d, size_t n, bool more) { begin_op(FLAG_A, more); absorb(d, n); }
   void prf(uint8_t* out, size_t n, bool more) { begin_op(FLAG_I | FLAG_A | FLAG_C, more); squeeze(out, n); }
+  // The whole state of a merlin::Transcript is its Strobe128 { state: [u8; 200], pos, pos_begin, cur_flags } (merlin 3.0.0,
+  // src/strobe.rs): 203 bytes. Exchanging them is how a caller-owned `&mut Transcript` (src/lib.rs:339-347) is continued by
+  // the library and handed back (spz_snark_prove_t / spz_nizk_prove_t, host_capi.cc).
+  static constexpr size_t STATE_BYTES = 203;
+  struct FromState {};
+  Strobe128(FromState, const uint8_t in[STATE_BYTES]) : pos_(in[200]), pos_begin_(in[201]), cur_flags_(in[202]) {
+    memcpy(st_, in, 200);
+    if (pos_ >= R || pos_begin_ > R) throw std::runtime_error("transcript state: position out of range");
+  }
+  void export_state(uint8_t out[STATE_BYTES]) const { memcpy(out, st_, 200); out[200] = pos_; out[201] = pos_begin_; out[202] = cur_flags_; }
 
  private:
   static constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, FLAG_K = 32;
@@ -139,6 +149,10 @@ class Strobe128 {  // STROBE v1.0.2, the subset Merlin uses (AD, meta-AD, PRF), 
 class Transcript {  // merlin::Transcript + libspartan's ProofTranscript trait
  public:
   explicit Transcript(const char* label) : s_("Merlin v1.0") { append_message("dom-sep", (const uint8_t*)label, strlen(label)); }
+  static constexpr size_t STATE_BYTES = Strobe128::STATE_BYTES;
+  struct FromState {};
+  Transcript(FromState, const uint8_t state[STATE_BYTES]) : s_(Strobe128::FromState(), state) {}  // continue a caller-owned transcript
+  void export_state(uint8_t out[STATE_BYTES]) const { s_.export_state(out); }
   void append_message(const char* label, const uint8_t* msg, size_t n) {
     uint8_t len[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
     s_.meta_ad((const uint8_t*)label, strlen(label), false);

@@ -10,7 +10,8 @@ if not os.path.exists(HOST_PATH):
 ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 H = ctypes.CDLL(HOST_PATH)
 for f in ("spz_ctx_new", "spz_instance_new", "spz_instance_synthetic", "spz_snark_gens_new", "spz_nizk_gens_new", "spz_snark_encode",
-          "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw", "spz_vars_assignment_new", "spz_snark_prove_resident", "spz_nizk_prove_resident"):
+          "spz_snark_prove", "spz_nizk_prove", "spz_ctx_raw", "spz_vars_assignment_new", "spz_snark_prove_resident", "spz_nizk_prove_resident",
+          "spz_snark_prove_t", "spz_nizk_prove_t"):
     getattr(H, f).restype = vp
 for f in ("spz_proof_bytes", "spz_encode_comm", "spz_snark_gens_stream", "spz_merlin_script", "spz_snark_gens_bincode", "spz_commitment_bincode", "spz_decommitment_bincode"):
     getattr(H, f).restype = sz
@@ -106,6 +107,11 @@ class SNARKGens:
         """signed window width of the fixed-base tables of generator stream `which` (0: gens_r1cs_sat, 1: gens_r1cs_eval)"""
         return int(H.spz_snark_gens_window_bits(self.h, ctypes.c_int(which)))
 
+    def table_bytes(self, which):
+        """HBM held by the window tables of generator stream `which`"""
+        H.spz_snark_gens_table_bytes.restype = sz
+        return int(H.spz_snark_gens_table_bytes(self.h, ctypes.c_int(which)))
+
     def serialize(self):
         n = H.spz_snark_gens_bincode(self.h, None, sz(0)); b = (ctypes.c_uint8 * n)()
         H.spz_snark_gens_bincode(self.h, b, sz(n))
@@ -170,7 +176,28 @@ class SNARK:
         return _proof_bytes(p)
 
 
+    @staticmethod
+    def prove_t(ctx, inst, enc, vars_, inputs, gens, transcript_state, tape_seed):
+        """SNARK::prove on a caller-owned transcript (lib.rs:339-347): `transcript_state` is a 203-byte ctypes array holding the
+        merlin transcript (Strobe128 state, pos, pos_begin, cur_flags); it is continued by the proof and left in the state the
+        proof ends in. Returns the proof bytes."""
+        tm = (ctypes.c_double * 10)()
+        res = isinstance(vars_, VarsAssignment)
+        p = _chk(H.spz_snark_prove_t(ctx.h, inst.h, gens.h, enc.h, vars_.h if res else None, None if res else vars_, sz(0 if res else len(vars_) // 4),
+                                     inputs, sz(inst.num_inputs), transcript_state, tape_seed, tm), "SNARK::prove")
+        return _proof_bytes(p)
+
+
 class NIZK:
+    @staticmethod
+    def prove_t(ctx, inst, vars_, inputs, gens, transcript_state, tape_seed):
+        """NIZK::prove on a caller-owned transcript (lib.rs:501-509); see SNARK.prove_t"""
+        tm = (ctypes.c_double * 10)()
+        res = isinstance(vars_, VarsAssignment)
+        p = _chk(H.spz_nizk_prove_t(ctx.h, inst.h, gens.h, vars_.h if res else None, None if res else vars_, sz(0 if res else len(vars_) // 4),
+                                    inputs, sz(inst.num_inputs), transcript_state, tape_seed, tm), "NIZK::prove")
+        return _proof_bytes(p)
+
     @staticmethod
     def prove(ctx, inst, vars_, inputs, gens, transcript_label, tape_seed, times=None):
         tm = (ctypes.c_double * 10)()

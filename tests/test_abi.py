@@ -62,7 +62,7 @@ def test_rust_binding_matches_header():
             assert rt.count("*") == ctype.count("*"), (name, ctype, rt)             # pointer depth
             if ctype.startswith("const ") and "*" in ctype:
                 assert "*const" in rt, (name, ctype, rt)                              # constness of the pointee
-        assert rret == {"int32_t": "i32", "size_t": "usize", "int": "c_int", "const char*": "*const c_char", "void": ""}[ret], name
+        assert rret == {"int32_t": "i32", "uint64_t": "u64", "size_t": "usize", "int": "c_int", "const char*": "*const c_char", "void": ""}[ret], name
     # the generator is idempotent: the committed file is what it emits today
     committed = src
     gen.emit()

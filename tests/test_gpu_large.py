@@ -327,89 +327,6 @@ def test_witness_sized_commit_every_row_matches_oracle(ctx, orc):
     t.free(); g.free()
 
 
-@pytest.mark.parametrize("ell,first_eval", [(9, True), (9, False), (6, True), (1, True), (2, False)])
-def test_resident_sumcheck_session_matches_reference_arithmetic(ctx, ell, first_eval):
-    """sp_sumcheck_session_* (session.hip): all remaining rounds of prove_cubic_batched (sumcheck.rs:287-419) inside one
-    resident kernel, the challenge and the evaluations travelling through mailboxes. Every round's evaluations, the table
-    contents after an early abort, and the final claims are compared with the reference arithmetic in Python; 3 'par'
-    instances share their C table, 2 'seq' instances own theirs. 2^9 = the largest session (tables held in LDS)."""
-    from spartan_amd import capi
-    n = 1 << ell
-    rng = random.Random(7000 + ell)
-    npar, nseq = 3, 2
-    ni = npar + nseq
-    A = [fast_scalars(rng, n) for _ in range(ni)]
-    B = [fast_scalars(rng, n) for _ in range(ni)]
-    Cpar = fast_scalars(rng, n)
-    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
-
-    def tables():
-        tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
-        tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
-        hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
-        return tA, tB, tCpar, tCseq, (vp * ni)(*[t.h for t in tA]), (vp * ni)(*[t.h for t in tB]), hC
-    tA, tB, tCpar, tCseq, hA, hB, hC = tables()
-    out = (ctypes.c_uint64 * (12 * ni))()
-    sess = vp()
-    assert capi.lib.sp_sumcheck_session_max_len() == 512
-    cA, cB, cCpar, cCseq = [list(a) for a in A], [list(b) for b in B], list(Cpar), [list(c) for c in Cseq]
-    cC = lambda: [cCpar] * npar + cCseq
-    if first_eval:
-        assert capi.lib.sp_sumcheck_session_begin(ctx.h, hA, hB, hC, sz(ni), ctypes.c_int(1), out, ctypes.byref(sess)) == 0
-        got = from_mont_bulk(out, 3 * ni)
-        for k in range(ni):
-            assert got[3 * k:3 * k + 3] == cubic_evals(cA[k], cB[k], cC()[k]), k
-    else:
-        assert capi.lib.sp_sumcheck_session_begin(ctx.h, hA, hB, hC, sz(ni), ctypes.c_int(0), None, ctypes.byref(sess)) == 0
-    length = n
-    while length >= 4:
-        r = rng.getrandbits(251)
-        cA = [bind(a, r) for a in cA]; cB = [bind(b, r) for b in cB]; cCpar = bind(cCpar, r); cCseq = [bind(c, r) for c in cCseq]
-        assert capi.lib.sp_sumcheck_session_round(sess, fq1(r), out) == 0
-        length //= 2
-        got = from_mont_bulk(out, 3 * ni)
-        for k in range(ni):
-            assert got[3 * k:3 * k + 3] == cubic_evals(cA[k], cB[k], cC()[k]), (length, k)
-        assert len(tA[0]) == length and len(tCpar) == length
-    r = rng.getrandbits(250)
-    heads = (ctypes.c_uint64 * (4 * (2 * ni + 1 + nseq)))()
-    assert capi.lib.sp_sumcheck_session_finish(sess, fq1(r), heads) == 0
-    got = from_mont_bulk(heads, 2 * ni + 1 + nseq)
-    fin = lambda T: (T[0] + r * (T[1] - T[0])) % Q
-    want = []
-    for k in range(ni):
-        want += [fin(cA[k]), fin(cB[k])]
-    want += [fin(cCpar)] + [fin(c) for c in cCseq]
-    assert got == want
-    # the table objects describe the bound tables (length 1, current buffer) — what the next protocol step reads
-    assert all(len(t) == 1 for t in tA + tB + tCseq + [tCpar])
-    assert from_mont_bulk(tCpar.download(1), 1) == [fin(cCpar)] and from_mont_bulk(tA[3].download(1), 1) == [fin(cA[3])]
-    assert from_mont_bulk(tCseq[1].download(1), 1) == [fin(cCseq[1])]
-    for t in tA + tB + tCseq + [tCpar]:
-        t.free()
-    if ell < 6:
-        return
-    # abort after two rounds: the tables hold the state after the last completed round, and the context keeps working
-    tA, tB, tCpar, tCseq, hA, hB, hC = tables()
-    assert capi.lib.sp_sumcheck_session_begin(ctx.h, hA, hB, hC, sz(ni), ctypes.c_int(0), None, ctypes.byref(sess)) == 0
-    cA, cCpar, cCseq = [list(a) for a in A], list(Cpar), [list(c) for c in Cseq]
-    for _ in range(3):
-        r = rng.getrandbits(251)
-        cA = [bind(a, r) for a in cA]; cCpar = bind(cCpar, r); cCseq = [bind(c, r) for c in cCseq]
-        assert capi.lib.sp_sumcheck_session_round(sess, fq1(r), out) == 0
-    capi.lib.sp_sumcheck_session_abort(sess)
-    ln = n // 8
-    assert len(tCpar) == ln and from_mont_bulk(tCpar.download(ln), ln) == cCpar
-    assert from_mont_bulk(tA[1].download(ln), ln) == cA[1] and from_mont_bulk(tCseq[0].download(ln), ln) == cCseq[0]
-    # and the launch-per-round path continues from there with the same result as the session would have given
-    r = rng.getrandbits(251)
-    assert capi.lib.sp_sumcheck_bind_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(r), out) == 0
-    cA = [bind(a, r) for a in cA]
-    assert from_mont_bulk(tA[2].download(ln // 2), ln // 2) == cA[2]
-    for t in tA + tB + tCseq + [tCpar]:
-        t.free()
-
-
 @pytest.mark.parametrize("ell", [2, 3, 4, 5, 9, 13, 15])
 def test_two_rounds_per_launch_match_reference_arithmetic(ctx, ell):
     """sp_sumcheck_eval_coeffs_batched / sp_sumcheck_bind2_eval_batched (spark.hip k_cubic_bind2_eval): two rounds of

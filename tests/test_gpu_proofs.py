@@ -88,6 +88,56 @@ def test_snark_encode_and_prove_bytes_match_oracle(P, ctx, orc, s, seed):
     enc.free(); gens.free(); inst.free()
 
 
+def _caller_transcript_state(lib, fn):
+    """a transcript that is NOT fresh: Transcript::new(b"caller protocol") that already absorbed two messages and drew a challenge"""
+    from tests.test_host_transcript import _state
+    return _state(lib, fn, b"caller protocol", [(0, b"session", b"\x01\x02\x03 some earlier statement"), (2, b"epoch", (77).to_bytes(8, "little")),
+                                               (1, b"earlier-challenge", 32)])
+
+
+@pytest.mark.parametrize("s,seed", [(6, 3), (12, 4)])
+def test_prove_continues_a_caller_owned_transcript(P, ctx, orc, s, seed):
+    """SNARK::prove / NIZK::prove take `transcript: &mut Transcript` (src/lib.rs:339-347, 501-509): the caller may have used it
+    before. spz_snark_prove_t / spz_nizk_prove_t continue the 203-byte merlin state they are handed and give it back; the
+    oracle proves on the same pre-used transcript. Same proof bytes, same transcript state afterwards (so whatever the caller
+    draws next agrees too), and the oracle's verifier accepts on its own copy of the pre-used transcript."""
+    N = 1 << s
+    orc.orc_snark_prove_t.restype = vp; orc.orc_nizk_prove_t.restype = vp
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=seed)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
+    tape = P.seed_scalar(b"tape", 40 + seed)
+    # SNARK
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    st_h, st_o, st_v = _caller_transcript_state(P.H, "spz_merlin_state"), _caller_transcript_state(orc, "orc_merlin_state"), _caller_transcript_state(orc, "orc_merlin_state")
+    assert bytes(st_h) == bytes(st_o)
+    got = P.SNARK.prove_t(ctx, inst, enc, inst.vars, inst.inputs, gens, st_h, tape)
+    op = vp(orc.orc_snark_prove_t(oi, og, oe, st_o, tape))
+    assert got == oracle_bytes(orc, op)
+    assert bytes(st_h) == bytes(st_o)                      # the caller's transcript after the proof
+    assert orc.orc_snark_verify_t(op, oi, og, oe, st_v) == 1 and bytes(st_v) == bytes(st_o)   # prover and verifier transcripts stay in step
+    fresh = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"caller protocol", tape)
+    assert fresh != got                                     # the earlier messages are bound into the proof
+    st2 = _caller_transcript_state(P.H, "spz_merlin_state")
+    va = P.VarsAssignment(ctx, inst.vars)
+    assert P.SNARK.prove_t(ctx, inst, enc, va, inst.inputs, gens, st2, tape) == got and bytes(st2) == bytes(st_h)   # resident assignment: same
+    va.free()
+    orc.orc_proof_free(op); orc.orc_encode_free(oe); orc.orc_snark_gens_free(og)
+    enc.free(); gens.free()
+    # NIZK
+    inst.set_digest(b"shape-digest")
+    ng = P.NIZKGens(ctx, N, N, 10)
+    ong = vp(orc.orc_nizk_gens_new(sz(N), sz(N), sz(10)))
+    st_h, st_o = _caller_transcript_state(P.H, "spz_merlin_state"), _caller_transcript_state(orc, "orc_merlin_state")
+    got = P.NIZK.prove_t(ctx, inst, inst.vars, inst.inputs, ng, st_h, tape)
+    op = vp(orc.orc_nizk_prove_t(oi, ong, b"shape-digest", sz(12), st_o, tape))
+    assert got == oracle_bytes(orc, op) and bytes(st_h) == bytes(st_o)
+    orc.orc_proof_free(op); orc.orc_nizk_gens_free(ong); orc.orc_instance_free(oi)
+    ng.free(); inst.free()
+
+
 def test_generator_streams_match_oracle(P, ctx, orc):
     gens = P.SNARKGens(ctx, 64, 64, 10, 64)
     sat = gens.stream(0); ev = gens.stream(1)

@@ -124,16 +124,17 @@ def test_pt10_add_and_encode_match_oracle(hc, orc):
 
 
 def test_small_commitments_on_the_host_core_match_oracle(orc):
-    """small_msm.cc: the few-term commitments of the Sigma protocols, computed on the proving thread's core from signed
-    10-bit window tables — same recoding, same point arithmetic as the device tables (no device needed)"""
+    """sp_host_commit_* (csrc/host_commit.hip): the few-term commitments of the Sigma protocols, computed on the calling
+    thread's core from signed 10-bit window tables — same recoding, same point arithmetic as the device tables (no device
+    needed: this is the device-free entry point of the same code)"""
     import ctypes, random
-    from spartan_amd import prover
+    from spartan_amd import capi
     rng = random.Random(2024)
     g = gens_bytes(orc, 4)  # 5 points
     for rows, kind in [(3, "uniform"), (2, "edge"), (4, "sparse"), (2, "small")]:
         S = rand_scalars(rng, rows * 5, kind)
         got = (ctypes.c_uint8 * (32 * rows))()
-        assert prover.H.spz_small_msm_probe(g, sz(5), mont_array(S), sz(rows), got) == 0
+        assert capi.lib.sp_host_commit_probe(g, sz(5), mont_array(S), sz(rows), got) == 0
         want = (ctypes.c_uint8 * 32)()
         for r in range(rows):
             assert orc.orc_pt_msm(mont_array(S[r * 5:(r + 1) * 5]), g, sz(5), want) == 1

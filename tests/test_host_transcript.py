@@ -59,3 +59,36 @@ def test_seed_scalar_matches_oracle(H, orc):
         H.spz_seed_scalar(b"tape", ctypes.c_uint64(seed), a)
         orc.orc_seed_scalar(b"tape", ctypes.c_uint64(seed), b)
         assert list(a) == list(b)
+
+
+def _state(lib, fn, tlabel, ops):
+    n = len(ops)
+    kinds = (ctypes.c_int * n)(*[o[0] for o in ops])
+    labels = (ctypes.c_char_p * n)(*[o[1] for o in ops])
+    bufs = [ctypes.create_string_buffer(o[2], max(len(o[2]), 1)) if o[0] != 1 else None for o in ops]
+    datas = (ctypes.POINTER(ctypes.c_uint8) * n)(*[ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)) if b is not None else None for b in bufs])
+    lens = (sz * n)(*[len(o[2]) if o[0] != 1 else o[2] for o in ops])
+    out = (ctypes.c_uint8 * 203)()
+    getattr(lib, fn)(tlabel, sz(n), kinds, labels, datas, lens, out)
+    return out
+
+
+def test_transcript_state_export_import_matches_oracle(H, orc):
+    """The 203 bytes that ARE a merlin transcript (Strobe128 state, pos, pos_begin, cur_flags): what spz_snark_prove_t /
+    spz_nizk_prove_t take and return to continue a caller-owned `&mut Transcript` (src/lib.rs:339-347). Export after a script
+    equals the oracle's; a transcript continued from the exported state draws what the uninterrupted transcript draws."""
+    rng = random.Random(5)
+    for trial in range(10):
+        ops = []
+        for _ in range(rng.randrange(1, 12)):
+            label = bytes(rng.randrange(97, 123) for _ in range(rng.randrange(1, 12)))
+            ops.append(rng.choice([(0, label, bytes(rng.randrange(256) for _ in range(rng.choice([0, 5, 32, 166, 300])))), (1, label, rng.choice([16, 64])),
+                                   (2, label, rng.randrange(2**64).to_bytes(8, "little"))]))
+        a, b = _state(H, "spz_merlin_state", b"caller protocol", ops), _state(orc, "orc_merlin_state", b"caller protocol", ops)
+        assert bytes(a) == bytes(b)
+        whole = _script(H, "spz_merlin_script", b"caller protocol", ops + [(1, b"next", 64)])
+        tail = whole[-64:]
+        oa, ob = (ctypes.c_uint8 * 64)(), (ctypes.c_uint8 * 64)()
+        H.spz_merlin_challenge_from_state(a, b"next", oa, sz(64))
+        orc.orc_merlin_challenge_from_state(b, b"next", ob, sz(64))
+        assert bytes(oa) == tail and bytes(ob) == tail and bytes(a) == bytes(b)  # the states after the draw agree too
