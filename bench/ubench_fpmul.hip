@@ -304,6 +304,107 @@ template <int V> __global__ void k_chain(uint32_t* out, const uint32_t* in, int 
     uint64_t s = 0; for (int i = 0; i < 5; i++) s ^= x.v[i] ^ x2.v[i]; out[tid] = (uint32_t)s;
   }
 }
+
+// ---------- variant F: 5 x 51-bit limbs held as doubles, products by FP64 FMA (round toward zero) ----------
+// For integers a, b < 2^51 as doubles: x = fma_rz(a, b, 2^103) = 2^103 + floor(ab / 2^51) 2^51 (the unit in the last place of
+// [2^103, 2^104) is 2^51), and y = fma_rz(a, b, (2^103 + 2^52) - x) = 2^52 + (ab mod 2^51), both exact. The bit patterns of x
+// and y are (exponent | 52-bit integer), so column sums accumulate as 64-bit INTEGER additions of the raw patterns and the
+// exponent constants are subtracted once per column. Per partial product: 2 FMA + 1 DADD + 2 64-bit adds, no carry flag.
+// Needs the double rounding mode set to round-toward-zero (s_setreg MODE[3:2] = 3) for the whole kernel.
+struct FF { double v[5]; };
+__device__ __forceinline__ FF mulF(const FF& a, const FF& b) {
+  const double C1 = 0x1p103, C2 = 0x1p103 + 0x1p52;
+  const uint64_t E1 = (uint64_t)__double_as_longlong(C1), E2 = (uint64_t)__double_as_longlong(0x1p52);
+  uint64_t H[9], L[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { H[k] = 0; L[k] = 0; }
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      double x = __builtin_fma(a.v[i], b.v[j], C1);
+      double y = __builtin_fma(a.v[i], b.v[j], C2 - x);
+      H[i + j] += (uint64_t)__double_as_longlong(x);
+      L[i + j] += (uint64_t)__double_as_longlong(y);
+    }
+  // strip the exponent patterns: column k holds n_k = min(k, 8 - k) + 1 products
+  uint64_t w[10];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint64_t n = (uint64_t)((k < 4 ? k : 8 - k) + 1);
+    H[k] -= n * E1;
+    L[k] -= n * E2;
+  }
+  w[0] = L[0];
+#pragma unroll
+  for (int k = 1; k < 9; k++) w[k] = L[k] + H[k - 1];
+  w[9] = H[8];
+  // 2^255 = 19: fold the high five words, then one carry pass (limbs end below 2^51 + small)
+#pragma unroll
+  for (int k = 0; k < 5; k++) w[k] += 19 * w[k + 5];
+  const uint64_t M = (1ULL << 51) - 1;
+  uint64_t c = w[0] >> 51; w[0] &= M; w[1] += c;
+  c = w[1] >> 51; w[1] &= M; w[2] += c;
+  c = w[2] >> 51; w[2] &= M; w[3] += c;
+  c = w[3] >> 51; w[3] &= M; w[4] += c;
+  c = w[4] >> 51; w[4] &= M; w[0] += 19 * c;
+  c = w[0] >> 51; w[0] &= M; w[1] += c;
+  FF r;
+#pragma unroll
+  for (int k = 0; k < 5; k++) r.v[k] = __longlong_as_double((long long)(w[k] | E2)) - 0x1p52;  // integer < 2^52 -> double, exact
+  return r;
+}
+__device__ __forceinline__ void set_round_toward_zero_f64() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3"); }
+__global__ void k_chainF(uint32_t* out, const uint32_t* in, int iters) {
+  set_round_toward_zero_f64();
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  FF x, y;
+  for (int i = 0; i < 5; i++) { x.v[i] = (double)(in[i] + tid); y.v[i] = (double)(in[8 + (i & 7)] ^ tid); }
+  FF x2 = y, y2 = x;
+  for (int it = 0; it < iters; it++) {
+    x = mulF(x, y); x2 = mulF(x2, y2);
+    y.v[0] = (double)((uint64_t)y.v[0] ^ ((uint64_t)x2.v[1] & 0xffff)); y2.v[0] = (double)((uint64_t)y2.v[0] ^ ((uint64_t)x.v[1] & 0xffff));
+  }
+  double sacc = 0; for (int i = 0; i < 5; i++) sacc += x.v[i] + x2.v[i]; out[tid] = (uint32_t)(uint64_t)sacc;
+}
+// device self-check of mulF against the 5x51 integer form on pseudo-random 51-bit limbs: out[0] = mismatching lanes
+__global__ void k_checkF(uint32_t* out) {
+  set_round_toward_zero_f64();
+  uint64_t s = 0x9e3779b97f4a7c15ULL * (threadIdx.x + 1 + 256 * blockIdx.x);
+  FE a, b; FF fa, fb;
+  for (int i = 0; i < 5; i++) {
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL; a.v[i] = (s >> 13) & ((1ULL << 51) - 1);
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL; b.v[i] = (s >> 13) & ((1ULL << 51) - 1);
+    if (threadIdx.x == 1) { a.v[i] = (1ULL << 51) - 1; b.v[i] = (1ULL << 51) - 1; }  // the largest operands
+    fa.v[i] = (double)a.v[i]; fb.v[i] = (double)b.v[i];
+  }
+  FE e = mulE(a, b);
+  FF f = mulF(fa, fb);
+  // compare as residues: both are loosely reduced; normalise e the same way mulF does (limbs < 2^51 except a small excess in limb 1)
+  unsigned __int128 ve = 0, vf = 0;  // compare modulo 2^127 of the weighted sums of the low limbs AND the full limb vectors after a canonical carry
+  uint64_t le[5], lf[5];
+  for (int i = 0; i < 5; i++) { le[i] = e.v[i]; lf[i] = (uint64_t)f.v[i]; }
+  for (int pass = 0; pass < 3; pass++) {
+    const uint64_t M = (1ULL << 51) - 1; uint64_t c;
+    c = le[0] >> 51; le[0] &= M; le[1] += c; c = le[1] >> 51; le[1] &= M; le[2] += c; c = le[2] >> 51; le[2] &= M; le[3] += c; c = le[3] >> 51; le[3] &= M; le[4] += c; c = le[4] >> 51; le[4] &= M; le[0] += 19 * c;
+    c = lf[0] >> 51; lf[0] &= M; lf[1] += c; c = lf[1] >> 51; lf[1] &= M; lf[2] += c; c = lf[2] >> 51; lf[2] &= M; lf[3] += c; c = lf[3] >> 51; lf[3] &= M; lf[4] += c; c = lf[4] >> 51; lf[4] &= M; lf[0] += 19 * c;
+  }
+  (void)ve; (void)vf;
+  bool same = true;
+  for (int i = 0; i < 5; i++) same = same && le[i] == lf[i];
+  // values in [p, 2^255) have two representations; treat x and x - p as equal
+  if (!same) {
+    uint64_t lp[5] = {le[0] + 19, le[1], le[2], le[3], le[4]};
+    const uint64_t M = (1ULL << 51) - 1; uint64_t c;
+    c = lp[0] >> 51; lp[0] &= M; lp[1] += c; c = lp[1] >> 51; lp[1] &= M; lp[2] += c; c = lp[2] >> 51; lp[2] &= M; lp[3] += c; c = lp[3] >> 51; lp[3] &= M; lp[4] += c; lp[4] &= M;
+    bool alt = true; for (int i = 0; i < 5; i++) alt = alt && lp[i] == lf[i];
+    uint64_t lq[5] = {lf[0] + 19, lf[1], lf[2], lf[3], lf[4]};
+    c = lq[0] >> 51; lq[0] &= M; lq[1] += c; c = lq[1] >> 51; lq[1] &= M; lq[2] += c; c = lq[2] >> 51; lq[2] &= M; lq[3] += c; c = lq[3] >> 51; lq[3] &= M; lq[4] += c; lq[4] &= M;
+    bool alt2 = true; for (int i = 0; i < 5; i++) alt2 = alt2 && lq[i] == le[i];
+    same = alt || alt2;
+  }
+  if (!same) atomicAdd(out, 1u);
+}
 // the product library's multipliers in the same 2-chain harness, and its mixed addition
 template <int V> __global__ void k_lib(uint32_t* out, const uint32_t* in, int iters) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -439,6 +540,13 @@ int main(int argc, char** argv) {
   ms = timeit([&] { k_chain<3><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[3], ms, nmul / ms / 1e6);
   ms = timeit([&] { k_chain<4><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[4], ms, nmul / ms / 1e6);
   ms = timeit([&] { k_chain<5><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", names[5], ms, nmul / ms / 1e6);
+  {
+    hipMemset(out, 0, 4);
+    k_checkF<<<64, 256>>>(out);
+    uint32_t bad = 0; hipMemcpy(&bad, out, 4, hipMemcpyDeviceToHost);
+    printf("F self-check (mulF vs mulE on 16384 random + extreme operand pairs): %u mismatches\n", bad);
+  }
+  ms = timeit([&] { k_chainF<<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "F 5x51 fp64-FMA (RZ)", ms, nmul / ms / 1e6);
   ms = timeit([&] { k_lib<0><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fp_mul (4x64 op-scan)", ms, nmul / ms / 1e6);
   ms = timeit([&] { k_lib<1><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fp_mul+fp_sqr pairs", ms, 2 * nmul / ms / 1e6);
   ms = timeit([&] { k_lib<2><<<blocks, threads>>>(out, in, iters); }, 5); printf("%-22s %8.3f ms  %8.2f Gmul/s\n", "lib fe10_mul (10x25.5 s)", ms, nmul / ms / 1e6);

@@ -1,0 +1,131 @@
+// src/nizk/mod.rs — prove() bodies under `--features gpu`. Transcript and tape operations are the reference's, in the
+// reference's order; what changes is who computes the group elements:
+//   * the 2-term commitments of the Sigma protocols: commit_small (the library's host-side engine, or the device);
+//   * ProductProof's delta (:197-205) is rewritten over the ORIGINAL generators — delta = b3 X + b5 h with X = x G + rX h is
+//     (b3 x) G + (b3 rX + b5) h: the same group element, no variable-base arithmetic;
+//   * DotProductProofLog::prove keeps x on the device and runs the inner-product argument through sp_ipa_*.
+// The C++ rendering that the parity tests execute is spartan_amd/host/prover.cc (knowledge_prove, equality_prove, product_prove,
+// dotproductlog_prove); these bodies issue the same C-ABI calls in the same order.
+use super::super::commitments::commit_small;
+use super::super::gpu;
+
+impl KnowledgeProof {
+  #[cfg(feature = "gpu")]
+  pub fn prove(gens_n: &MultiCommitGens, transcript: &mut Transcript, random_tape: &mut RandomTape, x: &Scalar, r: &Scalar) -> (KnowledgeProof, CompressedGroup) {
+    transcript.append_protocol_name(KnowledgeProof::protocol_name());
+    let t1 = random_tape.random_scalar(b"t1");
+    let t2 = random_tape.random_scalar(b"t2");
+    let d = &gens_n.dev;
+    let cm = commit_small(d.g, &[d.G[0], d.h], &[*x, *r, t1, t2], 2, None); // C = x G + r h ; alpha = t1 G + t2 h
+    let (C, alpha) = (cm[0], cm[1]);
+    C.append_to_transcript(b"C", transcript);
+    alpha.append_to_transcript(b"alpha", transcript);
+    let c = transcript.challenge_scalar(b"c");
+    (KnowledgeProof { alpha, z1: x * c + t1, z2: r * c + t2 }, C)
+  }
+}
+
+impl EqualityProof {
+  #[cfg(feature = "gpu")]
+  pub fn prove(
+    gens_n: &MultiCommitGens, transcript: &mut Transcript, random_tape: &mut RandomTape,
+    v1: &Scalar, s1: &Scalar, v2: &Scalar, s2: &Scalar,
+  ) -> (EqualityProof, CompressedGroup, CompressedGroup) {
+    transcript.append_protocol_name(EqualityProof::protocol_name());
+    let r = random_tape.random_scalar(b"r");
+    let d = &gens_n.dev;
+    let cm = commit_small(d.g, &[d.G[0], d.h], &[*v1, *s1, *v2, *s2, Scalar::zero(), r], 3, None); // C1, C2, alpha = r h
+    let (C1, C2, alpha) = (cm[0], cm[1], cm[2]);
+    C1.append_to_transcript(b"C1", transcript);
+    C2.append_to_transcript(b"C2", transcript);
+    alpha.append_to_transcript(b"alpha", transcript);
+    let c = transcript.challenge_scalar(b"c");
+    (EqualityProof { alpha, z: c * (s1 - s2) + r }, C1, C2)
+  }
+}
+
+impl ProductProof {
+  #[cfg(feature = "gpu")]
+  pub fn prove(
+    gens_n: &MultiCommitGens, transcript: &mut Transcript, random_tape: &mut RandomTape,
+    x: &Scalar, rX: &Scalar, y: &Scalar, rY: &Scalar, z: &Scalar, rZ: &Scalar,
+  ) -> (ProductProof, CompressedGroup, CompressedGroup, CompressedGroup) {
+    transcript.append_protocol_name(ProductProof::protocol_name());
+    let (b1, b2, b3) = (random_tape.random_scalar(b"b1"), random_tape.random_scalar(b"b2"), random_tape.random_scalar(b"b3"));
+    let (b4, b5) = (random_tape.random_scalar(b"b4"), random_tape.random_scalar(b"b5"));
+    let d = &gens_n.dev;
+    // X, Y, Z, alpha, beta, delta in one call; delta over the original generators (see the header of this file)
+    let rows = [*x, *rX, *y, *rY, *z, *rZ, b1, b2, b3, b4, b3 * x, b3 * rX + b5];
+    let cm = commit_small(d.g, &[d.G[0], d.h], &rows, 6, None);
+    let (X, Y, Z, alpha, beta, delta) = (cm[0], cm[1], cm[2], cm[3], cm[4], cm[5]);
+    X.append_to_transcript(b"X", transcript);
+    Y.append_to_transcript(b"Y", transcript);
+    Z.append_to_transcript(b"Z", transcript);
+    alpha.append_to_transcript(b"alpha", transcript);
+    beta.append_to_transcript(b"beta", transcript);
+    delta.append_to_transcript(b"delta", transcript);
+    let c = transcript.challenge_scalar(b"c");
+    let z = [b1 + c * x, b2 + c * rX, b3 + c * y, b4 + c * rY, b5 + c * (rZ - rX * y)];
+    (ProductProof { alpha, beta, delta, z }, X, Y, Z)
+  }
+}
+
+impl DotProductProofLog {
+  /// DotProductProofLog::prove (:440-525) with x_vec resident on the device (it is the bound polynomial LZ of
+  /// PolyEvalProof::prove and never visits the host). Returns (proof, Cx, Cy) like the reference.
+  #[cfg(feature = "gpu")]
+  pub fn prove_dev(
+    gens: &DotProductProofGens, transcript: &mut Transcript, random_tape: &mut RandomTape,
+    x_dev: &gpu::Table, blind_x: &Scalar, a_vec: &[Scalar], y: &Scalar, blind_y: &Scalar,
+  ) -> (DotProductProofLog, CompressedGroup, CompressedGroup) {
+    transcript.append_protocol_name(DotProductProofLog::protocol_name());
+    let n = x_dev.len();
+    assert_eq!(a_vec.len(), n);
+    assert_eq!(gens.n, n);
+    let d = random_tape.random_scalar(b"d");
+    let r_delta = random_tape.random_scalar(b"r_delta");
+    let r_beta = random_tape.random_scalar(b"r_delta"); // sic: the reference draws r_beta under the label "r_delta" (:459)
+    let lg_n = n.log_2();
+    let v1 = random_tape.random_vector(b"blinds_vec_1", lg_n);
+    let v2 = random_tape.random_vector(b"blinds_vec_2", lg_n);
+    let (gn, g1) = (&gens.gens_n.dev, &gens.gens_1.dev);
+    assert!(gn.G.windows(2).all(|w| w[1] == w[0] + 1)); // one contiguous run of the generator stream
+    // Cx = commit(x, blind_x) and the argument's device state from one copy of x; Q = r * gens_1.G[0] (gens_1.scale(r), :479-480)
+    // with r drawn below; H = h
+    let mut ipa: *mut gpu::sp_ipa = std::ptr::null_mut();
+    let mut cx = [0u8; 32];
+    gpu::ok(unsafe {
+      gpu::sp_ipa_begin_dev(gpu::ctx(), gn.g, gn.G[0] as usize, n, g1.G[0] as usize, gn.h as usize, x_dev.0, gpu::limbs(a_vec), gpu::limbs1(blind_x),
+                            cx.as_mut_ptr(), &mut ipa)
+    });
+    let ipa = gpu::Ipa(ipa); // sp_ipa_free on drop
+    let Cx = CompressedGroup::from_slice(&cx);
+    Cx.append_to_transcript(b"Cx", transcript);
+    let Cy = y.commit_compressed(blind_y, &gens.gens_1);
+    Cy.append_to_transcript(b"Cy", transcript);
+    a_vec.append_to_transcript(b"a", transcript);
+    let r = transcript.challenge_scalar(b"r");
+    gpu::ok(unsafe { gpu::sp_ipa_set_scale(ipa.0, gpu::limbs1(&r)) });
+    let blind_Gamma = blind_x + r * blind_y;
+    let blinds_vec: Vec<(Scalar, Scalar)> = (0..lg_n).map(|i| (v1[i], v2[i])).collect();
+    // BulletReductionProof::prove (bullet.rs:32-132): rounds on the device, transcript here (seams/bullet.rs)
+    let (bullet_reduction_proof, rhat_Gamma) = BulletReductionProof::prove_rounds_gpu(transcript, &ipa, &blind_Gamma, &blinds_vec);
+    // a_hat, b_hat and delta = commit(d, r_delta) under {g_hat, h} (:496-501) in ONE trip: the commitment does not depend on them
+    let (mut x_hat, mut a_hat) = (Scalar::zero(), Scalar::zero());
+    let mut delta = [0u8; 32];
+    gpu::ok(unsafe {
+      gpu::sp_ipa_finish_commit(ipa.0, gpu::limbs1(&d), gpu::limbs1(&r_delta), &mut x_hat as *mut Scalar as *mut u64, &mut a_hat as *mut Scalar as *mut u64,
+                                delta.as_mut_ptr())
+    });
+    let y_hat = x_hat * a_hat;
+    let delta = CompressedGroup::from_slice(&delta);
+    delta.append_to_transcript(b"delta", transcript);
+    // beta = commit(d, r_beta) under gens_1.scale(r): (d r) G + r_beta h over the original generators
+    let beta = commit_small(g1.g, &[g1.G[0], g1.h], &[d * r, r_beta], 1, None)[0];
+    beta.append_to_transcript(b"beta", transcript);
+    let c = transcript.challenge_scalar(b"c");
+    let z1 = d + c * y_hat;
+    let z2 = a_hat * (c * rhat_Gamma + r_beta) + r_delta;
+    (DotProductProofLog { bullet_reduction_proof, delta, beta, z1, z2 }, Cx, Cy)
+  }
+}

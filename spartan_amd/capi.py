@@ -2,7 +2,7 @@
 import ctypes, os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspartan_hip.so")
+LIB_PATH = os.environ.get("SPARTAN_HIP_LIB") or os.path.join(_HERE, "lib", "libspartan_hip.so")  # the override is for diagnostic builds (bench/ktime_probe.py)
 sz = ctypes.c_size_t
 vp = ctypes.c_void_p
 u64p = ctypes.POINTER(ctypes.c_uint64)

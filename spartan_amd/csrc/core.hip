@@ -136,7 +136,7 @@ int32_t sync_spin(sp_ctx* c) { return sync_wait(c, sync_post(c)); }
 DoneSig sig_make(sp_ctx* c, size_t total_workgroups) {
   static const bool off = getenv("SPARTAN_NO_KERNEL_SIGNAL") != nullptr;  // A/B switch: completion by a flag kernel behind the last kernel
   if (off || !c->done_counter) return sig_none();
-  return DoneSig{c->done_flag, c->done_counter, ++c->done_seq, (uint32_t)total_workgroups};
+  return DoneSig{c->done_flag, c->done_counter, ++c->done_seq, (uint32_t)total_workgroups, c->ktime};
 }
 // wait for a trip whose last kernel was launched with `sig` (falls back to the flag kernel when the signal is off)
 int32_t sig_wait(sp_ctx* c, const DoneSig& sig) { return sig.flag ? sync_wait(c, sig.seq) : sync_spin(c); }
@@ -376,6 +376,68 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
     else ((Pt10*)out)[row * gridDim.x + blockIdx.x] = r;
   }
 }
+// The same lookups + tree for commitments of more than 256 (column, window) pairs per row (rows <= 8), in ONE launch: every
+// workgroup leaves its partial sum in device memory and takes a ticket at its row's counter; the workgroup that draws the last
+// ticket of a row adds the row's partial sums in a second tree and writes the row sum to the host-mapped page; the last
+// workgroup of the launch raises the completion flag. (Before: lookups + tree, reduction and flag as three launches.)
+__global__ void __launch_bounds__(256) k_msm_windows_tree_fused(const Fq* __restrict__ Z, size_t z_row_stride, size_t cols, const Niels* __restrict__ table,
+                                                                size_t g_off, const uint32_t* __restrict__ idx, size_t idx_row_stride,
+                                                                const Fq* __restrict__ blinds, size_t h_idx, Pt10* __restrict__ part, uint32_t* __restrict__ tickets,
+                                                                Pt* __restrict__ sums_out, MsmGeom geom, DoneSig sig) {
+  __shared__ Pt10 sm[256];
+  __shared__ Fe10 xch[256];
+  __shared__ unsigned ticket;
+  size_t ncol = cols + (blinds ? 1 : 0), P = ncol * geom.nwin, row = blockIdx.y;
+  int t = threadIdx.x;
+  size_t p = (size_t)blockIdx.x * 256 + t;
+  Pt10 acc = pt10_identity();
+  if (p < P) {
+    size_t j = p % ncol;
+    int w = (int)(p / ncol);
+    Fq sc = j < cols ? ld_fq(Z + row * z_row_stride + j) : ld_fq(blinds + row);
+    size_t pt = j < cols ? (idx ? (size_t)idx[row * idx_row_stride + j] : g_off + j) : h_idx;
+    if (!fq_is_zero(sc)) {
+      int d = msm_digit(fq_from_mont(sc), w, geom);
+      if (d != 0) {
+        Niels n = table[msm_tidx(geom, pt, w, d < 0 ? -d : d)];
+        Fp dx = fp_sub(n.yp, n.ym), sy = fp_add(n.yp, n.ym);
+        Fp X = fp_add(dx, dx), T = fp_mul(dx, sy);
+        if (d < 0) { X = fp_neg(X); T = fp_neg(T); }
+        acc = Pt10{fe10_load(X), fe10_load(fp_add(sy, sy)), Fe10{{4, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, fe10_load(T)};
+      }
+    }
+  }
+  sm[t] = acc;
+  __syncthreads();
+  pt10_tree_quad(sm, xch, P - (size_t)blockIdx.x * 256);
+  const unsigned nblk = gridDim.x;
+  if (t == 0) {
+    part[row * nblk + blockIdx.x] = sm[0];
+    __threadfence();
+    ticket = atomicAdd(tickets + row, 1u);
+  }
+  __syncthreads();
+  if (ticket == nblk - 1) {
+    __threadfence();
+    Pt10 r = pt10_identity();
+    bool any = false;
+    for (size_t k2 = t; k2 < nblk; k2 += 256) {
+      Pt10 q2 = part[row * nblk + k2];
+      r = any ? pt10_add(r, q2) : q2;
+      any = true;
+    }
+    __syncthreads();
+    sm[t] = r;
+    __syncthreads();
+    pt10_tree_quad(sm, xch, nblk < 256 ? nblk : 256);
+    if (t == 0) {
+      Pt10 z = sm[0];
+      sums_out[row] = Pt{fe10_to_fp(z.X), fe10_to_fp(z.Y), fe10_to_fp(z.Z), fe10_to_fp(z.T)};
+      tickets[row] = 0;
+    }
+  }
+  signal_done(sig);
+}
 // ---- one inner-product round in ONE launch (BulletReductionProof::prove, src/nizk/bullet.rs:72-100) ---------------------
 // L = <a_L, G_R>, R = <a_R, G_L> over the ORIGINAL generators (spartan_hip.h: the folded generators are never built): row 0
 // pairs scalar a'[i] s'[p] with generator p n_cur + h + i, row 1 scalar a'[h + i] s'[p] with generator p n_cur + i, for
@@ -463,6 +525,8 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
   }
   // ---- lookups of one row + tree
   const unsigned row = blockIdx.x / A.nblk, blk = blockIdx.x % A.nblk;
+  DoneSig kt0 = sig; if (blockIdx.x != 0) kt0.kt = nullptr;   // stamps 0..5: the first workgroup
+  SP_KT(kt0, 0);
   const size_t cols = A.n0 / 2, P = cols * (size_t)geom.nwin;
   const size_t p = (size_t)blk * 256 + t;
   Pt10 acc = pt10_identity();
@@ -474,10 +538,12 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
     Fq av = ipa_fold_a(A.a, row == 0 ? i : h + i, A.n_cur, A.fold, A.u, A.u_inv);
     Fq sv = A.fold ? fq_mul(ld_fq(A.s + pb / 2), (pb & 1) ? A.u : A.u_inv) : ld_fq(A.s + pb);
     Fq sc = fq_mul(av, sv);
+    SP_KT(kt0, 1);
     if (!fq_is_zero(sc)) {
       int d = msm_digit(fq_from_mont(sc), w, geom);
       if (d != 0) {
         Niels n = table[msm_tidx(geom, gen, w, d < 0 ? -d : d)];
+        SP_KT(kt0, 2);
         Fp dx = fp_sub(n.yp, n.ym), sy = fp_add(n.yp, n.ym);
         Fp X = fp_add(dx, dx), T = fp_mul(dx, sy);
         if (d < 0) { X = fp_neg(X); T = fp_neg(T); }
@@ -486,15 +552,20 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
     }
   }
   sm[t] = acc;
+  SP_KT(kt0, 3);
   __syncthreads();
   pt10_tree_quad(sm, xch, P - (size_t)blk * 256);
+  SP_KT(kt0, 4);
   if (t == 0) {
     A.part[(size_t)row * A.nblk + blk] = sm[0];
     __threadfence();  // the partial sum is visible device-wide before this block counts itself in
     ticket = atomicAdd(A.counters + row, 1u);
   }
   __syncthreads();
+  SP_KT(kt0, 5);
   if (ticket == A.nblk - 1) {  // last block of the row: add the row's partial sums
+    DoneSig kt1 = sig; if (row != 0) kt1.kt = nullptr;   // stamps 8..11: the reducing workgroup of row 0
+    SP_KT(kt1, 8);
     __threadfence();
     Pt10 r = pt10_identity();
     bool any = false;
@@ -505,13 +576,16 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
     }
     __syncthreads();
     sm[t] = r;
+    SP_KT(kt1, 9);
     __syncthreads();
     pt10_tree_quad(sm, xch, A.nblk < 256 ? A.nblk : 256);
+    SP_KT(kt1, 10);
     if (t == 0) {
       Pt10 z = sm[0];
       A.sums_out[row] = Pt{fe10_to_fp(z.X), fe10_to_fp(z.Y), fe10_to_fp(z.Z), fe10_to_fp(z.T)};
       A.counters[row] = 0;
     }
+    SP_KT(kt1, 11);
   }
   signal_done(sig);
 }
@@ -704,6 +778,9 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->done_seq = 0;
   HIPCHK(hipMalloc((void**)&c->done_counter, 64));
   HIPCHK(hipMemset(c->done_counter, 0, 64));
+#ifdef SP_KTIME
+  if (getenv("SPARTAN_KTIME")) { HIPCHK(hipMalloc((void**)&c->ktime, 64 * 8)); HIPCHK(hipMemset(c->ktime, 0, 64 * 8)); }
+#endif
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
   return SP_OK;
 }
@@ -731,6 +808,16 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+#ifdef SP_KTIME
+// diagnostic build only (not in the header): the in-kernel time stamps of the last instrumented launch, in 100 MHz ticks
+int32_t sp_debug_ktime(sp_ctx* c, long long* out, int n) {
+  if (!c || !c->ktime || n > 64) return SP_EINVAL;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(out, c->ktime, 8 * (size_t)n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(c->ktime, 0, 64 * 8));
+  return SP_OK;
+}
+#endif
 int sp_ctx_device(const sp_ctx* c) { return c ? c->dev : -1; }
 uint64_t sp_ctx_trips(const sp_ctx* c) { return c ? c->sync_epoch : 0; }
 int32_t sp_ctx_sync(sp_ctx* c) {
@@ -1038,6 +1125,20 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
     if (m.windowed) {
       size_t nblk = (m.P + 255) / 256;
       Pt10* part = (Pt10*)c->scratch;  // nblk * rows * 160 B <= part_bytes
+      static const bool fused = getenv("SPARTAN_MSM_UNFUSED") == nullptr;  // A/B switch: lookups + tree, reduction and flag as three launches
+      if (fused && nblk > 1 && !c->device_encode && c->done_counter) {
+        DoneSig sig = sig_make(c, nblk * rows);
+        {
+          ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));
+          hipLaunchKernelGGL(k_msm_windows_tree_fused, dim3((unsigned)nblk, (unsigned)rows), dim3(256), 0, c->stream, dZ, z_stride, cols, (const Niels*)g->table, g_off,
+                             didx, idx_row_stride, dblinds, h_idx, part, c->done_counter + 4, (Pt*)hres(c), g->geom, sig);
+        }
+        SPCHK(sig_wait(c, sig));
+        if (hipGetLastError() != hipSuccess) return SP_EHIP;
+        const Pt* sums = (const Pt*)hres(c);
+        for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
+        return SP_OK;
+      }
       {
         ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));
         if (nblk == 1)

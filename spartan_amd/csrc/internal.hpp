@@ -76,6 +76,7 @@ struct sp_ctx {
   volatile uint32_t* done_flag;
   uint32_t done_seq;
   uint32_t* done_counter = nullptr;  // DoneSig::counter
+  long long* ktime = nullptr;        // DoneSig::kt (SP_KTIME builds with SPARTAN_KTIME set)
   uint8_t *vm_pinned = nullptr, *vm_dstage = nullptr;  // sp_vecmat_dev's own staging pair for L: the call does not wait (core.hip: vm_stage)
   size_t vm_cap = 0;
   hipEvent_t vm_ev = nullptr;
@@ -192,8 +193,15 @@ struct DoneSig {
   volatile uint32_t* flag;
   uint32_t* counter;  // device word, zero between kernels (the signalling workgroup resets it)
   uint32_t seq, total;  // total: workgroups of the launch
+  long long* kt;        // diagnostic builds (-DSP_KTIME, bench/ktime_probe.py): device buffer for in-kernel time stamps; else null
 };
-static inline DoneSig sig_none() { return DoneSig{nullptr, nullptr, 0, 0}; }
+static inline DoneSig sig_none() { return DoneSig{nullptr, nullptr, 0, 0, nullptr}; }
+// in-kernel phase stamps of the first workgroup (100 MHz wall clock): compiled in only with -DSP_KTIME
+#if defined(SP_KTIME) && defined(__HIPCC__)
+#define SP_KT(sig, i) do { if ((sig).kt && threadIdx.x == 0) (sig).kt[i] = wall_clock64(); } while (0)
+#else
+#define SP_KT(sig, i) do { } while (0)
+#endif
 DoneSig sig_make(sp_ctx* c, size_t total_workgroups);
 int32_t sig_wait(sp_ctx* c, const DoneSig& sig);  // reserves the next sequence number; wait for it with sync_wait(c, sig.seq)
 #if defined(__HIPCC__)

@@ -140,6 +140,19 @@ __global__ void __launch_bounds__(256) k_ipa_ghat_row(const Fq* __restrict__ s, 
   }
 }
 
+// The end of the argument in one launch: a_hat, b_hat (the vectors at length 1, bullet.rs:121-131) into the host-mapped page and
+// the scalar row d * s (+ 0 * Q + r * H) of the commitment under g_hat = sum_p s[p] G[p] (nizk/mod.rs:496-501), with the last
+// recorded fold applied on the way (a' = a_0 u + u^-1 a_1, s'[2p] = s[p] u^-1, s'[2p+1] = s[p] u) instead of a launch of its own.
+__global__ void __launch_bounds__(256) k_ipa_finish_rows(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n0, int fold, Fq u, Fq u_inv,
+                                                         Fq d, Fq r, Fq* __restrict__ row, Fq* __restrict__ ab_out) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0; j += (size_t)gridDim.x * blockDim.x) st_fq(row + j, fq_mul(ipa_s(s, j, fold, u, u_inv), d));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st_fq(row + n0, fq_zero());
+    st_fq(row + n0 + 1, r);
+    st_fq(ab_out, ipa_a(a, 0, 1, fold, u, u_inv));
+    st_fq(ab_out + 1, ipa_b(b, 0, 1, fold, u, u_inv));
+  }
+}
 // a_hat, b_hat (the vectors at length 1) into the host-mapped result page
 __global__ void k_ipa_heads(const Fq* __restrict__ a, const Fq* __restrict__ b, Fq* __restrict__ out, DoneSig sig) {
   if (threadIdx.x == 0) { st_fq(out, ld_fq(a)); st_fq(out + 1, ld_fq(b)); }
@@ -360,15 +373,14 @@ int32_t sp_ipa_finish_commit(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[
   if (!ipa || !d || !r || !a_hat || !b_hat || !delta_out || ipa->n_cur != 1) return SP_EINVAL;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
-  SPCHK(ipa_flush_fold(ipa));
   // between the partial sums (< HOST_SUM_BYTES) and the row sums (last KiB) of the result page: msm_launch leaves it alone
   Fq* ab = (Fq*)(hres(c) + HOST_SUM_BYTES);
-  hipLaunchKernelGGL(k_ipa_heads, dim3(1), dim3(64), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, ab, sig_none());
   {
     ProfScope ps(c, PF_IPA, 64.0 * (double)ipa->n0);
-    hipLaunchKernelGGL(k_ipa_ghat_row, dim3((unsigned)grid_for(ipa->n0, 64)), dim3(256), 0, c->stream, (const Fq*)ipa->s, ipa->n0, limbs(d),
-                       limbs(r), ipa->rows);
+    hipLaunchKernelGGL(k_ipa_finish_rows, dim3((unsigned)grid_for(ipa->n0, 64)), dim3(256), 0, c->stream, (const Fq*)ipa->a, (const Fq*)ipa->b, (const Fq*)ipa->s, ipa->n0,
+                       ipa->fold_pending ? 1 : 0, ipa->fu, ipa->fu_inv, limbs(d), limbs(r), ipa->rows, ab);
   }
+  // (the recorded fold stays recorded: the vectors behind the handle are not needed again — sp_ipa_free follows)
   SPCHK(msm_launch(c, ipa->g, ipa->rows, ipa->n0 + 2, 1, ipa->n0 + 2, 0, ipa->idx, nullptr, 0, delta_out));  // waits for the stream
   memcpy(a_hat, ab, 32);
   memcpy(b_hat, ab + 1, 32);

@@ -41,8 +41,10 @@ struct Triple {
   Fq* c_out;  // where this instance writes the bound C (non-null for exactly one instance per distinct C table)
 };
 __device__ __forceinline__ void cubic_point(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c0, const Fq& c1, Fq (&e)[3]) {
-  Fq a2 = fq_sub(fq_dbl(a1), a0), b2 = fq_sub(fq_dbl(b1), b0), c2 = fq_sub(fq_dbl(c1), c0);
-  Fq a3 = fq_sub(fq_add(a2, a1), a0), b3 = fq_sub(fq_add(b2, b1), b0), c3 = fq_sub(fq_add(c2, c1), c0);
+  // the line through (0, x0), (1, x1) at 2 and 3: x1 + d, x1 + 2d with d = x1 - x0 (three modular additions per table)
+  Fq da = fq_sub(a1, a0), db = fq_sub(b1, b0), dc = fq_sub(c1, c0);
+  Fq a2 = fq_add(a1, da), b2 = fq_add(b1, db), c2 = fq_add(c1, dc);
+  Fq a3 = fq_add(a2, da), b3 = fq_add(b2, db), c3 = fq_add(c2, dc);
   e[0] = fq_add(e[0], fq_mul(fq_mul(a0, b0), c0));
   e[1] = fq_add(e[1], fq_mul(fq_mul(a2, b2), c2));
   e[2] = fq_add(e[2], fq_mul(fq_mul(a3, b3), c3));
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* _
 // each), so a round costs ~3 multiplications of latency instead of 12. Block = 32 indices x 8 roles; grid (nblk, ninst).
 __global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
   __shared__ Fq bound[32][6];  // [index][table*2 + half]
+  __shared__ Fq lv[32][3][3];  // [index][table][t = 0, 2, 3]: the bound pair's line
   __shared__ Fq red[3][32];
   Triple t = T[blockIdx.y];
   int li = threadIdx.x >> 3, role = threadIdx.x & 7;
@@ -108,23 +111,17 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __re
     else if (t.c_out) st_fq(t.c_out + (size_t)half * quarter + i, v);  // C may be shared between instances: bound out of place, once
   }
   __syncthreads();
+  // lane `role` < 3 first extends the line of table `role` to t = 2, 3 (three modular additions), then — as evaluation point
+  // `role` — multiplies the three tables' values: 3 additions + 2 multiplications deep instead of 12 + 2 per lane
+  if (role < 3 && live) {
+    const Fq lo = bound[li][2 * role], hi = bound[li][2 * role + 1];
+    const Fq d = fq_sub(hi, lo), e2 = fq_add(hi, d), e3 = fq_add(e2, d);
+    lv[li][role][0] = lo; lv[li][role][1] = e2; lv[li][role][2] = e3;
+  }
+  __syncthreads();
   if (role < 3) {
     Fq e = fq_zero();
-    if (live) {
-      // the three evaluation points run the SAME instruction stream (no divergence inside the wave): the value of a
-      // table's line at t = 0, 2, 3 is selected per lane, then one product of three
-      Fq a0 = bound[li][0], a1 = bound[li][1], b0 = bound[li][2], b1 = bound[li][3], c0 = bound[li][4], c1 = bound[li][5];
-      Fq a2 = fq_sub(fq_dbl(a1), a0), b2 = fq_sub(fq_dbl(b1), b0), c2 = fq_sub(fq_dbl(c1), c0);
-      Fq a3 = fq_sub(fq_add(a2, a1), a0), b3 = fq_sub(fq_add(b2, b1), b0), c3 = fq_sub(fq_add(c2, c1), c0);
-      Fq av, bv, cv;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        av.l[k] = role == 0 ? a0.l[k] : (role == 1 ? a2.l[k] : a3.l[k]);
-        bv.l[k] = role == 0 ? b0.l[k] : (role == 1 ? b2.l[k] : b3.l[k]);
-        cv.l[k] = role == 0 ? c0.l[k] : (role == 1 ? c2.l[k] : c3.l[k]);
-      }
-      e = fq_mul(fq_mul(av, bv), cv);
-    }
+    if (live) e = fq_mul(fq_mul(lv[li][0][role], lv[li][1][role]), lv[li][2][role]);
     red[role][li] = e;
   }
   __syncthreads();
@@ -197,7 +194,11 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
   __shared__ Fq red[18][8];
+  __shared__ Fq lv[8][3][6][3];   // [group][table][line V, W, P, U, P + U, P - U][t = 0, 2, 3]
+  DoneSig kt = sig; if (blockIdx.x != 0 || blockIdx.y != 0) kt.kt = nullptr;
+  SP_KT(kt, 0);
   const Triple2 t = T[blockIdx.y];
+  const Fq wv = weights ? ld_fq(weights + blockIdx.y) : fq_zero();  // from the host-mapped page: requested now, needed last
   const int grp = threadIdx.x >> 5, lane = threadIdx.x & 31;
   const size_t n2 = len >> nbind;                  // length of the tables the outputs describe (nbind = 0, 1 or 2 binds first)
   const size_t np = n2 < 4 ? n2 : 4, ng = n2 / np; // entries per group, groups
@@ -211,9 +212,11 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
         if ((size_t)p < np) {
           const size_t y = g + (size_t)p * ng + (size_t)h * (len / 4);
           Fq lo = ld_fq(ptr[k] + y), hi = ld_fq(ptr[k] + y + len / 2);
+          SP_KT(kt, 1);
           first[grp][k * 4 + p][h] = fq_add(lo, fq_mul(r0, fq_sub(hi, lo)));
         }
       }
+      SP_KT(kt, 2);
       __syncthreads();
     }
     if (live && lane < 12) {
@@ -238,29 +241,40 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
       bnd[grp][k * 4 + (np == 2 && p == 1 ? 2 : p)] = v;
     }
   }
+  SP_KT(kt, 3);
   __syncthreads();
-  // 18 triple products per group: lane = 6 t' + kind, kind 0/1 = the two entry pairs of this round, 2..5 = M0, M3, T1, T2
+  // The 18 triple products per group (lane = 6 t' + kind; kind 0/1 = the two entry pairs of this round, 2..5 = M0, M3, T1, T2)
+  // take the values of four lines per table — V through (x0, x2), W through (x1, x3), P through (x0, x1), U through (x2, x3) —
+  // at t = 0, 2, 3, and of P + U, P - U. Each is a handful of modular additions; computed inside the product lanes they ran
+  // as three divergent paths, ~55 dependent additions deep (9 us of a 17 us workgroup: bench/ktime_probe.py). Here twelve
+  // lanes extend one line each (3 additions), nine lanes form sum and difference (2), and the product lanes only multiply.
+  if (live && lane < 12 && np >= 2) {
+    const int k = lane >> 2, line = lane & 3;
+    if (line == 0 || np == 4) {
+      const int iu = line == 0 ? 0 : (line == 1 ? 1 : (line == 2 ? 0 : 2)), iv = line == 0 ? 2 : (line == 1 ? 3 : (line == 2 ? 1 : 3));
+      const Fq u = bnd[grp][k * 4 + iu], v = bnd[grp][k * 4 + iv];
+      const Fq d = fq_sub(v, u), e2 = fq_add(v, d), e3 = fq_add(e2, d);  // the line through (0, u), (1, v) at 2 and 3
+      lv[grp][k][line][0] = u; lv[grp][k][line][1] = e2; lv[grp][k][line][2] = e3;
+    }
+  }
+  __syncthreads();
+  if (live && lane < 9 && np == 4) {
+    const int k = lane / 3, tt = lane % 3;
+    const Fq P = lv[grp][k][2][tt], U = lv[grp][k][3][tt];
+    lv[grp][k][4][tt] = fq_add(P, U);
+    lv[grp][k][5][tt] = fq_sub(P, U);
+  }
+  __syncthreads();
   Fq e = fq_zero();
   if (live && lane < 18 && np >= 2) {
     const int tt = lane / 6, kind = lane % 6;
     if (kind == 0 || np == 4) {
-      Fq f[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const Fq x0 = bnd[grp][k * 4], x1 = bnd[grp][k * 4 + 1], x2 = bnd[grp][k * 4 + 2], x3 = bnd[grp][k * 4 + 3];
-        if (kind <= 1) {
-          f[k] = kind == 0 ? line_at(x0, x2, tt) : line_at(x1, x3, tt);
-        } else {
-          Fq P = line_at(x0, x1, tt), U = line_at(x2, x3, tt);
-          Fq s = fq_add(P, U), d = fq_sub(P, U);
-#pragma unroll
-          for (int w = 0; w < 4; w++) f[k].l[w] = kind == 2 ? P.l[w] : (kind == 3 ? U.l[w] : (kind == 4 ? s.l[w] : d.l[w]));
-        }
-      }
-      e = fq_mul(fq_mul(f[0], f[1]), f[2]);
-      if (weights) e = fq_mul(e, ld_fq(weights + blockIdx.y));  // coeffs[i] of sumcheck.rs:359-369: the caller only adds the instances up
+      e = fq_mul(fq_mul(lv[grp][0][kind][tt], lv[grp][1][kind][tt]), lv[grp][2][kind][tt]);
+      SP_KT(kt, 4);
+      if (weights) e = fq_mul(e, wv);  // coeffs[i] of sumcheck.rs:359-369: the caller only adds the instances up
     }
   }
+  SP_KT(kt, 5);
   if (lane < 18) red[lane][grp] = e;
   __syncthreads();
   if (threadIdx.x < 18) {
@@ -279,7 +293,9 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
     else v = (n2 == 1 && blockIdx.x == 0) ? bnd[0][(x - 15) * 4] : fq_zero();  // final claims
     st_fq(o + x, v);
   }
+  SP_KT(kt, 6);
   signal_done(sig);
+  SP_KT(kt, 7);
 }
 // partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
 __global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) {

@@ -188,7 +188,7 @@ def test_snark_full_size_properties(P, ctx, orc, s):
     inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
     gens = P.SNARKGens(ctx, N, N, 10, N)
     if s == 24:
-        assert (gens.window_bits(0), gens.window_bits(1)) == (15, 12)
+        assert (gens.window_bits(0), gens.window_bits(1)) == (14, 12)
     enc = P.SNARK.encode(ctx, inst, gens)
     tape = P.seed_scalar(b"tape", s)
     proof = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
