@@ -303,6 +303,18 @@ int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table
 int32_t sp_sumcheck_bind2_eval_tables_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r0,
                                               const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs,
                                               uint64_t* out_heads, uint64_t* out_tables /* 4*ninst*3*8 */);
+/* Up to THREE rounds per call (generalises the two calls above). The call first binds every table at r[0..nbind) (nbind <= 3; a
+ * shared C table is bound once, out of place), then returns, for the tables so bound (length n2 = len / 2^nbind >= 2^kd), the
+ * weighted sums over the instances of
+ *   F(y_0, .., y_{kd-1}) = sum_z A~(y, z) B~(y, z) C~(y, z)          on the grid y in {0, 1, 2, 3}^kd,  out_grid[y_0 4^(kd-1) + .. + y_{kd-1}],
+ * A~ etc. being multilinear in the top kd index bits. F has degree 3 in each y, so the grid determines it and the caller runs the
+ * next kd rounds of prove_cubic_batched without the device: round j sends s_j(t) = sum_{b in {0,1}^(kd-1)} F(t, b); its challenge r_j
+ * contracts the first axis with the Lagrange basis of {0, 1, 2, 3}; round j+1 sends sum_b F(r_j, t, b); and so on (the values at
+ * t = 0, 2, 3 are the reference's evaluations, sumcheck.rs:290-357; the value at t = 1 is e - s(0)). kd = 0: only bind.
+ * out_tables (may be NULL): as sp_sumcheck_bind2_eval_tables_batched — the bound tables, [ninst][3][n2], when n2 <= 8 and ninst <= 21
+ * (n2 = 1: the final claims), else out_tables[0] is set to all ones. weights (4*ninst limbs) are mandatory. */
+int32_t sp_sumcheck_grid_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r, size_t nbind,
+                                 const uint64_t* weights, size_t kd, uint64_t* out_grid /* 4*4^kd */, uint64_t* out_tables /* 4*ninst*3*8 */);
 /* out[k] = <chi, T_k> for k < nt (the ~23 DensePolynomial::evaluate calls of HashLayerProof::prove share chi). */
 int32_t sp_dot_many(sp_ctx* ctx, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out /*4*nt*/);
 /* DotProductCircuit::evaluate (product_tree.rs:84-88): sum l[i]*r[i]*w[i] over n elements from the given offsets. */

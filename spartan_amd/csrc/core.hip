@@ -607,7 +607,7 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
   A->nblk = (unsigned)((P + 255) / 256);
   const size_t qlen = A->n_cur >= 4 ? A->n_cur / 4 : 1;
   A->nd = (unsigned)((qlen + 63) / 64);
-  if ((size_t)A->nd * 8 * 32 > 8192) return SP_EINVAL;  // the dot-product partials share the host page with the two row sums
+  if (1024 + (size_t)A->nd * 8 * 32 > HOST_SUM_BYTES) return SP_EINVAL;  // the dot-product partials share the host page with the two row sums (n_cur <= 16384)
   SPCHK(ensure(&c->scratch, &c->scratch_cap, sizeof(Pt10) * 2 * (size_t)A->nblk + 256));
   A->part = (Pt10*)c->scratch;
   A->sums_out = (Pt*)hres(c);
@@ -798,6 +798,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
+  if (c->grid_tickets) (void)hipFree(c->grid_tickets);
+  if (c->ktime) (void)hipFree(c->ktime);
   if (c->vm_pinned) (void)hipHostFree(c->vm_pinned);
   if (c->vm_dstage) (void)hipFree(c->vm_dstage);
   if (c->vm_ev) (void)hipEventDestroy(c->vm_ev);
@@ -1045,7 +1047,8 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
   if (m.windowed) {
     m.P = ncol * NWIN;
   } else {
-    m.strip = total / 524288;  // enough threads for >= 4 waves per SIMD on 256 CUs
+    static const size_t target_threads = [] { const char* e = getenv("SPARTAN_MSM_THREADS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 65536 ? v : (size_t)524288; }();
+    m.strip = total / target_threads;  // enough threads for >= 4 waves per SIMD on 256 CUs
     if (m.strip < 1) m.strip = 1;
     if (m.strip > cols) m.strip = cols;
     m.nstrips = (cols + m.strip - 1) / m.strip;

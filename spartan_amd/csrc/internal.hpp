@@ -77,6 +77,7 @@ struct sp_ctx {
   uint32_t done_seq;
   uint32_t* done_counter = nullptr;  // DoneSig::counter
   long long* ktime = nullptr;        // DoneSig::kt (SP_KTIME builds with SPARTAN_KTIME set)
+  uint32_t* grid_tickets = nullptr;  // k_cubic_grid: per-instance and global tickets, zero between launches
   uint8_t *vm_pinned = nullptr, *vm_dstage = nullptr;  // sp_vecmat_dev's own staging pair for L: the call does not wait (core.hip: vm_stage)
   size_t vm_cap = 0;
   hipEvent_t vm_ev = nullptr;

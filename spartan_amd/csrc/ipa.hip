@@ -310,7 +310,7 @@ int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t b
   if (!ipa || !blind_L || !blind_R || !L_out || !R_out || ipa->n_cur < 2) return SP_EINVAL;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
-  if (ipa_fused() && !c->device_encode && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0)))
+  if (ipa_fused() && !c->device_encode && ipa->n_cur <= 16384 && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0)))
     return ipa_round_fused(ipa, blind_L, blind_R, L_out, R_out);
   ipa->have_c0 = ipa->have_dots = false;
   {

@@ -117,6 +117,12 @@ int spz_cubic_tail_probe(uint64_t* tab, size_t ni, size_t m, const uint64_t* coe
   memcpy(evs, e.data(), 32 * e.size());
   return (int)rounds;
 }
+// grid with `axes` axes (4^axes scalars) and one challenge per axis -> the 4 values s(0..3) each round sends (spark.inc: RoundGrid)
+void spz_round_grid_probe(const uint64_t* F, int axes, const uint64_t* challenges, uint64_t* msgs) {
+  FqVec f = limbs_vec(F, (size_t)1 << (2 * axes)), ch = limbs_vec(challenges, (size_t)axes), m;
+  round_grid_probe(f, axes, ch, &m);
+  memcpy(msgs, m.data(), 32 * m.size());
+}
 int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint64_t* coeffs, uint64_t* compressed, uint64_t eval_at_r[4]) {
   try {
     FqVec e(n), c, cc;
