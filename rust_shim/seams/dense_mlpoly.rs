@@ -1,10 +1,25 @@
 // src/dense_mlpoly.rs — bodies swapped under `--features gpu` (same pattern as the `multicore` pair at :148-177).
 // DensePolynomial gains `#[cfg(feature = "gpu")] dev: Option<gpu::Table>`: tables produced on the device (eq tables,
-// Az/Bz/Cz, bound polynomials, product-circuit layers) stay there; `Z` is only materialised by `download()` when host code
-// indexes it.
+// Az/Bz/Cz, bound polynomials, product-circuit layers, views into the SPARK dense representation) stay there; `Z` is only
+// materialised by `download()` when host code indexes it. The C++ rendering is spartan_amd/host/prover.cc (poly_commit,
+// polyeval_prove) — same calls, same order.
 use super::gpu;
 
 impl DensePolynomial {
+  /// A polynomial that lives on the device: `len` elements of table `t` (an owned table or a view, gpu::Table::view).
+  #[cfg(feature = "gpu")]
+  pub fn from_dev(t: gpu::Table) -> Self {
+    let len = t.len();
+    DensePolynomial { num_vars: len.log_2(), len, Z: Vec::new(), dev: Some(t) }
+  }
+  #[cfg(feature = "gpu")]
+  fn table(&self) -> std::borrow::Cow<'_, gpu::Table> {
+    match &self.dev {
+      Some(t) => std::borrow::Cow::Borrowed(t),
+      None => std::borrow::Cow::Owned(gpu::Table::upload(&self.Z)), // sp_table_upload
+    }
+  }
+
   /// DensePolynomial::commit_inner (:164-177): L row commitments in one call.
   #[cfg(feature = "gpu")]
   fn commit_inner(&self, blinds: &[Scalar], gens: &MultiCommitGens) -> PolyCommitment {
@@ -12,38 +27,61 @@ impl DensePolynomial {
     let R_size = self.len() / L_size;
     assert_eq!(L_size * R_size, self.len());
     assert_eq!(gens.n, R_size);
+    let d = &gens.dev;
+    let t = self.table();
     let mut out = vec![0u8; 32 * L_size];
-    let g = gpu::gens_for(gens); // points G[0..n), h at index n
-    match &self.dev {
-      Some(t) => gpu::ok(unsafe {
-        gpu::sp_commit_rows_dev(gpu::ctx(), g, 0, gens.n, t.0, 0, L_size, R_size, gpu::limbs(blinds), out.as_mut_ptr())
-      }),
-      None => gpu::ok(unsafe {
-        gpu::sp_commit_rows(gpu::ctx(), g, 0, gens.n, gpu::limbs(&self.Z), L_size, R_size, gpu::limbs(blinds), out.as_mut_ptr())
-      }),
-    }
-    PolyCommitment {
-      C: out.chunks_exact(32).map(|c| CompressedGroup::from_slice(c)).collect(),
-    }
+    gpu::ok(unsafe {
+      gpu::sp_commit_rows_dev(gpu::ctx(), d.g, d.G[0] as usize, d.h as usize, t.0, 0, L_size, R_size, gpu::limbs(blinds), out.as_mut_ptr())
+    });
+    PolyCommitment { C: out.chunks_exact(32).map(CompressedGroup::from_slice).collect() }
   }
 
-  /// DensePolynomial::bound (:206-213): LZ = L * Z.
+  /// rows [row0, row0 + rows) of the L x R layout, no blinds, synchronous (a handful of rows left over next to a background job)
   #[cfg(feature = "gpu")]
-  pub fn bound(&self, L: &[Scalar]) -> Vec<Scalar> {
-    let (left_num_vars, right_num_vars) = EqPolynomial::compute_factored_lens(self.get_num_vars());
-    let (L_size, R_size) = (left_num_vars.pow2(), right_num_vars.pow2());
-    assert_eq!(L.len(), L_size);
-    let owned;
-    let t = match &self.dev {
-      Some(t) => t,
-      None => {
-        owned = gpu::Table::upload(&self.Z);
-        &owned
-      }
-    };
-    let mut out = vec![Scalar::zero(); R_size];
-    gpu::ok(unsafe { gpu::sp_vecmat(gpu::ctx(), gpu::limbs(L), L_size, t.0, gpu::limbs_mut(&mut out)) });
-    out
+  pub fn commit_rows_sync(&self, gens: &MultiCommitGens, row0: usize, rows: usize) -> Vec<CompressedGroup> {
+    let d = &gens.dev;
+    let t = self.dev.as_ref().expect("device-resident polynomial");
+    let mut out = vec![0u8; 32 * rows];
+    gpu::ok(unsafe { gpu::sp_commit_rows_dev(gpu::ctx(), d.g, d.G[0] as usize, d.h as usize, t.0, row0 * gens.n, rows, gens.n, std::ptr::null(), out.as_mut_ptr()) });
+    out.chunks_exact(32).map(CompressedGroup::from_slice).collect()
+  }
+
+  /// The same commitment queued on the context's main stream without waiting (rows > 8): the caller does host work — R1CSProof::prove
+  /// absorbs the transcript prefix while the witness commitment is computed — and collects it with `CommitJob::wait`.
+  #[cfg(feature = "gpu")]
+  pub fn commit_start(&self, blinds: Option<&[Scalar]>, gens: &MultiCommitGens, row0: usize, rows: usize) -> gpu::CommitJob {
+    let R_size = gens.n;
+    let d = &gens.dev;
+    let t = self.dev.as_ref().expect("device-resident polynomial");
+    let mut job = std::ptr::null_mut();
+    gpu::ok(unsafe {
+      gpu::sp_commit_rows_dev_start(gpu::ctx(), d.g, d.G[0] as usize, d.h as usize, t.0, row0 * R_size, rows, R_size,
+                                    blinds.map_or(std::ptr::null(), |b| gpu::limbs(b)), &mut job)
+    });
+    gpu::CommitJob { job, rows } // wait(): sp_job_wait -> Vec<CompressedGroup>
+  }
+  /// ... and on the low-priority background stream (no blinds; persistent workgroups on half the CUs), for a commitment that
+  /// can run under latency-bound work: the row half of `derefs`, started as soon as rx is known (seams/lib.rs).
+  #[cfg(feature = "gpu")]
+  pub fn commit_begin_background(&self, gens: &MultiCommitGens, row0: usize, rows: usize) -> gpu::CommitJob {
+    let R_size = gens.n;
+    let d = &gens.dev;
+    let t = self.dev.as_ref().expect("device-resident polynomial");
+    let mut job = std::ptr::null_mut();
+    gpu::ok(unsafe { gpu::sp_commit_rows_dev_begin(gpu::ctx(), d.g, d.G[0] as usize, t.0, row0 * R_size, rows, R_size, &mut job) });
+    gpu::CommitJob { job, rows }
+  }
+
+  /// DensePolynomial::bound (:206-213): LZ = L * Z, left on the device (PolyEvalProof::prove only commits to it and feeds it to
+  /// the inner-product argument). Queued, not waited for: the caller computes the R vector meanwhile.
+  #[cfg(feature = "gpu")]
+  pub fn bound_dev(&self, L: &[Scalar]) -> gpu::Table {
+    let (left_num_vars, _right_num_vars) = EqPolynomial::compute_factored_lens(self.get_num_vars());
+    assert_eq!(L.len(), left_num_vars.pow2());
+    let t = self.table();
+    let mut lz = std::ptr::null_mut();
+    gpu::ok(unsafe { gpu::sp_vecmat_dev(gpu::ctx(), gpu::limbs(L), L.len(), t.0, &mut lz) });
+    gpu::Table(lz)
   }
 
   /// DensePolynomial::bound_poly_var_top (:215-223).
@@ -60,14 +98,7 @@ impl DensePolynomial {
   #[cfg(feature = "gpu")]
   pub fn evaluate(&self, r: &[Scalar]) -> Scalar {
     assert_eq!(r.len(), self.get_num_vars());
-    let owned;
-    let t = match &self.dev {
-      Some(t) => t,
-      None => {
-        owned = gpu::Table::upload(&self.Z);
-        &owned
-      }
-    };
+    let t = self.table();
     let mut out = Scalar::zero();
     gpu::ok(unsafe { gpu::sp_evaluate(gpu::ctx(), t.0, gpu::limbs(r), r.len(), &mut out as *mut Scalar as *mut u64) });
     out
@@ -78,6 +109,33 @@ impl EqPolynomial {
   /// EqPolynomial::evals (:68-84) as a device table (r[0] <-> most significant index bit, as in the reference).
   #[cfg(feature = "gpu")]
   pub fn evals_dev(&self) -> gpu::Table {
-    gpu::Table::eq(&self.r)
+    gpu::Table::eq(&self.r) // sp_eq_expand
+  }
+}
+
+impl PolyEvalProof {
+  /// PolyEvalProof::prove (:312-365).
+  #[cfg(feature = "gpu")]
+  pub fn prove(
+    poly: &DensePolynomial, blinds_opt: Option<&PolyCommitmentBlinds>, r: &[Scalar], Zr: &Scalar, blind_Zr_opt: Option<&Scalar>,
+    gens: &PolyCommitmentGens, transcript: &mut Transcript, random_tape: &mut RandomTape,
+  ) -> (PolyEvalProof, CompressedGroup) {
+    transcript.append_protocol_name(PolyEvalProof::protocol_name());
+    assert_eq!(poly.get_num_vars(), r.len());
+    let (left_num_vars, right_num_vars) = EqPolynomial::compute_factored_lens(r.len());
+    let (L_size, _R_size) = (left_num_vars.pow2(), right_num_vars.pow2());
+    // the sqrt(N)-sized L and R vectors stay on the host (compute_factored_evals, :90-98); L first: the device multiplies
+    // while R is computed
+    let L = EqPolynomial::new(r[..left_num_vars].to_vec()).evals();
+    let LZ = poly.bound_dev(&L);
+    let R = EqPolynomial::new(r[left_num_vars..].to_vec()).evals();
+    let LZ_blind: Scalar = match blinds_opt {
+      Some(b) => { assert_eq!(b.blinds.len(), L_size); (0..L.len()).map(|i| b.blinds[i] * L[i]).sum() }
+      None => Scalar::zero(),
+    };
+    let zero = Scalar::zero();
+    let blind_Zr = blind_Zr_opt.map_or(&zero, |p| p);
+    let (proof, _C_LR, C_Zr_prime) = DotProductProofLog::prove_dev(&gens.gens, transcript, random_tape, &LZ, &LZ_blind, &R, Zr, blind_Zr);
+    (PolyEvalProof { proof }, C_Zr_prime)
   }
 }

@@ -1,9 +1,261 @@
-// src/sumcheck.rs — SumcheckInstanceProof::prove_cubic_batched (:254-424) under `--features gpu`.
-// The round body (:287-357 evaluations, :379-393 binds) is one C-ABI call per round, exactly as the C++ host driver issues
-// it (spartan_amd/host/spark.inc: prove_cubic_batched): sp_sumcheck_eval_batched once, then sp_sumcheck_bind_eval_batched
-// per round (bind at r_j fused with the next round's evaluations), and sp_table_bind_top_heads for the last round, which
-// also returns the final claims (:395-419). Every transcript operation stays where the reference has it.
-// comb_func is always the cubic product on this path (product_tree.rs:316-318), which is what the kernels compute.
+// src/sumcheck.rs — the provers under `--features gpu`. Every polynomial is a device table (DensePolynomial.dev, see
+// seams/dense_mlpoly.rs); the round bodies are C-ABI calls; every transcript and tape operation stays here, in the
+// reference's order. The executable rendering of exactly these bodies is spartan_amd/host/prover.cc (zk_sumcheck_prove) and
+// spartan_amd/host/spark.inc (prove_cubic_batched_v2, prove_cubic_batched): same calls, same order, byte-identical proofs.
+use super::commitments::commit_small;
+use super::gpu::{self, sp_host_point, sp_table};
+
+// ------------------------------------------------------------------------------------------------------------------
+// ZKSumcheckInstanceProof::prove_quad (:428-586, kind 0: A*B over gens_3) and ::prove_cubic_with_additive_term (:588-776,
+// kind 2: A*(B*C - D) over gens_4) share everything but `kind`.
+// Round j: the device binds the tables at r_j and evaluates round j+1 in the same pass (sp_sumcheck_bind_eval_start ..
+// _collect) while this core commits: comm_eval, the DotProductProof's delta, Cy, beta and the next comm_poly are 2..5-term
+// commitments under (gens_n.G.., gens_n.h, gens_1.G, gens_1.h) — ONE index list serves them all. Everything in them that
+// depends on the tape alone (delta entirely; the blind terms of comm_eval, beta, comm_poly) is computed AHEAD of the rounds by
+// the library's helper thread (sp_host_zk_ahead_*): inside the round loop nothing but DotProductProof::prove draws from the
+// tape (d_vec, r_delta, r_beta: nizk/mod.rs:330-334), so the rounds' draws are taken up front, in the reference's order.
+#[cfg(feature = "gpu")]
+impl ZKSumcheckInstanceProof {
+  pub fn prove_zk_gpu(
+    kind: i32, // 0: prove_quad, 2: prove_cubic_with_additive_term
+    claim: &Scalar,
+    blind_claim: &Scalar,
+    num_rounds: usize,
+    polys: &mut [&mut DensePolynomial], // (A, B) or (A, B, C, D), device-resident
+    gens_1: &MultiCommitGens,
+    gens_n: &MultiCommitGens,
+    transcript: &mut Transcript,
+    random_tape: &mut RandomTape,
+  ) -> (Self, Vec<Scalar>, Vec<Scalar>, Scalar) {
+    let blinds_poly = random_tape.random_vector(b"blinds_poly", num_rounds);
+    let blinds_evals = random_tape.random_vector(b"blinds_evals", num_rounds);
+    let tabs: Vec<*mut sp_table> = polys.iter().map(|p| p.dev.as_ref().expect("device-resident polynomial").0).collect();
+    let (gn, g1) = (&gens_n.dev, &gens_1.dev);
+    assert!(gn.g == g1.g); // both are prefixes of the "gens_r1cs_sat" stream
+    let nn = gens_n.n;
+    let mut idx_u: Vec<u32> = gn.G.clone();
+    idx_u.extend_from_slice(&[gn.h, g1.G[0], g1.h]);
+    let W = idx_u.len();
+    let on_host = gpu::small_msm_on_host();
+
+    // the rounds' tape draws, up front (same stream of draws as the reference's loop: see the header)
+    let mut d_all: Vec<Scalar> = Vec::new();
+    let (mut r_delta_all, mut r_beta_all) = (Vec::new(), Vec::new());
+    let ahead = if on_host {
+      for _ in 0..num_rounds {
+        d_all.extend(random_tape.random_vector(b"d_vec", nn));
+        r_delta_all.push(random_tape.random_scalar(b"r_delta"));
+        r_beta_all.push(random_tape.random_scalar(b"r_beta"));
+      }
+      let mut h = std::ptr::null_mut();
+      gpu::ok(unsafe {
+        gpu::sp_host_zk_ahead_begin(gn.g, idx_u.as_ptr(), W, nn, num_rounds, gpu::limbs(&blinds_poly), gpu::limbs(&blinds_evals), gpu::limbs(&d_all),
+                                    gpu::limbs(&r_delta_all), gpu::limbs(&r_beta_all), &mut h)
+      });
+      Some(gpu::ZkAhead::new(h, num_rounds)) // sp_host_zk_ahead_wait per round, sp_host_zk_ahead_free on drop
+    } else {
+      None
+    };
+    // rows of scalars over idx_u -> encoded commitments (+ a point computed ahead, host mode)
+    let commit_rows = |rows: &[Scalar], nrows: usize, addend: Option<&[*const sp_host_point]>| commit_small(gn.g, &idx_u, rows, nrows, addend);
+    let make_poly = |ev: &[Scalar], cl: &Scalar| {
+      if kind == 0 { UniPoly::from_evals(&[ev[0], cl - ev[0], ev[1]]) } else { UniPoly::from_evals(&[ev[0], cl - ev[0], ev[1], ev[2]]) }
+    };
+
+    let mut ev = vec![Scalar::zero(); 3];
+    gpu::ok(unsafe { gpu::sp_sumcheck_eval(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs_mut(&mut ev)) });
+    let mut claim_per_round = *claim;
+    let mut poly = make_poly(&ev, &claim_per_round);
+    assert_eq!(poly.as_vec().len(), nn);
+    // comm_claim_per_round (:448 / :611) and the first comm_poly (:473 / :661) in one call
+    let (mut comm_claim_per_round, mut comm_poly) = {
+      let mut rows = vec![Scalar::zero(); 2 * W];
+      rows[nn + 1] = claim_per_round;
+      rows[nn + 2] = *blind_claim;
+      rows[W..W + nn].copy_from_slice(&poly.as_vec());
+      if !on_host { rows[W + nn] = blinds_poly[0]; }
+      let add = ahead.as_ref().map(|a| [std::ptr::null(), a.wait(0).bp_hn()]);
+      let cm = commit_rows(&rows, 2, add.as_ref().map(|a| &a[..]));
+      (cm[0], cm[1])
+    };
+
+    let (mut r, mut comm_polys, mut comm_evals, mut proofs) = (Vec::new(), Vec::new(), Vec::new(), Vec::new());
+    for j in 0..num_rounds {
+      comm_poly.append_to_transcript(b"comm_poly", transcript);
+      comm_polys.push(comm_poly);
+      let r_j = transcript.challenge_scalar(b"challenge_nextround");
+      let more = j + 1 < num_rounds;
+      let eval = poly.evaluate(&r_j);
+      let (d, r_delta, r_beta) = if on_host {
+        (d_all[j * nn..(j + 1) * nn].to_vec(), r_delta_all[j], r_beta_all[j])
+      } else {
+        (random_tape.random_vector(b"d_vec", nn), random_tape.random_scalar(b"r_delta"), random_tape.random_scalar(b"r_beta"))
+      };
+      // bind every table at r_j (:485-486 / :673-676), fused with the next round's evaluations (:460-469 / :624-652)
+      let len = unsafe { gpu::sp_table_len(tabs[0]) };
+      let (comm_eval, delta, pending);
+      if on_host {
+        if len >= 4 {
+          gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_start(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs1(&r_j)) });
+          pending = true;
+        } else {
+          gpu::ok(unsafe { gpu::sp_table_bind_top(gpu::ctx(), tabs.as_ptr(), tabs.len(), gpu::limbs1(&r_j)) });
+          pending = false;
+        }
+        let aj = ahead.as_ref().unwrap().wait(j);
+        let mut row = vec![Scalar::zero(); W];
+        row[nn + 1] = eval; // comm_eval = eval * G1 + blinds_evals[j] * h: the blind term comes from `ahead`
+        comm_eval = commit_rows(&row, 1, Some(&[aj.be_h()]))[0];
+        delta = aj.delta(); // commit(d_j, r_delta_j) under gens_n: complete
+      } else {
+        pending = false;
+        let mut rows1 = vec![Scalar::zero(); 2 * W];
+        rows1[nn + 1] = eval;
+        rows1[nn + 2] = blinds_evals[j];
+        rows1[W..W + nn].copy_from_slice(&d);
+        rows1[W + nn] = r_delta;
+        if len >= 4 {
+          // all-device variant: the round's r-dependent commitments next to the bind, one completion wait
+          let mut pts = [0u8; 64];
+          gpu::ok(unsafe {
+            gpu::sp_sumcheck_bind_eval_commit(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev), gn.g, idx_u.as_ptr(), W,
+                                              gpu::limbs(&rows1), 2, pts.as_mut_ptr())
+          });
+          comm_eval = CompressedGroup::from_slice(&pts[..32]);
+          delta = CompressedGroup::from_slice(&pts[32..]);
+        } else {
+          gpu::ok(unsafe { gpu::sp_table_bind_top(gpu::ctx(), tabs.as_ptr(), tabs.len(), gpu::limbs1(&r_j)) });
+          let cm = commit_rows(&rows1, 2, None);
+          comm_eval = cm[0];
+          delta = cm[1];
+        }
+      }
+      comm_claim_per_round.append_to_transcript(b"comm_claim_per_round", transcript);
+      comm_eval.append_to_transcript(b"comm_eval", transcript);
+      let w = transcript.challenge_vector(b"combine_two_claims_to_one", 2);
+      let target = w[0] * claim_per_round + w[1] * eval;
+      let blind_sc = if j == 0 { *blind_claim } else { blinds_evals[j - 1] };
+      let blind = w[0] * blind_sc + w[1] * blinds_evals[j];
+      // a = w[0] * a_sc + w[1] * a_eval (:509-533 / :699-723)
+      let mut a = Vec::with_capacity(nn);
+      let mut pw = Scalar::one();
+      for i in 0..nn {
+        let a_sc = if i == 0 { Scalar::one() + Scalar::one() } else { Scalar::one() };
+        a.push(w[0] * a_sc + w[1] * pw);
+        pw *= r_j;
+      }
+      // DotProductProof::prove (nizk/mod.rs:311-370): x = poly.coeffs, blind_x = blinds_poly[j], y = target, blind_y = blind
+      transcript.append_protocol_name(b"dot product proof");
+      comm_poly.append_to_transcript(b"Cx", transcript); // Cx = commit(x, blind_x): same inputs and generators as comm_poly
+      let dp: Scalar = (0..nn).map(|i| a[i] * d[i]).sum();
+      // Cy = target * G1 + blind * h ; beta = dp * G1 + r_beta * h ; and the next round's comm_poly
+      let coeffs = poly.as_vec();
+      let (Cy, beta, next);
+      if on_host {
+        let mut rows2 = vec![Scalar::zero(); 2 * W];
+        rows2[nn + 1] = target;
+        rows2[nn + 2] = blind;
+        rows2[W + nn + 1] = dp; // + r_beta * h from `ahead`
+        let cm2 = commit_rows(&rows2, 2, Some(&[std::ptr::null(), ahead.as_ref().unwrap().wait(j).rb_h()]));
+        Cy = cm2[0];
+        beta = cm2[1];
+        if pending { gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_collect(gpu::ctx(), gpu::limbs_mut(&mut ev)) }); }
+        next = if more {
+          assert!(pending);
+          let np = make_poly(&ev, &eval);
+          let mut row3 = vec![Scalar::zero(); W];
+          row3[..nn].copy_from_slice(&np.as_vec());
+          let cp = commit_rows(&row3, 1, Some(&[ahead.as_ref().unwrap().wait(j + 1).bp_hn()]))[0];
+          Some((np, cp))
+        } else { None };
+      } else {
+        let nrows2 = if more { 3 } else { 2 };
+        let mut rows2 = vec![Scalar::zero(); nrows2 * W];
+        rows2[nn + 1] = target;
+        rows2[nn + 2] = blind;
+        rows2[W + nn + 1] = dp;
+        rows2[W + nn + 2] = r_beta;
+        let np = if more { Some(make_poly(&ev, &eval)) } else { None };
+        if let Some(p) = &np {
+          rows2[2 * W..2 * W + nn].copy_from_slice(&p.as_vec());
+          rows2[2 * W + nn] = blinds_poly[j + 1];
+        }
+        let cm2 = commit_rows(&rows2, nrows2, None);
+        Cy = cm2[0];
+        beta = cm2[1];
+        next = np.map(|p| (p, cm2[2]));
+      }
+      Cy.append_to_transcript(b"Cy", transcript);
+      a.append_to_transcript(b"a", transcript);
+      delta.append_to_transcript(b"delta", transcript);
+      beta.append_to_transcript(b"beta", transcript);
+      let c = transcript.challenge_scalar(b"c");
+      let z = (0..nn).map(|i| c * coeffs[i] + d[i]).collect::<Vec<Scalar>>();
+      proofs.push(DotProductProof { delta, beta, z, z_delta: c * blinds_poly[j] + r_delta, z_beta: c * blind + r_beta });
+      claim_per_round = eval;
+      comm_claim_per_round = comm_eval;
+      comm_evals.push(comm_eval);
+      r.push(r_j);
+      if let Some((np, cp)) = next { poly = np; comm_poly = cp; }
+    }
+    let mut final_claims = vec![Scalar::zero(); tabs.len()];
+    gpu::ok(unsafe { gpu::sp_table_heads(gpu::ctx(), tabs.as_ptr(), tabs.len(), gpu::limbs_mut(&mut final_claims)) });
+    for p in polys.iter_mut() { p.num_vars -= num_rounds; p.len >>= num_rounds; }
+    (ZKSumcheckInstanceProof::new(comm_polys, comm_evals, proofs), r, final_claims, blinds_evals[num_rounds - 1])
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SumcheckInstanceProof::prove_cubic_batched (:254-424). comb_func is the cubic product on this path
+// (product_tree.rs:316-318). Long tables: one round per call, the bind at r_j fused with round j+1's evaluations
+// (sp_sumcheck_eval_batched, then sp_sumcheck_bind_eval_batched). Short tables (<= 512 entries: ~290 of the 361 rounds of a 2^20
+// proof, each a latency-bound trip): TWO rounds per call — the evaluations of the round after a bind are a cubic in that bind's
+// challenge,  E(t; r) = (1-r)^3 M0 + (1-r)^2 r M1 + (1-r) r^2 M2 + r^3 M3,  M1 = (T1-T2)/2 - M3,  M2 = (T1+T2)/2 - M0,
+// and the device returns (M0, M3, T1, T2) for t = 0, 2, 3 next to a round's evaluations (sp_sumcheck_eval_coeffs_batched /
+// sp_sumcheck_bind2_eval_batched), already weighted by `coeffs` and summed over the instances. Once the tables have at most 8
+// entries the same call hands them over (.._tables_batched) and the last <= 3 rounds run here with the reference's own loop
+// body. Exact field arithmetic throughout: same values, same transcript, same bytes as the one-round form.
+#[cfg(feature = "gpu")]
+fn evals_from_coeffs(S: &[Scalar], r: &Scalar) -> [Scalar; 3] {
+  let half = (2_usize).to_scalar().invert().unwrap();
+  let om = Scalar::one() - r;
+  let (w0, w1, w2, w3) = (om * om * om, om * om * r, om * r * r, r * r * r);
+  let mut ev = [Scalar::zero(); 3];
+  for k in 0..3 {
+    let (M0, M3, T1, T2) = (S[4 * k], S[4 * k + 1], S[4 * k + 2], S[4 * k + 3]);
+    let (M1, M2) = ((T1 - T2) * half - M3, (T1 + T2) * half - M0);
+    ev[k] = M0 * w0 + M1 * w1 + M2 * w2 + M3 * w3;
+  }
+  ev
+}
+/// The last rounds on tables of m <= 8 entries, tab = [instance][A, B, C][m]: the reference's loop body (:290-393) verbatim in
+/// structure; `message` appends the round's polynomial and returns its challenge.
+#[cfg(feature = "gpu")]
+fn cubic_tail_rounds(tab: &mut [Scalar], ni: usize, m_in: usize, coeffs: &[Scalar], message: &mut dyn FnMut([Scalar; 3]) -> Scalar) {
+  let mut m = m_in;
+  while m >= 2 {
+    let h = m / 2;
+    let mut evc = [Scalar::zero(); 3];
+    for i in 0..ni {
+      let at = |k: usize, z: usize| tab[(i * 3 + k) * m_in + z];
+      let (mut e0, mut e2, mut e3) = (Scalar::zero(), Scalar::zero(), Scalar::zero());
+      for z in 0..h {
+        let (a0, a1, b0, b1, c0, c1) = (at(0, z), at(0, h + z), at(1, z), at(1, h + z), at(2, z), at(2, h + z));
+        let (a2, b2, c2) = (a1 + a1 - a0, b1 + b1 - b0, c1 + c1 - c0);
+        let (a3, b3, c3) = (a2 + a1 - a0, b2 + b1 - b0, c2 + c1 - c0);
+        e0 += a0 * b0 * c0; e2 += a2 * b2 * c2; e3 += a3 * b3 * c3;
+      }
+      evc[0] += e0 * coeffs[i]; evc[1] += e2 * coeffs[i]; evc[2] += e3 * coeffs[i];
+    }
+    let r = message(evc);
+    for i in 0..ni { for k in 0..3 { for z in 0..h {
+      let (lo, hi) = (tab[(i * 3 + k) * m_in + z], tab[(i * 3 + k) * m_in + h + z]);
+      tab[(i * 3 + k) * m_in + z] = lo + r * (hi - lo);
+    } } }
+    m = h;
+  }
+}
+
 #[cfg(feature = "gpu")]
 impl SumcheckInstanceProof {
   pub fn prove_cubic_batched_gpu(
@@ -14,7 +266,6 @@ impl SumcheckInstanceProof {
     coeffs: &[Scalar],
     transcript: &mut Transcript,
   ) -> (Self, Vec<Scalar>, (Vec<Scalar>, Vec<Scalar>, Scalar), (Vec<Scalar>, Vec<Scalar>, Vec<Scalar>)) {
-    use super::gpu::{self, sp_table};
     let (poly_A_vec_par, poly_B_vec_par, poly_C_par) = poly_vec_par;
     let (poly_A_vec_seq, poly_B_vec_seq, poly_C_vec_seq) = poly_vec_seq;
     let (np, ns) = (poly_A_vec_par.len(), poly_A_vec_seq.len());
@@ -27,47 +278,188 @@ impl SumcheckInstanceProof {
     A.extend(poly_A_vec_seq.iter().map(|p| dev(p)));
     B.extend(poly_B_vec_seq.iter().map(|p| dev(p)));
     C.extend(poly_C_vec_seq.iter().map(|p| dev(p)));
-    // every table once, for the last round: A_i, B_i interleaved, then the distinct C tables
+    // every table once: A_i, B_i interleaved, then the distinct C tables (the order of the final claims)
     let mut all: Vec<*mut sp_table> = Vec::with_capacity(2 * ni + 1 + ns);
-    for i in 0..ni {
-      all.push(A[i]);
-      all.push(B[i]);
-    }
+    for i in 0..ni { all.push(A[i]); all.push(B[i]); }
     all.push(dev(poly_C_par));
     all.extend(poly_C_vec_seq.iter().map(|p| dev(p)));
+    let (ap, bp, cp, c) = (A.as_ptr(), B.as_ptr(), C.as_ptr(), gpu::ctx());
+    let null = std::ptr::null_mut::<u64>();
 
     let mut e = *claim;
     let mut r: Vec<Scalar> = Vec::new();
     let mut cubic_polys: Vec<CompressedUniPoly> = Vec::new();
-    let mut ev = vec![Scalar::zero(); 3 * ni]; // (eval_point_0, eval_point_2, eval_point_3) per instance
+    let mut ev = vec![Scalar::zero(); 3 * ni]; // per-instance evaluations (one round per launch)
+    let mut evc = [Scalar::zero(); 3];         // combined with coeffs (:359-369)
+    let mut S = vec![Scalar::zero(); 12];      // the cubic that gives the next round's evaluations
     let mut heads = vec![Scalar::zero(); all.len()];
-    let mut have_heads = false;
-    if num_rounds > 0 {
-      gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(gpu::ctx(), A.as_ptr(), B.as_ptr(), C.as_ptr(), ni, gpu::limbs_mut(&mut ev)) });
-    }
-    for _j in 0..num_rounds {
-      let evals_combined_0: Scalar = (0..ni).map(|i| ev[3 * i] * coeffs[i]).sum();
-      let evals_combined_2: Scalar = (0..ni).map(|i| ev[3 * i + 1] * coeffs[i]).sum();
-      let evals_combined_3: Scalar = (0..ni).map(|i| ev[3 * i + 2] * coeffs[i]).sum();
-      let evals = vec![evals_combined_0, e - evals_combined_0, evals_combined_2, evals_combined_3];
-      let poly = UniPoly::from_evals(&evals);
+    let mut tail = vec![Scalar::zero(); 3 * 8 * ni];
+    let (mut have_heads, mut have_S) = (false, false);
+    let tail_ok = std::env::var_os("SPARTAN_NO_HOST_TAIL").is_none() && np >= 1 && ni <= 21;
+    let dmax = gpu::double_round_max_len(); // 512 (SPARTAN_DOUBLE_ROUND_MAX_LEN)
+    let len_of = |t: *mut sp_table| unsafe { gpu::sp_table_len(t) };
+    // :370-381 and :395-396: the round's cubic, its transcript message, the challenge
+    let mut round_message = |evc: &[Scalar; 3], e: &mut Scalar, r: &mut Vec<Scalar>, polys: &mut Vec<CompressedUniPoly>, transcript: &mut Transcript| {
+      let poly = UniPoly::from_evals(&[evc[0], *e - evc[0], evc[1], evc[2]]);
       poly.append_to_transcript(b"poly", transcript);
       let r_j = transcript.challenge_scalar(b"challenge_nextround");
       r.push(r_j);
-      let len = unsafe { gpu::sp_table_len(A[0]) };
-      if len >= 4 {
-        gpu::ok(unsafe {
-          gpu::sp_sumcheck_bind_eval_batched(gpu::ctx(), A.as_ptr(), B.as_ptr(), C.as_ptr(), ni, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev))
-        });
-      } else {
-        gpu::ok(unsafe { gpu::sp_table_bind_top_heads(gpu::ctx(), all.as_ptr(), all.len(), gpu::limbs1(&r_j), gpu::limbs_mut(&mut heads)) });
+      *e = poly.evaluate(&r_j);
+      polys.push(poly.compress());
+      r_j
+    };
+    let combine = |ev: &[Scalar]| -> [Scalar; 3] {
+      let mut o = [Scalar::zero(); 3];
+      for i in 0..ni { o[0] += ev[3 * i] * coeffs[i]; o[1] += ev[3 * i + 1] * coeffs[i]; o[2] += ev[3 * i + 2] * coeffs[i]; }
+      o
+    };
+    let tail_given = |tail: &[Scalar]| gpu::limbs_of(&tail[0]) != [!0u64, 0, 0, 0];
+    let mark = |tail: &mut [Scalar]| gpu::set_limbs(&mut tail[0], [!0u64, 0, 0, 0]);
+
+    let mut j = 0usize;
+    // the last rounds on this core: (m entries per table in `tail`) -> final claims in `heads`
+    macro_rules! finish_on_host { ($m:expr) => {{
+      let m = $m;
+      cubic_tail_rounds(&mut tail, ni, m, coeffs, &mut |evs| { j += 1; round_message(&evs, &mut e, &mut r, &mut cubic_polys, transcript) });
+      for i in 0..ni { heads[2 * i] = tail[(i * 3) * m]; heads[2 * i + 1] = tail[(i * 3 + 1) * m]; }
+      heads[2 * ni] = tail[2 * m]; // poly_C_par is instance 0's C
+      for k in 0..ns { heads[2 * ni + 1 + k] = tail[((np + k) * 3 + 2) * m]; }
+      have_heads = true;
+    }} }
+
+    if gpu::trip_rounds() == 3 {
+      // ---- up to THREE rounds per trip: the grid form (A/B option; spark.inc prove_cubic_batched, default off) -------------
+      // sp_sumcheck_grid_batched returns F on {0,1,2,3}^kd; round: s(t) = sum of F(t, b) over b in {0,1}^(axes-1); then the first
+      // axis is contracted at the challenge with the Lagrange basis of {0, 1, 2, 3}.
+      let gmax = gpu::grid_max_len();
+      let mut pend: Vec<Scalar> = Vec::new();
+      let (mut F, mut axes): (Vec<Scalar>, usize) = (Vec::new(), 0);
+      while j < num_rounds {
+        if axes == 0 {
+          let eff = len_of(A[0]) >> pend.len();
+          if tail_ok && eff <= 8 {
+            mark(&mut tail);
+            gpu::ok(unsafe { gpu::sp_sumcheck_grid_batched(c, ap, bp, cp, ni, gpu::limbs(&pend), pend.len(), gpu::limbs(coeffs), 0, null, gpu::limbs_mut(&mut tail)) });
+            assert!(tail_given(&tail));
+            pend.clear();
+            finish_on_host!(eff);
+            break;
+          }
+          if eff <= gmax {
+            let left = eff.log_2() - if tail_ok { 3 } else { 0 };
+            let kd = left.min(3).min(num_rounds - j);
+            F = vec![Scalar::zero(); 1 << (2 * kd)];
+            gpu::ok(unsafe { gpu::sp_sumcheck_grid_batched(c, ap, bp, cp, ni, gpu::limbs(&pend), pend.len(), gpu::limbs(coeffs), kd, gpu::limbs_mut(&mut F), null) });
+            axes = kd;
+            pend.clear();
+          } else {
+            if pend.is_empty() { gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) }); }
+            else { gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&pend[0]), gpu::limbs_mut(&mut ev)) }); pend.clear(); }
+            evc = combine(&ev);
+            pend.push(round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript));
+            j += 1;
+            continue;
+          }
+        }
+        let S4 = 1usize << (2 * (axes - 1));
+        let mut s = [Scalar::zero(); 4];
+        for t in 0..4 { for m in 0..(1usize << (axes - 1)) {
+          let idx: usize = (0..axes - 1).map(|i| ((m >> i) & 1) << (2 * i)).sum();
+          s[t] += F[t * S4 + idx];
+        } }
+        evc = [s[0], s[2], s[3]]; // s[1] = e - s[0] by the sum-check invariant
+        let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+        let (inv2, inv6) = ((2_usize).to_scalar().invert().unwrap(), (6_usize).to_scalar().invert().unwrap());
+        let (r1, r2, r3) = (r_j - Scalar::one(), r_j - Scalar::one() - Scalar::one(), r_j - Scalar::one() - Scalar::one() - Scalar::one());
+        let (L0, L1, L2, L3) = (-(r1 * r2 * r3 * inv6), r_j * r2 * r3 * inv2, -(r_j * r1 * r3 * inv2), r_j * r1 * r2 * inv6);
+        F = (0..S4).map(|i| L0 * F[i] + L1 * F[S4 + i] + L2 * F[2 * S4 + i] + L3 * F[3 * S4 + i]).collect();
+        axes -= 1;
+        pend.push(r_j);
+        j += 1;
+      }
+      if !have_heads {
+        if !pend.is_empty() && ni <= 21 {
+          mark(&mut tail);
+          gpu::ok(unsafe { gpu::sp_sumcheck_grid_batched(c, ap, bp, cp, ni, gpu::limbs(&pend), pend.len(), gpu::limbs(coeffs), 0, null, gpu::limbs_mut(&mut tail)) });
+          for i in 0..ni { heads[2 * i] = tail[i * 3]; heads[2 * i + 1] = tail[i * 3 + 1]; }
+          heads[2 * ni] = tail[2];
+          for k in 0..ns { heads[2 * ni + 1 + k] = tail[(np + k) * 3 + 2]; }
+        } else {
+          for k in 0..pend.len().saturating_sub(1) { gpu::ok(unsafe { gpu::sp_table_bind_top(c, all.as_ptr(), all.len(), gpu::limbs1(&pend[k])) }); }
+          if let Some(last) = pend.last() { gpu::ok(unsafe { gpu::sp_table_bind_top_heads(c, all.as_ptr(), all.len(), gpu::limbs1(last), gpu::limbs_mut(&mut heads)) }); }
+          else { gpu::ok(unsafe { gpu::sp_table_heads(c, all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) }); }
+        }
         have_heads = true;
       }
-      e = poly.evaluate(&r_j);
-      cubic_polys.push(poly.compress());
-    }
-    if !have_heads {
-      gpu::ok(unsafe { gpu::sp_table_heads(gpu::ctx(), all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) });
+    } else {
+      // ---- TWO rounds per trip on short tables (the default) ---------------------------------------------------------------
+      if num_rounds > 0 {
+        let len0 = len_of(A[0]);
+        if tail_ok && len0 >= 2 && len0 <= 8 {
+          mark(&mut tail);
+          gpu::ok(unsafe {
+            gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, std::ptr::null(), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc),
+                                                       if len0 >= 4 { gpu::limbs_mut(&mut S) } else { null }, null, gpu::limbs_mut(&mut tail))
+          });
+          assert!(tail_given(&tail));
+          finish_on_host!(len0);
+        } else if len0 >= 4 && len0 <= dmax {
+          gpu::ok(unsafe { gpu::sp_sumcheck_eval_coeffs_batched(c, ap, bp, cp, ni, gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S)) });
+          have_S = true;
+        } else {
+          gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) });
+          evc = combine(&ev);
+        }
+      }
+      while j < num_rounds {
+        let len = len_of(A[0]);
+        let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+        if have_S && len >= 4 {
+          // two rounds in one trip: the next round's evaluations are the device's cubic at r_j
+          evc = evals_from_coeffs(&S, &r_j);
+          let r_j1 = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+          let n2 = len / 4;
+          let want_tail = tail_ok && n2 >= 2 && n2 <= 8;
+          let (pe, ps) = (if n2 >= 2 { gpu::limbs_mut(&mut evc) } else { null }, if n2 >= 4 { gpu::limbs_mut(&mut S) } else { null });
+          if want_tail {
+            mark(&mut tail);
+            gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs1(&r_j1), gpu::limbs(coeffs), pe, ps, null, gpu::limbs_mut(&mut tail)) });
+          } else {
+            gpu::ok(unsafe {
+              gpu::sp_sumcheck_bind2_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs1(&r_j1), gpu::limbs(coeffs), pe, ps,
+                                                  if n2 == 1 { gpu::limbs_mut(&mut heads) } else { null })
+            });
+          }
+          have_S = n2 >= 4;
+          have_heads = n2 == 1;
+          j += 2;
+          if want_tail && tail_given(&tail) { finish_on_host!(n2); }
+          continue;
+        }
+        if len >= 8 && len / 2 <= dmax {
+          // the tables become short with this bind: it also returns the cubic, then two rounds per trip
+          let n2 = len / 2;
+          let want_tail = tail_ok && n2 <= 8;
+          if want_tail {
+            mark(&mut tail);
+            gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S), null, gpu::limbs_mut(&mut tail)) });
+          } else {
+            gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S), null) });
+          }
+          have_S = true;
+          j += 1;
+          if want_tail && tail_given(&tail) { finish_on_host!(n2); }
+          continue;
+        } else if len >= 4 {
+          gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev)) });
+          evc = combine(&ev);
+        } else {
+          gpu::ok(unsafe { gpu::sp_table_bind_top_heads(c, all.as_ptr(), all.len(), gpu::limbs1(&r_j), gpu::limbs_mut(&mut heads)) });
+          have_heads = true;
+        }
+        j += 1;
+      }
+      if !have_heads { gpu::ok(unsafe { gpu::sp_table_heads(c, all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) }); }
     }
     // host-side bookkeeping of the bound polynomials (their tables were halved num_rounds times on the device)
     for p in poly_A_vec_par.iter_mut().chain(poly_B_vec_par.iter_mut()).chain(poly_A_vec_seq.iter_mut())
@@ -77,12 +469,7 @@ impl SumcheckInstanceProof {
     }
     poly_C_par.num_vars -= num_rounds;
     poly_C_par.len >>= num_rounds;
-
-    let claims_prod = (
-      (0..np).map(|k| heads[2 * k]).collect(),
-      (0..np).map(|k| heads[2 * k + 1]).collect(),
-      heads[2 * ni],
-    );
+    let claims_prod = ((0..np).map(|k| heads[2 * k]).collect(), (0..np).map(|k| heads[2 * k + 1]).collect(), heads[2 * ni]);
     let claims_dotp = (
       (0..ns).map(|k| heads[2 * (np + k)]).collect(),
       (0..ns).map(|k| heads[2 * (np + k) + 1]).collect(),
@@ -91,27 +478,3 @@ impl SumcheckInstanceProof {
     (SumcheckInstanceProof::new(cubic_polys), r, claims_prod, claims_dotp)
   }
 }
-
-// The C++ driver additionally advances TWO rounds per call while the tables are short (<= 512 entries, the latency-bound
-// tail: ~290 of the 361 rounds of a 2^20 proof): sp_sumcheck_eval_coeffs_batched / sp_sumcheck_bind2_eval_batched return,
-// next to the evaluations of a round, the coefficients (M0, M3, T1, T2 at t = 0, 2, 3) of the cubic in the NEXT challenge
-// that the following round's evaluations are; the caller derives r_j, evaluates that cubic on the host, derives r_{j+1},
-// and only then goes back to the device with both challenges (spartan_amd/host/spark.inc: prove_cubic_batched, evals_from_coeffs).
-// Same field values, same transcript operations, half the round trips. Once the tables have at most 8 entries the call's
-// `_tables_` variant (sp_sumcheck_bind2_eval_tables_batched) also returns the tables themselves and the driver runs the last
-// <= 3 rounds with the reference's own loop body on the CPU (spark.inc: cubic_tail_rounds). The one-round form above is the same proof.
-
-// ZKSumcheckInstanceProof::prove_quad (:428-586) and ::prove_cubic_with_additive_term (:588-776): the round body becomes
-//   round 0:  sp_sumcheck_eval(kind, tabs) -> evals -> UniPoly -> comm_poly  (reference code: poly.commit(...))
-//   round j:  sp_sumcheck_bind_eval_start(kind, tabs, r_j)        // bound_poly_var_top on every table (:485-486 / :673-676)
-//                                                                 // fused with the next round's evaluations (:460-469 / :624-652)
-//             ... the round's Sigma-protocol commitments, UNCHANGED reference code on the CPU (comm_eval, DotProductProof::prove's
-//                 delta, Cy, beta: 2..5-term commitments under gens_1 / gens_n — dalek's multiscalar_mul on a handful of points) ...
-//             sp_sumcheck_bind_eval_collect(evals_next)           // the device finished long ago
-//             comm_poly of round j+1 from evals_next              // reference code
-// kind 0 = A*B (prove_quad), kind 2 = A*(B*C - D) (prove_cubic_with_additive_term); tabs in that order.
-// Why the few-term commitments stay on the CPU: each is a chain of ~100 dependent point additions plus one inverse square
-// root that the transcript waits for; a host core finishes it in ~15 us, a lone wavefront in ~60 us plus the round trip
-// (measured: DESIGN.md section 4). The C++ driver does exactly this with its own window tables for those generators
-// (spartan_amd/host/small_msm.cc); sp_sumcheck_bind_eval_commit / sp_msm_indexed keep the all-device variant available.
-// The complete C++ rendering of both provers, line-by-line against sumcheck.rs, is spartan_amd/host/prover.cc (zk_sumcheck_prove).

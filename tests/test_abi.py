@@ -99,3 +99,27 @@ def test_rust_seams_call_only_declared_symbols():
             assert nargs == arity[name], (os.path.basename(f), name, nargs, arity[name])
             ncalls += 1
     assert ncalls >= 20
+
+
+def test_rust_seams_call_what_the_driver_calls():
+    """The measured path must be the drop-in's path: the set of C-ABI entry points the C++ host driver calls (prover.cc + spark.inc,
+    every switch included) equals the set the Rust seam bodies call (rust_shim/seams/*.rs + the hand-written tail of gpu.rs). An entry
+    point the driver needs and no seam calls would mean the Rust crate cannot run the path that bench.py times."""
+    import re, glob
+    _, protos = _header_protos()
+    declared = {p[0] for p in protos}
+
+    def calls(files):
+        found = set()
+        for f in files:
+            src = open(f).read()
+            src = re.sub(r"//[^\n]*", "", src)
+            found |= {m for m in re.findall(r"\b(sp_\w+)\s*\(", src) if m in declared}
+        return found
+    host = os.path.join(ROOT, "spartan_amd", "host")
+    driver = calls([os.path.join(host, "prover.cc"), os.path.join(host, "spark.inc")])
+    seams = calls(glob.glob(os.path.join(ROOT, "rust_shim", "seams", "*.rs")) + [os.path.join(ROOT, "rust_shim", "src", "gpu_tail.rs.in")])
+    assert len(driver) >= 55
+    assert driver - seams == set(), f"called by the C++ driver, by no Rust seam: {sorted(driver - seams)}"
+    # what only the Rust side touches: helpers of its own handle types
+    assert seams - driver <= {"sp_gens_upload", "sp_table_download"}, f"called by a seam, never by the driver: {sorted(seams - driver)}"
