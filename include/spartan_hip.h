@@ -198,6 +198,17 @@ int32_t sp_table_heads(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, uint64_
  * product_tree.rs:58-63, reads the two roots of every circuit): out[(k*count + e)*4 ..]. */
 int32_t sp_table_gather(sp_ctx* ctx, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out);
 
+/* ---- sharding helpers: a sum-check table split by INDEX RESIDUE keeps every top-variable pair (i, i + len/2) on one
+ * shard while len/2 is a multiple of W, so a shard runs the ordinary round kernels on its sub-table and only the 2..3 partial sums of
+ * a round (<= 96 bytes) are exchanged; DensePolynomial::bound shards by row blocks and its partial vectors are added.
+ *   sp_table_residue_split: out[k] = src[k W + g], k < len(src) / W, as a new table of `ctx` (src may belong to another context of the
+ *     same GPU: the virtual-shard test transport; the caller orders the two contexts' streams with sp_ctx_sync).
+ *   sp_table_set_len: the current (bound) length of a table, e.g. W after the W surviving entries of the shards were written back.
+ *   sp_table_add_into: dst[k] += src[k] (F_q), equal current lengths. */
+int32_t sp_table_residue_split(sp_ctx* ctx, const sp_table* src, size_t W, size_t g, sp_table** out);
+int32_t sp_table_set_len(sp_table* t, size_t len);
+int32_t sp_table_add_into(sp_ctx* ctx, sp_table* dst, const sp_table* src);
+
 /* ---- sparse matrices: SparseMatPolynomial (src/sparse_mlpoly.rs:19-38, 429-481) ----------------------
  * Entries (row, col, val). Upload keeps a row-sorted (CSR) and a column-sorted (CSC) copy on the device so
  * both products are gather-only (F_q has no atomic add). */

@@ -687,6 +687,34 @@ static int32_t gather_elems(sp_ctx* c, sp_table* const* tabs, const size_t* offs
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t* out) { return gather_elems(c, tabs, nullptr, ntabs, 1, out); }
+// ---- sharding helpers (sum-check tables by index residue, bound by row blocks) --------------------------------
+__global__ void __launch_bounds__(256) k_residue_split(const Fq* __restrict__ src, size_t W, size_t g, size_t n, Fq* __restrict__ dst) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) st_fq(dst + k, ld_fq(src + k * W + g));
+}
+__global__ void __launch_bounds__(256) k_add_into(Fq* __restrict__ dst, const Fq* __restrict__ src, size_t n) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) st_fq(dst + k, fq_add(ld_fq(dst + k), ld_fq(src + k)));
+}
+int32_t sp_table_residue_split(sp_ctx* c, const sp_table* src, size_t W, size_t g, sp_table** out) {
+  if (!c || !src || !out || W == 0 || g >= W || src->len % W != 0 || src->len / W == 0 || src->ctx->dev != c->dev) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t n = src->len / W;
+  SPCHK(table_new(c, n, false, out));
+  ProfScope ps(c, PF_MISC, 64.0 * (double)n);
+  hipLaunchKernelGGL(k_residue_split, dim3((unsigned)grid_for(n)), dim3(256), 0, c->stream, (const Fq*)src->d, W, g, n, (*out)->d);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_table_set_len(sp_table* t, size_t len) {
+  if (!t || len == 0 || len > t->cap) return SP_EINVAL;
+  t->len = len;
+  return SP_OK;
+}
+int32_t sp_table_add_into(sp_ctx* c, sp_table* dst, const sp_table* src) {
+  if (!c || !dst || !src || dst->len != src->len) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  ProfScope ps(c, PF_MISC, 96.0 * (double)dst->len);
+  hipLaunchKernelGGL(k_add_into, dim3((unsigned)grid_for(dst->len)), dim3(256), 0, c->stream, dst->d, (const Fq*)src->d, dst->len);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
 int32_t sp_table_gather(sp_ctx* c, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out) {
   return gather_elems(c, tabs, offs, ntabs, count, out);
 }

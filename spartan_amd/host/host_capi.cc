@@ -56,6 +56,9 @@ int spz_ctx_set_commit_shard_rccl(void* c, int rank, int world, const uint8_t un
 int spz_ctx_set_commit_shard_virtual(void* c, int nshards) {
   try { set_commit_shard_virtual(*(Ctx*)c, nshards); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+double spz_rccl_allgather_probe(void* c, size_t bytes, int iters) {
+  try { return rccl_allgather_probe(((Ctx*)c)->h, bytes, iters); } catch (const std::exception& e) { g_err = e.what(); return -2.0; }
+}
 void spz_ctx_shard_stats(void* c, int reset, uint64_t out[2]) {
   ShardStats s = commit_shard_stats(*(Ctx*)c, reset != 0);
   out[0] = s.gathers; out[1] = s.bytes;

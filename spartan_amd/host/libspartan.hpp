@@ -60,6 +60,9 @@ struct ShardStats { size_t gathers = 0, bytes = 0; };  // exchanges since the la
 ShardStats commit_shard_stats(Ctx& c, bool reset);
 // internal to the driver (prover.cc <-> shard.cc)
 bool commit_shard_active(sp_ctx* c);
+std::vector<sp_ctx*> residue_shard_ctxs(sp_ctx* c);  // virtual shards: [c, sub-contexts...]; empty when none
+void commit_shard_note_gather(sp_ctx* c, size_t bytes);
+double rccl_allgather_probe(sp_ctx* c, size_t bytes, int iters);  // us per H2D + ncclAllGather + D2H + sync of `bytes` per rank
 bool commit_shard_shared_seed(sp_ctx* c, Fq* seed);  // multi-rank transports only: rank 0's OS-entropy draw, handed to every rank
 void commit_shard_forget(sp_ctx* c);
 bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,

@@ -486,6 +486,75 @@ struct ZkAhead {
   }
 };
 
+// ------------------------------------------------------------------ sum-check tables sharded by index residue
+// Shard g of W holds the entries {i : i = g (mod W)} of every table as a contiguous sub-table T_g[k] = T[k W + g]. The
+// top-variable pair (i, i + len/2) of a round (sumcheck.rs:460-469, 624-652) stays on one shard while len/2 is a multiple of W, so
+// every shard runs the ordinary round kernels on its sub-tables and a round exchanges only its 2..3 partial sums (<= 96 bytes per
+// shard), added in F_q here (the modular addition is no RCCL operator: all-gather, then add). When the sub-tables are down to
+// one entry the W survivors are gathered into the owner's tables (entry g of a table = shard g's entry) and the last log2(W)
+// rounds run unsharded. Same field values as the unsharded rounds — sums of the same terms — hence the same proof bytes.
+struct ResidueShards {
+  sp_ctx* owner = nullptr;
+  std::vector<sp_ctx*> ctxs;
+  std::vector<std::vector<DevTable>> sub;  // [shard][table]
+  std::vector<std::vector<sp_table*>> h;
+  bool active = false;
+  size_t ntab = 0;
+  void split(sp_ctx* c, const std::vector<sp_table*>& tabs) {
+    ctxs = residue_shard_ctxs(c);
+    size_t W = ctxs.size(), len = tabs.empty() ? 0 : sp_table_len(tabs[0]);
+    if (W < 2 || (W & (W - 1)) || len < 4 * W || getenv("SPARTAN_NO_RESIDUE_SHARDS")) return;
+    owner = c; ntab = tabs.size();
+    SPX(sp_ctx_sync(c));  // the tables as produced by everything queued on the owning context
+    sub.resize(W); h.resize(W);
+    for (size_t g = 0; g < W; g++)
+      for (sp_table* t : tabs) {
+        sp_table* o = nullptr;
+        SPX(sp_table_residue_split(ctxs[g], t, W, g, &o));
+        sub[g].emplace_back(ctxs[g], o);
+        h[g].push_back(o);
+      }
+    active = true;
+  }
+  size_t sub_len() const { return sp_table_len(h[0][0]); }
+  void add_partials(uint64_t* ev, const std::vector<std::array<uint64_t, 12>>& parts, int n) {
+    for (int k = 0; k < n; k++) {
+      Fq acc = fq_zero();
+      for (auto& p : parts) { Fq x; memcpy(x.l, &p[4 * k], 32); acc += x; }
+      memcpy(ev + 4 * k, acc.l, 32);
+    }
+    commit_shard_note_gather(owner, 32 * (size_t)n * parts.size());
+  }
+  void eval(int kind, uint64_t* ev) {
+    std::vector<std::array<uint64_t, 12>> parts(ctxs.size());
+    for (size_t g = 0; g < ctxs.size(); g++) SPX(sp_sumcheck_eval(ctxs[g], kind, h[g].data(), ntab, parts[g].data()));
+    add_partials(ev, parts, kind == 0 ? 2 : 3);
+  }
+  void bind_eval_start(int kind, const Fq& r) {  // every shard's bind + next evaluation in flight together (own streams)
+    for (size_t g = 0; g < ctxs.size(); g++) SPX(sp_sumcheck_bind_eval_start(ctxs[g], kind, h[g].data(), ntab, U(r)));
+  }
+  void bind_eval_collect(int kind, uint64_t* ev) {
+    std::vector<std::array<uint64_t, 12>> parts(ctxs.size());
+    for (size_t g = 0; g < ctxs.size(); g++) SPX(sp_sumcheck_bind_eval_collect(ctxs[g], parts[g].data()));
+    add_partials(ev, parts, kind == 0 ? 2 : 3);
+  }
+  // sub-tables of two entries: bind them to one and hand the W survivors of every table back to the owner's tables
+  void bind_last_and_gather(const Fq& r, std::vector<sp_table*>& tabs) {
+    size_t W = ctxs.size();
+    std::vector<FqVec> heads(W, FqVec(ntab));
+    for (size_t g = 0; g < W; g++) SPX(sp_table_bind_top_heads(ctxs[g], h[g].data(), ntab, U(r), U(heads[g])));
+    for (size_t t = 0; t < ntab; t++) {
+      FqVec v(W);
+      for (size_t g = 0; g < W; g++) v[g] = heads[g][t];
+      SPX(sp_table_write(owner, tabs[t], 0, U(v), W));
+      SPX(sp_table_set_len(tabs[t], W));
+    }
+    commit_shard_note_gather(owner, 32 * ntab * W);
+    sub.clear(); h.clear();
+    active = false;
+  }
+};
+
 // ------------------------------------------------------------------ sumcheck.rs: the two ZK provers share everything but `kind`
 // kind 2: prove_cubic_with_additive_term (:588-776), tables (A,B,C,D), comb A*(B*C-D), gens_n = gens_4
 // kind 0: prove_quad (:428-586), tables (A,B), comb A*B, gens_n = gens_3
@@ -541,7 +610,10 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     rows[row * W + nn] = on_host ? fq_zero() : blinds_poly[j];
   };
   uint64_t ev[12];
-  SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev));
+  ResidueShards rs;  // virtual shards configured: the rounds run on W residue classes of the tables
+  if (on_host) rs.split(c, tabs);
+  if (rs.active) rs.eval(kind, ev);
+  else SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev));
   UniPoly poly = make_poly(ev, claim_per_round);
   REQUIRE(poly.coeffs.size() == nn);
   CP comm_claim_per_round, comm_poly;
@@ -572,8 +644,15 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     // comm_eval = eval*G1 + blinds_evals[j]*h ; delta = <d, Gn> + r_delta*hn: their scalars are known as soon as r_j is, like the bind
     CP comm_eval, delta;
     bool pending = false;  // the bind and the next evaluation are in flight on the device while this core commits
+    bool resharded = false;  // the shards have just handed their last entries back: the next evaluation is a call of its own
     if (on_host) {
-      if (sp_table_len(tabs[0]) >= 4) {
+      if (rs.active && rs.sub_len() >= 4) {
+        rs.bind_eval_start(kind, r_j);
+        pending = true;
+      } else if (rs.active) {
+        rs.bind_last_and_gather(r_j, tabs);
+        resharded = true;
+      } else if (sp_table_len(tabs[0]) >= 4) {
         SPX(sp_sumcheck_bind_eval_start(c, kind, tabs.data(), tabs.size(), U(r_j)));
         pending = true;
       } else {
@@ -586,7 +665,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         const sp_host_point* add[1] = {&aj.be_h};
         comm_eval = commit_rows(row, 1, add)[0];
         delta = aj.delta;
-      } catch (...) { if (pending) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
     } else {
       FqVec rows1(2 * W, fq_zero());
       rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
@@ -631,8 +710,10 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         rows2[W + nn + 1] = dp;
         const sp_host_point* add2[2] = {nullptr, &ahead.wait(j).rb_h};
         cm2 = commit_rows(rows2, 2, add2);
-      } catch (...) { if (pending) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
-      if (pending) SPX(sp_sumcheck_bind_eval_collect(c, ev));
+      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+      if (pending && rs.active) rs.bind_eval_collect(kind, ev);
+      else if (pending) SPX(sp_sumcheck_bind_eval_collect(c, ev));
+      if (resharded && more) { SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev)); pending = true; }
       if (more) {
         REQUIRE(pending);  // a further round means the tables had >= 4 entries: the next evaluations came with the bind
         next_poly = make_poly(ev, eval);
@@ -751,7 +832,28 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
   REQUIRE(poly.len() == Ls * Rs);
   FqVec Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
   sp_table* lz = nullptr;
-  SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device; queued, not waited for
+  std::vector<sp_ctx*> shards = residue_shard_ctxs(c);
+  if (shards.size() >= 2 && Ls % shards.size() == 0 && !getenv("SPARTAN_NO_RESIDUE_SHARDS")) {
+    // DensePolynomial::bound sharded by row blocks (the same contiguous rows a sharded commitment gives each shard):
+    // shard g multiplies rows [g Ls/W, (g+1) Ls/W) by its slice of L; the W partial vectors (R scalars each) are added in F_q
+    const size_t W = shards.size(), per = Ls / W;
+    SPX(sp_ctx_sync(c));
+    std::vector<DevTable> views, parts;
+    for (size_t g = 0; g < W; g++) {
+      views.push_back(tab_view(shards[g], poly, g * per * Rs, per * Rs));
+      sp_table* pz = nullptr;
+      SPX(sp_vecmat_dev(shards[g], U(Lv) + 4 * g * per, per, views.back().h, &pz));
+      parts.emplace_back(shards[g], pz);
+    }
+    for (size_t g = 1; g < W; g++) SPX(sp_ctx_sync(shards[g]));
+    for (size_t g = 1; g < W; g++) SPX(sp_table_add_into(c, parts[0].h, parts[g].h));
+    SPX(sp_ctx_sync(c));  // the partial vectors go back to their contexts' pools below
+    commit_shard_note_gather(c, 32 * Rs * W);
+    lz = parts[0].h;
+    parts[0].h = nullptr;
+  } else {
+    SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device; queued, not waited for
+  }
   DevTable LZ(c, lz);
   FqVec Rv = eq_evals_host(FqVec(r.begin() + r.size() / 2, r.end()));  // while the device multiplies
   Fq LZ_blind = fq_zero();
@@ -883,7 +985,28 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   double t3 = now_s();
   FqVec ry1(ry.begin() + 1, ry.end());
   Fq eval_vars_at_ry;
-  SPX(sp_evaluate(c, poly_vars.h, U(ry1), ry1.size(), eval_vars_at_ry.l));  // :299
+  {
+    std::vector<sp_ctx*> shards = residue_shard_ctxs(c);
+    size_t W = shards.size(), lw = W >= 2 ? log_2(W) : 0;
+    if (W >= 2 && ry1.size() > lw + 1 && !getenv("SPARTAN_NO_RESIDUE_SHARDS")) {
+      // DensePolynomial::evaluate as W partial dot products over contiguous chunks (chunk g = the top log2 W index
+      // bits): <Z, chi(r)> = sum_g chi_g(r[..lw]) <Z_g, chi(r[lw..])>, one scalar per shard gathered and combined here
+      SPX(sp_ctx_sync(c));
+      FqVec top = eq_evals_host(FqVec(ry1.begin(), ry1.begin() + lw)), low(ry1.begin() + lw, ry1.end());
+      size_t chunk = poly_vars.len() / W;
+      std::vector<DevTable> views;
+      eval_vars_at_ry = fq_zero();
+      for (size_t g = 0; g < W; g++) {
+        views.push_back(tab_view(shards[g], poly_vars, g * chunk, chunk));
+        Fq e;
+        SPX(sp_evaluate(shards[g], views.back().h, U(low), low.size(), e.l));
+        eval_vars_at_ry += top[g] * e;
+      }
+      commit_shard_note_gather(c, 32 * W);
+    } else {
+      SPX(sp_evaluate(c, poly_vars.h, U(ry1), ry1.size(), eval_vars_at_ry.l));  // :299
+    }
+  }
   Fq blind_eval = tape.random_scalar("blind_eval");
   P.proof_eval_vars_at_ry = polyeval_prove(c, poly_vars, &blinds_vars, ry1, eval_vars_at_ry, &blind_eval, gens.gens_pc, t, tape, &P.comm_vars_at_ry);
   if (tm) tm->polyeval = now_s() - t3;

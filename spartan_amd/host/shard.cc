@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <map>
 #include <mutex>
 
@@ -203,6 +204,59 @@ bool commit_shard_shared_seed(sp_ctx* c, Fq* seed) {
   memcpy(seed->l, buf.data(), 32);  // rank 0's draw
   s.stats.gathers++; s.stats.bytes += 32 * W;
   return true;
+}
+
+// Cost of one small all-gather on the context's RCCL communicator (bench/shard_probe.py: the per-round exchange of the residue-sharded
+// sum-checks is 96 bytes per rank): `iters` times H2D of `bytes`, ncclAllGather, D2H, stream sync — what sharded_commit_rows does per
+// commitment. Returns microseconds per exchange, or < 0 when no RCCL transport is configured.
+double rccl_allgather_probe(sp_ctx* c, size_t bytes, int iters) {
+  ShardState* sp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_state.find(c);
+    if (it == g_state.end() || it->second.mode != 2) return -1.0;
+    sp = &it->second;
+  }
+  ShardState& s = *sp;
+  size_t W = (size_t)s.world, need = bytes + bytes * W;
+  hip_ok(hipSetDevice(s.dev), "hipSetDevice");
+  if (s.dbuf_bytes < need) {
+    if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
+    s.dbuf = nullptr;
+    hip_ok(hipMalloc((void**)&s.dbuf, need), "hipMalloc");
+    s.dbuf_bytes = need;
+  }
+  std::vector<uint8_t> host(need, 1);
+  auto once = [&]() {
+    hip_ok(hipMemcpyAsync(s.dbuf, host.data(), bytes, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+    nccl_ok(rccl().AllGather(s.dbuf, s.dbuf + bytes, bytes, 1, s.comm, s.stream), "ncclAllGather");
+    hip_ok(hipMemcpyAsync(host.data(), s.dbuf + bytes, bytes * W, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+    hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+  };
+  for (int i = 0; i < 20; i++) once();
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) once();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / iters * 1e6;
+}
+
+// The sub-contexts of a virtual sharding (shard 0 = the owning context), for the residue-sharded sum-checks, bound and evaluate of
+// prover.cc; empty when no virtual sharding is configured. (With one process per GPU the same partition runs with the partial sums
+// travelling over the gather transport; virtual shards exercise the partition and its arithmetic on one GPU.)
+std::vector<sp_ctx*> residue_shard_ctxs(sp_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c);
+  std::vector<sp_ctx*> v;
+  if (it == g_state.end() || it->second.mode != 3 || it->second.world <= 1) return v;
+  v.push_back(c);
+  for (sp_ctx* x : it->second.vctx) v.push_back(x);
+  return v;
+}
+void commit_shard_note_gather(sp_ctx* c, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c);
+  if (it == g_state.end()) return;
+  it->second.stats.gathers++;
+  it->second.stats.bytes += bytes;
 }
 
 // DensePolynomial::commit_inner over the shards of the context; returns false when the commitment is not sharded (no

@@ -77,12 +77,60 @@ def test_virtual_shards_on_one_gpu_are_byte_identical(s, nshards):
     got = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
     st = ctx.shard_stats()
     assert got == ref
-    assert st["gathers"] == 2 and st["bytes"] == 32 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))   # witness + derefs commitments
+    # exchanges of one proof: the two row-sharded commitments (witness, derefs) + the residue-sharded sum-checks of R1CSProof::prove
+    # (one partial-sum gather per round while the shards hold >= 2 entries, one hand-back of the survivors: phase one
+    # s - lw + 1, phase two s - lw + 2) + the row-sharded `bound` of the four openings + the chunked evaluate of the witness
+    lw = nshards.bit_length() - 1
+    assert st["gathers"] == 2 + (s - lw + 1) + (s - lw + 2) + 4 + 1
+    assert st["bytes"] > 32 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))
     enc2 = P.SNARK.encode(ctx, inst, gens)    # SNARK::encode's multi_commit shards the same way
     assert enc2.serialize_commitment() == enc.serialize_commitment()
     ctx.set_commit_shard_virtual(1)
     assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
     enc2.free(); enc.free(); gens.free(); inst.free(); ctx.close()
+
+
+def test_residue_shards_can_be_switched_off_and_nizk_matches():
+    """NIZK::prove under 8 virtual shards (residue-sharded sum-checks, row-sharded bound, chunked evaluate) equals the unsharded
+    proof; SPARTAN_NO_RESIDUE_SHARDS=1 keeps only the commitment sharding (the A/B switch of DESIGN.md section 6)."""
+    from spartan_amd import prover as P
+    s = 14
+    N = 1 << s
+    ctx = P.Ctx(0)
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=2)
+    inst.set_digest(b"d")
+    gens = P.NIZKGens(ctx, N, N, 10)
+    tape = P.seed_scalar(b"tape", 9)
+    ref = P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape)
+    ctx.set_commit_shard_virtual(8)
+    ctx.shard_stats(reset=True)
+    assert P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape) == ref
+    full = ctx.shard_stats(reset=True)["gathers"]
+    os.environ["SPARTAN_NO_RESIDUE_SHARDS"] = "1"
+    try:
+        assert P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape) == ref
+        assert ctx.shard_stats()["gathers"] == 1 and full == 1 + (s - 3 + 1) + (s - 3 + 2) + 1 + 1   # commit | + sum-checks, bound, evaluate
+    finally:
+        del os.environ["SPARTAN_NO_RESIDUE_SHARDS"]
+    ctx.set_commit_shard_virtual(1)
+    gens.free(); inst.free(); ctx.close()
+
+
+def test_sharded_proving_with_an_os_entropy_tape():
+    """tape_seed=None (the production setting) with lock-step ranks: rank 0 draws the RandomTape seed and the commit transport
+    hands it to the others — otherwise every rank would blind its row slice with its own tape (round-2 advisor finding)."""
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_seed_worker.py"), "10"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    assert "SHARD_SEED_OK" in outs[0]
 
 
 def test_rccl_transport_inside_the_library_single_rank():
