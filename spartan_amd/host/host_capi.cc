@@ -144,6 +144,23 @@ int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint
 }
 void spz_seed_scalar(const char* domain, uint64_t seed, uint64_t out[4]) { Fq s = seed_scalar(domain, seed); memcpy(out, s.l, 32); }
 void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->digest.assign(d, d + n); }
+// R1CSShape::get_digest (r1cs.rs:154-158): the zlib stream; and the bincode it compresses (for the round-trip tests)
+size_t spz_instance_digest(void* inst, uint8_t* out, size_t cap) {
+  const std::vector<uint8_t>& d = ((Instance*)inst)->compute_digest();
+  if (out && cap >= d.size()) memcpy(out, d.data(), d.size());
+  return d.size();
+}
+size_t spz_instance_shape_bincode(void* inst, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> b = ((Instance*)inst)->shape_bincode();
+  if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
+  return b.size();
+}
+// the deflater alone (CPU tests): zlib_level6_miniz of arbitrary bytes
+size_t spz_zlib_level6(const uint8_t* data, size_t n, int old_header, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> z = zlib_level6_miniz(data, n, old_header != 0);
+  if (out && cap >= z.size()) memcpy(out, z.data(), z.size());
+  return z.size();
+}
 void spz_instance_free(void* i) { delete (Instance*)i; }
 void* spz_snark_gens_new(void* ctx, size_t nc, size_t nv, size_t ni, size_t nnz) {
   return guard([&]() -> void* { return new SNARKGens(*(Ctx*)ctx, nc, nv, ni, nnz); });

@@ -135,9 +135,12 @@ struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the m
   size_t num_cons = 0, num_vars = 0, num_inputs = 0;
   std::vector<SparseEntry> A, B, C;
   sp_sparse *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  // R1CSShapeDigest bytes (zlib(bincode(shape)) in the reference, r1cs.rs:154-158): an opaque input the Rust side computes.
-  // NIZK::prove refuses to run without it (the transcript would not be bound to the shape, lib.rs:514).
+  // R1CSShapeDigest bytes: zlib(level 6)(bincode(shape)) (r1cs.rs:154-158), absorbed by NIZK::prove (lib.rs:514). Computed on first
+  // use by compute_digest() (deflate.cc: a restatement of miniz's level-6 tdefl, what flate2's rust_backend runs); a caller that
+  // holds the bytes of a real libspartan Instance may set them instead.
   std::vector<uint8_t> digest;
+  std::vector<uint8_t> shape_bincode() const;  // bincode(R1CSShape): r1cs.rs:18-26, sparse_mlpoly.rs:19-38
+  const std::vector<uint8_t>& compute_digest();
   // Instance::new (lib.rs:121-228): padding of num_cons / num_vars and the column shift are applied here.
   Instance(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const std::vector<SparseEntry>& A,
            const std::vector<SparseEntry>& B, const std::vector<SparseEntry>& C);
@@ -161,6 +164,9 @@ struct VarsAssignment {
 // TEST/BENCH ONLY: from_bytes_wide(SHAKE256(domain || LE64(seed))[0..64]), the documented seed -> scalar map behind the
 // reproducible RandomTape seeds of tests/ and bench.py. 64 bits of entropy: never a production tape seed.
 Fq seed_scalar(const char* domain, uint64_t seed);
+
+// zlib stream of `data` as miniz's tdefl produces it at level 6 (deflate.cc). old_header: 0x78 0x01 (miniz, miniz_oxide 0.3) instead of 0x78 0x9C
+std::vector<uint8_t> zlib_level6_miniz(const uint8_t* data, size_t n, bool old_header = false);
 
 // ---- proof structs: field order == bincode order (same as the reference's serde derives) ----
 struct PolyCommitment { std::vector<CP> C; };                                   // dense_mlpoly.rs:38-41

@@ -241,6 +241,26 @@ Instance::Instance(Ctx& ctx, size_t nc, size_t nv, size_t ni, const std::vector<
   }
 }
 Instance::~Instance() { sp_sparse_free(dA); sp_sparse_free(dB); sp_sparse_free(dC); }
+std::vector<uint8_t> Instance::shape_bincode() const {
+  std::vector<uint8_t> b;
+  auto u64 = [&](uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); };
+  size_t total = 24;
+  for (auto m : {&A, &B, &C}) total += 24 + 48 * m->size();
+  b.reserve(total);
+  u64(num_cons); u64(num_vars); u64(num_inputs);
+  for (auto m : {&A, &B, &C}) {
+    u64(log_2(num_cons)); u64(log_2(2 * num_vars)); u64(m->size());  // SparseMatPolynomial { num_vars_x, num_vars_y, M } (r1cs.rs:104-112)
+    for (auto& e : *m) { u64(e.row); u64(e.col); for (int i = 0; i < 4; i++) u64(e.val.l[i]); }
+  }
+  return b;
+}
+const std::vector<uint8_t>& Instance::compute_digest() {
+  if (digest.empty()) {
+    std::vector<uint8_t> sb = shape_bincode();
+    digest = zlib_level6_miniz(sb.data(), sb.size(), getenv("SPARTAN_ZLIB_OLD_HEADER") != nullptr);
+  }
+  return digest;
+}
 
 Fq seed_scalar(const char* domain, uint64_t seed) {
   Shake256 sh;
@@ -1031,7 +1051,7 @@ VarsAssignment::VarsAssignment(Ctx& ctx, const Fq* vars, size_t n_) : c(ctx.h), 
 NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& inputs, const NIZKGens& gens, Transcript& t,
                  const Fq* tape_seed, ProveTimes* tm, const sp_table* vars_resident) {  // lib.rs:501-546
   double t0 = now_s();
-  REQUIRE(!inst.digest.empty());  // lib.rs:514 absorbs inst.digest: an empty one would leave the proof unbound to the shape
+  const_cast<Instance&>(inst).compute_digest();  // lib.rs:514 absorbs inst.digest (r1cs.rs:154-158); computed once per instance
   Fq shared_seed;  // lock-step ranks of a sharded proof must share one tape: rank 0 draws it (shard.cc)
   if (!tape_seed && commit_shard_shared_seed(ctx.h, &shared_seed)) tape_seed = &shared_seed;
   RandomTape tape = tape_seed ? RandomTape("proof", *tape_seed) : RandomTape("proof");  // random.rs:11-18

@@ -138,6 +138,30 @@ def test_prove_continues_a_caller_owned_transcript(P, ctx, orc, s, seed):
     ng.free(); inst.free()
 
 
+def test_nizk_binds_to_the_shape_digest_it_computes(P, ctx, orc):
+    """NIZK::prove absorbs R1CSShape::get_digest (lib.rs:514, r1cs.rs:154-158). Without a caller-supplied digest the driver
+    computes it (deflate.cc): it must inflate (Python zlib) to the bincode of the shape as the oracle serialises it, and the
+    proof must equal the oracle's proof over the same digest bytes."""
+    import zlib
+    s, seed = 8, 5
+    N = 1 << s
+    P.H.spz_instance_digest.restype = sz
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=seed)
+    n = P.H.spz_instance_digest(inst.h, None, sz(0)); buf = (ctypes.c_uint8 * n)(); P.H.spz_instance_digest(inst.h, buf, sz(n))
+    digest = bytes(buf)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
+    m = orc.orc_instance_shape_bincode(oi, None, sz(0)); sb = (ctypes.c_uint8 * m)(); orc.orc_instance_shape_bincode(oi, sb, sz(m))
+    assert zlib.decompress(digest) == bytes(sb)
+    gens = P.NIZKGens(ctx, N, N, 10)
+    tape = P.seed_scalar(b"tape", seed)
+    got = P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape)     # no set_digest: computed
+    og = vp(orc.orc_nizk_gens_new(sz(N), sz(N), sz(10)))
+    op = vp(orc.orc_nizk_prove(oi, og, digest, sz(len(digest)), b"nizk_example", tape, None))
+    assert got == oracle_bytes(orc, op)
+    orc.orc_proof_free(op); orc.orc_nizk_gens_free(og); orc.orc_instance_free(oi)
+    gens.free(); inst.free()
+
+
 def test_generator_streams_match_oracle(P, ctx, orc):
     gens = P.SNARKGens(ctx, 64, 64, 10, 64)
     sat = gens.stream(0); ev = gens.stream(1)

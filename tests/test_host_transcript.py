@@ -92,3 +92,43 @@ def test_transcript_state_export_import_matches_oracle(H, orc):
         H.spz_merlin_challenge_from_state(a, b"next", oa, sz(64))
         orc.orc_merlin_challenge_from_state(b, b"next", ob, sz(64))
         assert bytes(oa) == tail and bytes(ob) == tail and bytes(a) == bytes(b)  # the states after the draw agree too
+
+
+def _zlib6(H, data, old=0):
+    H.spz_zlib_level6.restype = sz
+    cap = 2 * len(data) + 1024
+    out = (ctypes.c_uint8 * cap)()
+    n = H.spz_zlib_level6(data, sz(len(data)), ctypes.c_int(old), out, sz(cap))
+    return bytes(out[:n])
+
+
+def test_shape_digest_deflater_round_trips_and_keeps_miniz_parameters(H, orc):
+    """R1CSShape::get_digest (src/r1cs.rs:154-158) = zlib(level 6)(bincode(shape)) through flate2's rust_backend, i.e. miniz's tdefl.
+    spartan_amd/host/deflate.cc restates that path; no miniz exists here, so what is pinned is: (1) every stream inflates with an
+    independent implementation (Python zlib) to exactly its input — stored, static and dynamic blocks, multi-block inputs, the
+    bincode of a synthetic R1CS shape as the ORACLE serialises it; (2) the stream shape miniz documents: header 0x78 0x9C (0x78 0x01
+    with the old-header switch), Adler-32 trailer, a stored block for inputs a coded block would expand, blocks closed by the
+    31 KiB / code-buffer rule (so a 150 KB input has several blocks). Byte equality with miniz_oxide needs the Rust run of
+    scripts/compare_with_libspartan.sh."""
+    import zlib
+    rng = random.Random(11)
+    shape = None
+    N = 1 << 9
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(3)))
+    n = orc.orc_instance_shape_bincode(oi, None, sz(0)); b = (ctypes.c_uint8 * n)(); orc.orc_instance_shape_bincode(oi, b, sz(n))
+    shape = bytes(b)
+    orc.orc_instance_free(oi)
+    assert len(shape) == 24 + 3 * (24 + 48 * N)
+    cases = [b"", b"a", b"hello hello hello hello", bytes(5000), bytes(rng.randrange(256) for _ in range(40000)), b"abcdefghij" * 20000,
+             bytes(rng.randrange(4) for _ in range(150000)), shape]
+    for c in cases:
+        z = _zlib6(H, c)
+        assert zlib.decompress(z) == c
+        assert z[:2] == b"\x78\x9c" and z[-4:] == zlib.adler32(c).to_bytes(4, "big")
+        z1 = _zlib6(H, c, 1)
+        assert z1[:2] == b"\x78\x01" and z1[2:] == z[2:]
+    assert _zlib6(H, b"a")[2:8] == b"\x01\x01\x00\xfe\xff\x61"            # one byte: the coded block would not be smaller -> stored, final
+    incompressible = cases[4]
+    z = _zlib6(H, incompressible)
+    assert len(z) == len(incompressible) + 2 + 4 + 5 * 2 and z[2] == 0        # two stored blocks (the 31 KiB rule), not final / final
+    d = zlib.decompressobj(); d.decompress(_zlib6(H, shape)); assert d.eof
