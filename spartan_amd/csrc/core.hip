@@ -214,6 +214,7 @@ __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __res
 // thread <-> (row, strip): accumulates sum_{j in strip} Z[row][j] * P[col(j)] into one extended point.
 // Lanes run fastest over rows so a wave shares the generator (and its 12 KiB window sub-table) whenever
 // rows >= 64: table gathers then hit L1/L2, while the scalar load (32 B per 32 additions) is the strided one.
+template <bool PF2>
 __device__ __forceinline__ void msm_rows_tile(size_t lb, unsigned tid, const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols,
                                               size_t strip, size_t nstrips, const Niels* __restrict__ table, size_t g_off,
                                               const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial,
@@ -238,16 +239,17 @@ __device__ __forceinline__ void msm_rows_tile(size_t lb, unsigned tid, const Fq*
   for (size_t j = j0; j < j1; j++) {
     Fq sc = ld_fq(Z + row * z_row_stride + j);
     size_t pt = idx ? (size_t)idx[j] : g_off + j;
-    msm_accumulate(acc, sc, table, pt, geom);
+    msm_accumulate_t<PF2>(acc, sc, table, pt, geom);
   }
-  if (blinds && s == 0) msm_accumulate(acc, ld_fq(blinds + row), table, h_idx, geom);
+  if (blinds && s == 0) msm_accumulate_t<PF2>(acc, ld_fq(blinds + row), table, h_idx, geom);
   partial[row * nstrips + s] = acc;
 }
+template <bool PF2>
 __global__ void __launch_bounds__(256) k_msm_rows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols, size_t strip,
                                                   size_t nstrips, const Niels* __restrict__ table, size_t g_off,
                                                   const uint32_t* __restrict__ idx, const Fq* __restrict__ blinds, size_t h_idx,
                                                   Pt* __restrict__ partial, int xcd_map, MsmGeom geom) {
-  msm_rows_tile(blockIdx.x, threadIdx.x, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, idx, blinds, h_idx, partial, xcd_map, geom);
+  msm_rows_tile<PF2>(blockIdx.x, threadIdx.x, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, idx, blinds, h_idx, partial, xcd_map, geom);
 }
 // Background form: persistent 1024-thread workgroups, launched on fewer workgroups than the chip has CUs. At 127 VGPRs a
 // CU holds exactly one of them (16 waves, 508 of 512 registers per lane), so the CUs left over cannot receive a second
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(1024) k_msm_rows_bg(const Fq* __restrict__ Z, 
                                                       int xcd_map, size_t ntiles, MsmGeom geom) {
   extern __shared__ uint8_t occupancy_fence[];
   for (size_t lb = (size_t)blockIdx.x * 4 + threadIdx.x / 256; lb < ntiles; lb += (size_t)gridDim.x * 4)
-    msm_rows_tile(lb, threadIdx.x % 256, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, nullptr, nullptr, 0, partial, xcd_map, geom);
+    msm_rows_tile<false>(lb, threadIdx.x % 256, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, nullptr, nullptr, 0, partial, xcd_map, geom);
 }
 // Latency-bound shapes (Sigma-protocol commits, IPA rounds, single-row commits): one thread per (row, column,
 // window) performs a single table lookup, so the serial chain per thread is one mixed addition instead of 32.
@@ -1091,8 +1093,13 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
       hipLaunchKernelGGL(k_msm_rows_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
                          (const Niels*)g->table, g_off, partial, xcd_map, nblocks, g->geom);
     } else {
-      hipLaunchKernelGGL(k_msm_rows, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
-                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
+      static const bool pf2 = getenv("SPARTAN_MSM_PREFETCH1") == nullptr;  // A/B switch: one table entry in flight instead of two
+      if (pf2)
+        hipLaunchKernelGGL(k_msm_rows<true>, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
+                           (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
+      else
+        hipLaunchKernelGGL(k_msm_rows<false>, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
+                           (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
     }
   }
   if (m.two_pass) {

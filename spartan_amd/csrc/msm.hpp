@@ -80,7 +80,9 @@ SP_HD int msm_digit(const Fq& s, int w) { return msm_digit(s, w, msm_geom(MSM_WB
 
 // acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar. The table entry of the
 // next window is requested before the current mixed addition so the gather latency overlaps the 7 multiplications.
-SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) {
+// PF2: two table entries in flight instead of one (26 more registers: the foreground row MSM has them, the 1024-thread background form has not)
+template <bool PF2>
+SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) {
   if (fq_is_zero(s_mont)) return;
   Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
   const Niels* base = table + pt * g.pt_entries;
@@ -94,6 +96,34 @@ SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ t
   uint32_t m = (uint32_t)(d < 0 ? -d : d);
   bool ng = d < 0;
   Niels cur = base[m ? m - 1 : 0];
+  if (PF2) {
+  // two table entries in flight (PMC: waves of the row MSM wait on memory 43 % of their cycles at every window width — the gathers
+  // are latency-, not bandwidth- or translation-bound: profiles/r3_pmc_msm_translation_fabric.txt)
+  auto next_digit = [&](int& dn, uint32_t& mn) {
+    s.l[0] = (s.l[0] >> c) | (s.l[1] << (64 - c));
+    s.l[1] = (s.l[1] >> c) | (s.l[2] << (64 - c));
+    s.l[2] = (s.l[2] >> c) | (s.l[3] << (64 - c));
+    s.l[3] >>= c;
+    dn = (int)(s.l[0] & mask) + carry;
+    carry = dn >= g.tent;
+    dn -= carry << c;
+    mn = (uint32_t)(dn < 0 ? -dn : dn);
+  };
+  int d1; uint32_t m1;
+  next_digit(d1, m1);
+  Niels nx1 = base[(size_t)(g.nwin > 1 ? 1 : 0) * g.tent + (m1 ? m1 - 1 : 0)];
+  bool ng1 = d1 < 0;
+#pragma unroll 1
+  for (int w = 0; w < g.nwin; w++) {
+    int d2; uint32_t m2;
+    next_digit(d2, m2);  // window w + 2 (zero past the top: s < 2^253)
+    int w2 = (w + 2 < g.nwin) ? w + 2 : g.nwin - 1;
+    Niels nx2 = base[(size_t)w2 * g.tent + (m2 ? m2 - 1 : 0)];
+    if (m != 0) acc = pt_madd(acc, cur, ng);
+    cur = nx1; m = m1; ng = ng1;
+    nx1 = nx2; m1 = m2; ng1 = d2 < 0;
+  }
+  } else {
 #pragma unroll 1
   for (int w = 0; w < g.nwin; w++) {
     s.l[0] = (s.l[0] >> c) | (s.l[1] << (64 - c));
@@ -111,7 +141,9 @@ SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ t
     m = mn;
     ng = dn < 0;
   }
+  }
 }
+SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) { msm_accumulate_t<false>(acc, s_mont, table, pt, g); }
 SP_HD void msm_accumulate(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt) { msm_accumulate(acc, s_mont, table, pt, msm_geom(MSM_WBITS)); }
 
 }  // namespace sp
