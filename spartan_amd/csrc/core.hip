@@ -766,10 +766,11 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
     // background MSMs: one 1024-thread workgroup per CU on half of the CUs (k_msm_rows_bg). Measured at 2^20 with the
     // derefs row half in the background, share in eighths 2 / 3 / 4 / 5 / 6 / 8 -> 63.1 / 59.2 / 58.0 / 59.0 / 61.5 / 62.5 ms
     // per proof (63.3 without the overlap): less and the MSM is not done when it is needed, more and the second
-    // sum-check's kernels queue behind MSM workgroups.
+    // sum-check's kernels queue behind MSM workgroups. Round 3 (the foreground under the MSM got shorter: look-ahead, fused inner-product
+    // rounds), share 3 / 4 / 5 / 6 -> 29.2 / 28.3 / 27.5 / 27.8 ms per proof (29.98 without the overlap): 5.
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
-    int share = 4;
+    int share = 5;
     if (const char* e = getenv("SPARTAN_BG_EIGHTHS")) { int v = atoi(e); if (v >= 0 && v <= 8) share = v; }
     c->bg_lds = 0;
     c->bg_blocks = prop.multiProcessorCount * share / 8;
