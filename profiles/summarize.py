@@ -14,3 +14,17 @@ for name, calls, total, avg, pct in rows:
     agg[short] = (c + calls, t + total, p + pct)
 for short, (calls, total, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-60s %8d %14.1f %12.3f %6.2f%%" % (short[:60], calls, total, total / calls, pct))
+# optional: --detail k_a,k_b  -> per-grid-size statistics of those kernels (which launches of a family are the slow ones)
+if "--detail" in sys.argv:
+    want = sys.argv[sys.argv.index("--detail") + 1].split(",")
+    cols = [r[1] for r in db.execute("PRAGMA table_info(kernels)")]
+    gcol = [c for c in cols if c.lower() in ("grid_size_x", "grid_x", "grid_size")]
+    dcol = "duration" if "duration" in cols else "(end - start)"
+    if not gcol:
+        print("# --detail: no grid column in view `kernels` (%s)" % ",".join(cols))
+    else:
+        print("\n# per grid size (x): kernel, grid_x, launches, avg_us, min_us, max_us")
+        for k in want:
+            q = "select %s, count(*), avg(%s), min(%s), max(%s) from kernels where name like ? group by 1 order by 1" % (gcol[0], dcol, dcol, dcol)
+            for g, n, a, mn, mx in db.execute(q, ("%" + k + "%",)):
+                print("%-36s %10d %6d %10.1f %10.1f %10.1f" % (k, g, n, a / 1e3, mn / 1e3, mx / 1e3))

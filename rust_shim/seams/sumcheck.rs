@@ -296,7 +296,7 @@ impl SumcheckInstanceProof {
     let mut tail = vec![Scalar::zero(); 3 * 8 * ni];
     let (mut have_heads, mut have_S) = (false, false);
     let tail_ok = std::env::var_os("SPARTAN_NO_HOST_TAIL").is_none() && np >= 1 && ni <= 21;
-    let dmax = gpu::double_round_max_len(); // 512 (SPARTAN_DOUBLE_ROUND_MAX_LEN)
+    let dmax = gpu::double_round_max_len(); // 4096 (SPARTAN_DOUBLE_ROUND_MAX_LEN)
     let len_of = |t: *mut sp_table| unsafe { gpu::sp_table_len(t) };
     // :370-381 and :395-396: the round's cubic, its transcript message, the challenge
     let mut round_message = |evc: &[Scalar; 3], e: &mut Scalar, r: &mut Vec<Scalar>, polys: &mut Vec<CompressedUniPoly>, transcript: &mut Transcript| {

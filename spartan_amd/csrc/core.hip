@@ -591,19 +591,6 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
   }
   signal_done(sig);
 }
-// c_L = <a_L, b_R>, c_R = <a_R, b_L> of the FIRST round (bullet.rs:80-81), one block; later rounds get theirs from the quarter
-// dot products of the round before (k_ipa_round)
-__global__ void __launch_bounds__(256) k_ipa_c0(const Fq* __restrict__ a, const Fq* __restrict__ b, size_t n, Fq* __restrict__ out) {
-  __shared__ Fq sm[256];
-  const size_t h = n / 2;
-  Fq c[2] = {fq_zero(), fq_zero()};
-  for (size_t i = threadIdx.x; i < h; i += 256) {
-    c[0] = fq_add(c[0], fq_mul(ld_fq(a + i), ld_fq(b + h + i)));
-    c[1] = fq_add(c[1], fq_mul(ld_fq(a + h + i), ld_fq(b + i)));
-  }
-  block_sum_fq<2>(c, sm);
-  if (threadIdx.x == 0) { st_fq(out, c[0]); st_fq(out + 1, c[1]); }
-}
 extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out) {
   const size_t P = (A->n0 / 2) * (size_t)g->geom.nwin;
   A->nblk = (unsigned)((P + 255) / 256);
@@ -620,11 +607,6 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
     hipLaunchKernelGGL(k_ipa_round, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
   }
   *sig_out = sig;
-  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
-}
-extern "C" int32_t ipa_c0_launch(sp_ctx* c, const Fq* a, const Fq* b, size_t n, Fq* out) {
-  ProfScope ps(c, PF_IPA, 64.0 * (double)n);
-  hipLaunchKernelGGL(k_ipa_c0, dim3(1), dim3(256), 0, c->stream, a, b, n, out);
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 

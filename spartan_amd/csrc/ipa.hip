@@ -17,7 +17,7 @@ struct sp_ipa {
   uint32_t* idx_lr;           // device: [2][n0/2+2] per-row generator lists of the current round
   uint32_t* counters;         // device: [2] row tickets of k_ipa_round (zero between launches)
   size_t bytes;
-  // one-launch rounds (k_ipa_round, core.hip): c_L, c_R of the first round (k_ipa_c0) and the eight quarter dot products the
+  // one-launch rounds (k_ipa_round, core.hip): c_L, c_R of the first round (k_ipa_init) and the eight quarter dot products the
   // last round left behind, from which the next c_L, c_R follow once the fold challenge is recorded
   Fq c0[2], dots[8];
   bool have_c0, have_dots;
@@ -36,7 +36,7 @@ struct IpaRoundArgs {
   unsigned nblk, nd;
 };
 extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out);
-extern "C" int32_t ipa_c0_launch(sp_ctx* c, const Fq* a, const Fq* b, size_t n, Fq* out);
+static unsigned ipa_c0_blocks(size_t n) { return (unsigned)((n / 2 + 511) / 512); }  // k_ipa_init: one workgroup per 512 index pairs
 static bool ipa_fused() {
   static const bool on = getenv("SPARTAN_IPA_UNFUSED") == nullptr;  // A/B switch: three launches + flag kernel per round (the round-2 path)
   return on;
@@ -159,6 +159,36 @@ __global__ void k_ipa_heads(const Fq* __restrict__ a, const Fq* __restrict__ b, 
   signal_done(sig);
 }
 
+// One launch sets an opening up (was: four copies, a memset and the c_L/c_R kernel): a (a device table, or a pinned host copy the
+// kernel reads over PCIe) and b (pinned host copy) into the working buffers, the generator index list, s = [1], the row tickets, and
+// the first round's c_L = <a_L, b_R>, c_R = <a_R, b_L> (bullet.rs:80-81) as one partial pair per block of 512 index pairs.
+__global__ void __launch_bounds__(256) k_ipa_init(const Fq* __restrict__ a_src, const Fq* __restrict__ b_src, size_t n, size_t g_off, uint32_t q_idx,
+                                                  uint32_t h_idx, Fq* __restrict__ a, Fq* __restrict__ b, Fq* __restrict__ s, uint32_t* __restrict__ idx,
+                                                  uint32_t* __restrict__ counters, Fq* __restrict__ c0_out) {
+  __shared__ Fq sm[256];
+  const size_t h = n / 2;
+  Fq c[2] = {fq_zero(), fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x, k = 0; k < 2 && i < h; k++, i += 256) {
+    const Fq al = ld_fq(a_src + i), ah = ld_fq(a_src + h + i), bl = ld_fq(b_src + i), bh = ld_fq(b_src + h + i);
+    st_fq(a + i, al); st_fq(a + h + i, ah); st_fq(b + i, bl); st_fq(b + h + i, bh);
+    idx[i] = (uint32_t)(g_off + i); idx[h + i] = (uint32_t)(g_off + h + i);
+    c[0] = fq_add(c[0], fq_mul(al, bh));
+    c[1] = fq_add(c[1], fq_mul(ah, bl));
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 16) counters[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+      if (n == 1) { st_fq(a, ld_fq(a_src)); st_fq(b, ld_fq(b_src)); idx[0] = (uint32_t)g_off; }
+      idx[n] = q_idx; idx[n + 1] = h_idx;
+      st_fq(s, fq_one());
+    }
+  }
+  if (c0_out) {
+    block_sum_fq<2>(c, sm);
+    if (threadIdx.x == 0) { st_fq(c0_out + 2 * blockIdx.x, c[0]); st_fq(c0_out + 2 * blockIdx.x + 1, c[1]); }
+  }
+}
+
 static Fq limbs(const uint64_t* p) {
   Fq x;
   memcpy(x.l, p, 32);
@@ -200,26 +230,24 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
   ipa->idx_lr = ipa->idx + (n + 2);
   ipa->counters = ipa->idx_lr + (n + 4);
   ipa->have_c0 = ipa->have_dots = false;
-  std::vector<uint32_t> idx(n + 2);
-  for (size_t j = 0; j < n; j++) idx[j] = (uint32_t)(g_off + j);
-  idx[n] = (uint32_t)q_idx;
-  idx[n + 1] = (uint32_t)h_idx;
-  Fq one = fq_one();
-  hipError_t e = a_dev ? hipMemcpyAsync(ipa->a, a_dev->d, 32 * n, hipMemcpyDeviceToDevice, c->stream)
-                       : hipMemcpyAsync(ipa->a, a, 32 * n, hipMemcpyHostToDevice, c->stream);
-  if (e != hipSuccess || hipMemcpyAsync(ipa->b, b, 32 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(ipa->s, &one, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(ipa->idx, idx.data(), 4 * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemsetAsync(ipa->counters, 0, 64, c->stream) != hipSuccess) {
-    sp_ipa_free(ipa);
-    return SP_EHIP;
-  }
-  int32_t rc = SP_OK;
-  // c_L, c_R of the first round ride along with whatever this call waits for: into the result page, clear of the row sums
-  Fq* c0_dst = (Fq*)(hres(c) + HOST_SUM_BYTES + 128);
-  const bool want_c0 = ipa_fused() && n >= 2 && !c->device_encode;
-  if (want_c0) rc = ipa_c0_launch(c, ipa->a, ipa->b, n, c0_dst);
+  // b (and a host-side a) go through the pinned staging buffer, which the set-up kernel reads directly; [0, 4096) of it belongs to stage_in
+  const size_t stage_off = 4096;
+  int32_t rc = ensure_pinned(c, stage_off + 64 * n);
   if (rc != SP_OK) { sp_ipa_free(ipa); return rc; }
+  Fq* pb = (Fq*)(c->pinned + stage_off);
+  memcpy(pb, b, 32 * n);
+  const Fq* a_src = a_dev ? (const Fq*)a_dev->d : pb + n;
+  if (!a_dev) memcpy(pb + n, a, 32 * n);
+  // c_L, c_R of the first round ride along with whatever this call waits for: into the result page, clear of the row sums
+  Fq* c0_dst = (Fq*)(hres(c) + HOST_SUM_BYTES);  // [30720, 31744): between the partial sums and the row sums of the last KiB
+  const unsigned nblk0 = ipa_c0_blocks(n) ? ipa_c0_blocks(n) : 1;
+  const bool want_c0 = ipa_fused() && n >= 2 && !c->device_encode && nblk0 <= 16;  // 16 partial pairs = 1 KiB of the page
+  {
+    ProfScope ps(c, PF_IPA, 128.0 * (double)n);
+    hipLaunchKernelGGL(k_ipa_init, dim3(nblk0), dim3(256), 0, c->stream, a_src, (const Fq*)pb, n, g_off, (uint32_t)q_idx, (uint32_t)h_idx, ipa->a, ipa->b, ipa->s,
+                       ipa->idx, ipa->counters, want_c0 ? c0_dst : (Fq*)nullptr);
+  }
+  if (hipGetLastError() != hipSuccess) { sp_ipa_free(ipa); return SP_EHIP; }
   if (commit_a) {  // waits for the stream: the host buffers above are released too
     rc = ensure_dstage(c, 32);
     if (rc == SP_OK) rc = stage_in(c, 0, blind_a, 32);
@@ -228,7 +256,11 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
     rc = SP_EHIP;
   }
   if (rc != SP_OK) { sp_ipa_free(ipa); return rc; }
-  if (want_c0) { memcpy(ipa->c0, c0_dst, 64); ipa->have_c0 = true; }
+  if (want_c0) {
+    ipa->c0[0] = ipa->c0[1] = fq_zero();
+    for (unsigned k = 0; k < ipa_c0_blocks(n); k++) { ipa->c0[0] = fq_add(ipa->c0[0], c0_dst[2 * k]); ipa->c0[1] = fq_add(ipa->c0[1], c0_dst[2 * k + 1]); }
+    ipa->have_c0 = true;
+  }
   *out = ipa;
   return SP_OK;
 }

@@ -81,11 +81,24 @@ SP_HD int msm_digit(const Fq& s, int w) { return msm_digit(s, w, msm_geom(MSM_WB
 // acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar. The table entry of the
 // next window is requested before the current mixed addition so the gather latency overlaps the 7 multiplications.
 // PF2: two table entries in flight instead of one (26 more registers: the foreground row MSM has them, the 1024-thread background form has not)
+#ifdef SP_EXP_E64
+// TIMING EXPERIMENT ONLY (wrong results): entries read as 64 bytes (y+x, y-x) at a 64-byte stride, 2dxy recomputed with two
+// multiplications when the entry is consumed
+struct MsmEntry { Fp yp, ym; };
+SP_HD Niels msm_entry_niels(const MsmEntry& e) {
+  Niels n; n.yp = e.yp; n.ym = e.ym;
+  n.t2d = fp_mul(fp_mul(fp_sub(e.yp, e.ym), fp_add(e.yp, e.ym)), fp_D2());
+  return n;
+}
+#else
+typedef Niels MsmEntry;
+SP_HD const Niels& msm_entry_niels(const MsmEntry& e) { return e; }
+#endif
 template <bool PF2>
 SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) {
   if (fq_is_zero(s_mont)) return;
   Fq s = fq_from_mont(s_mont);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
-  const Niels* base = table + pt * g.pt_entries;
+  const MsmEntry* base = reinterpret_cast<const MsmEntry*>(table) + pt * g.pt_entries;
   // digits are produced on the fly by shifting the scalar down one window per step (8 live registers instead of a
   // digit array; the loop stays rolled so the register budget allows a third wave per SIMD)
   const int c = g.wbits;
@@ -95,7 +108,7 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
   d -= carry << c;
   uint32_t m = (uint32_t)(d < 0 ? -d : d);
   bool ng = d < 0;
-  Niels cur = base[m ? m - 1 : 0];
+  MsmEntry cur = base[m ? m - 1 : 0];
   if (PF2) {
   // two table entries in flight (PMC: waves of the row MSM wait on memory 43 % of their cycles at every window width — the gathers
   // are latency-, not bandwidth- or translation-bound: profiles/r3_pmc_msm_translation_fabric.txt)
@@ -111,15 +124,15 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
   };
   int d1; uint32_t m1;
   next_digit(d1, m1);
-  Niels nx1 = base[(size_t)(g.nwin > 1 ? 1 : 0) * g.tent + (m1 ? m1 - 1 : 0)];
+  MsmEntry nx1 = base[(size_t)(g.nwin > 1 ? 1 : 0) * g.tent + (m1 ? m1 - 1 : 0)];
   bool ng1 = d1 < 0;
 #pragma unroll 1
   for (int w = 0; w < g.nwin; w++) {
     int d2; uint32_t m2;
     next_digit(d2, m2);  // window w + 2 (zero past the top: s < 2^253)
     int w2 = (w + 2 < g.nwin) ? w + 2 : g.nwin - 1;
-    Niels nx2 = base[(size_t)w2 * g.tent + (m2 ? m2 - 1 : 0)];
-    if (m != 0) acc = pt_madd(acc, cur, ng);
+    MsmEntry nx2 = base[(size_t)w2 * g.tent + (m2 ? m2 - 1 : 0)];
+    if (m != 0) acc = pt_madd(acc, msm_entry_niels(cur), ng);
     cur = nx1; m = m1; ng = ng1;
     nx1 = nx2; m1 = m2; ng1 = d2 < 0;
   }
@@ -135,8 +148,8 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
     dn -= carry << c;
     uint32_t mn = (uint32_t)(dn < 0 ? -dn : dn);
     int wn = (w + 1 < g.nwin) ? w + 1 : w;
-    Niels nxt = base[(size_t)wn * g.tent + (mn ? mn - 1 : 0)];
-    if (m != 0) acc = pt_madd(acc, cur, ng);
+    MsmEntry nxt = base[(size_t)wn * g.tent + (mn ? mn - 1 : 0)];
+    if (m != 0) acc = pt_madd(acc, msm_entry_niels(cur), ng);
     cur = nxt;
     m = mn;
     ng = dn < 0;
