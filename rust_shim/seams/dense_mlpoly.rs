@@ -79,6 +79,25 @@ impl DensePolynomial {
     let (left_num_vars, _right_num_vars) = EqPolynomial::compute_factored_lens(self.get_num_vars());
     assert_eq!(L.len(), left_num_vars.pow2());
     let t = self.table();
+    let shards = gpu::shard_ctxs();
+    let w = shards.len();
+    if w >= 2 && L.len() % w == 0 {
+      // row blocks. Shard g multiplies rows [g L/W, (g+1) L/W) by its slice of L; the W partial vectors are added in F_q
+      let (c, per, R_size) = (gpu::ctx(), L.len() / w, self.len() / L.len());
+      gpu::ok(unsafe { gpu::sp_ctx_sync(c) });
+      let mut parts: Vec<gpu::Table> = Vec::new();
+      let mut views: Vec<gpu::Table> = Vec::new();
+      for g in 0..w {
+        views.push(gpu::Table::view_on(shards[g], &t, g * per * R_size, per * R_size)); // sp_table_view on the shard's context
+        let mut pz = std::ptr::null_mut();
+        gpu::ok(unsafe { gpu::sp_vecmat_dev(shards[g], gpu::limbs(&L[g * per..]), per, views[g].0, &mut pz) });
+        parts.push(gpu::Table(pz));
+      }
+      for g in 1..w { gpu::ok(unsafe { gpu::sp_ctx_sync(shards[g]) }); }
+      for g in 1..w { gpu::ok(unsafe { gpu::sp_table_add_into(c, parts[0].0, parts[g].0) }); }
+      gpu::ok(unsafe { gpu::sp_ctx_sync(c) }); // the partial vectors go back to their contexts' pools when `parts` drops
+      return parts.swap_remove(0);
+    }
     let mut lz = std::ptr::null_mut();
     gpu::ok(unsafe { gpu::sp_vecmat_dev(gpu::ctx(), gpu::limbs(L), L.len(), t.0, &mut lz) });
     gpu::Table(lz)
@@ -99,6 +118,22 @@ impl DensePolynomial {
   pub fn evaluate(&self, r: &[Scalar]) -> Scalar {
     assert_eq!(r.len(), self.get_num_vars());
     let t = self.table();
+    let shards = gpu::shard_ctxs();
+    let (w, lw) = (shards.len(), shards.len().max(1).trailing_zeros() as usize);
+    if w >= 2 && r.len() > lw + 1 {
+      // <Z, chi(r)> = sum_g chi_g(r[..lw]) <Z_g, chi(r[lw..])> over contiguous chunks, one scalar per shard
+      gpu::ok(unsafe { gpu::sp_ctx_sync(gpu::ctx()) });
+      let top = EqPolynomial::new(r[..lw].to_vec()).evals();
+      let chunk = self.len() / w;
+      let mut acc = Scalar::zero();
+      for g in 0..w {
+        let v = gpu::Table::view_on(shards[g], &t, g * chunk, chunk);
+        let mut e = Scalar::zero();
+        gpu::ok(unsafe { gpu::sp_evaluate(shards[g], v.0, gpu::limbs(&r[lw..]), r.len() - lw, &mut e as *mut Scalar as *mut u64) });
+        acc += top[g] * e;
+      }
+      return acc;
+    }
     let mut out = Scalar::zero();
     gpu::ok(unsafe { gpu::sp_evaluate(gpu::ctx(), t.0, gpu::limbs(r), r.len(), &mut out as *mut Scalar as *mut u64) });
     out

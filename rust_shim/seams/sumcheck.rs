@@ -6,6 +6,73 @@ use super::commitments::commit_small;
 use super::gpu::{self, sp_host_point, sp_table};
 
 // ------------------------------------------------------------------------------------------------------------------
+// the tables of a ZK sum-check sharded by index residue (C++ rendering: ResidueShards, spartan_amd/host/prover.cc).
+// Shard g of W holds T_g[k] = T[k W + g] of every table; the top-variable pair (i, i + len/2) stays on one shard while len/2 is a
+// multiple of W, so every shard runs the ordinary round kernels on its sub-tables and a round exchanges its 2..3 partial sums,
+// added here in F_q. When the sub-tables are down to two entries they are bound to one and the W survivors of every table go
+// back into the owner's tables; the last log2(W) rounds run unsharded. Same field values, same proof bytes.
+#[cfg(feature = "gpu")]
+struct ResidueShards {
+  ctxs: Vec<*mut gpu::sp_ctx>,
+  sub: Vec<Vec<gpu::Table>>, // [shard][table]
+  active: bool,
+}
+#[cfg(feature = "gpu")]
+impl ResidueShards {
+  fn split(tabs: &[*mut sp_table]) -> Self {
+    let ctxs = gpu::shard_ctxs();
+    let (w, len) = (ctxs.len(), unsafe { gpu::sp_table_len(tabs[0]) });
+    if w < 2 || len < 4 * w { return ResidueShards { ctxs: Vec::new(), sub: Vec::new(), active: false }; }
+    gpu::ok(unsafe { gpu::sp_ctx_sync(gpu::ctx()) }); // the tables as produced by everything queued on the owning context
+    let sub = (0..w)
+      .map(|g| tabs.iter().map(|&t| { let mut o = std::ptr::null_mut(); gpu::ok(unsafe { gpu::sp_table_residue_split(ctxs[g], t, w, g, &mut o) }); gpu::Table(o) }).collect())
+      .collect();
+    ResidueShards { ctxs, sub, active: true }
+  }
+  fn sub_len(&self) -> usize { unsafe { gpu::sp_table_len(self.sub[0][0].0) } }
+  fn handles(&self, g: usize) -> Vec<*mut sp_table> { self.sub[g].iter().map(|t| t.0).collect() }
+  fn add_partials(parts: &[[Scalar; 3]], n: usize, ev: &mut [Scalar]) { for k in 0..n { ev[k] = parts.iter().map(|p| p[k]).sum(); } }
+  fn eval(&self, kind: i32, ev: &mut [Scalar]) {
+    let mut parts = vec![[Scalar::zero(); 3]; self.ctxs.len()];
+    for g in 0..self.ctxs.len() {
+      let h = self.handles(g);
+      gpu::ok(unsafe { gpu::sp_sumcheck_eval(self.ctxs[g], kind, h.as_ptr(), h.len(), gpu::limbs_mut(&mut parts[g])) });
+    }
+    Self::add_partials(&parts, if kind == 0 { 2 } else { 3 }, ev);
+  }
+  fn bind_eval_start(&self, kind: i32, r: &Scalar) { // every shard's bind + next evaluation in flight together (own streams)
+    for g in 0..self.ctxs.len() {
+      let h = self.handles(g);
+      gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_start(self.ctxs[g], kind, h.as_ptr(), h.len(), gpu::limbs1(r)) });
+    }
+  }
+  fn bind_eval_collect(&self, kind: i32, ev: &mut [Scalar]) {
+    let mut parts = vec![[Scalar::zero(); 3]; self.ctxs.len()];
+    for g in 0..self.ctxs.len() { gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_collect(self.ctxs[g], gpu::limbs_mut(&mut parts[g])) }); }
+    Self::add_partials(&parts, if kind == 0 { 2 } else { 3 }, ev);
+  }
+  /// sub-tables of two entries: bind them to one and hand the W survivors of every table back to the owner's tables
+  fn bind_last_and_gather(&mut self, r: &Scalar, tabs: &[*mut sp_table]) {
+    let w = self.ctxs.len();
+    let heads: Vec<Vec<Scalar>> = (0..w)
+      .map(|g| {
+        let h = self.handles(g);
+        let mut v = vec![Scalar::zero(); h.len()];
+        gpu::ok(unsafe { gpu::sp_table_bind_top_heads(self.ctxs[g], h.as_ptr(), h.len(), gpu::limbs1(r), gpu::limbs_mut(&mut v)) });
+        v
+      })
+      .collect();
+    for (t, &tab) in tabs.iter().enumerate() {
+      let v: Vec<Scalar> = (0..w).map(|g| heads[g][t]).collect();
+      gpu::ok(unsafe { gpu::sp_table_write(gpu::ctx(), tab, 0, gpu::limbs(&v), w) });
+      gpu::ok(unsafe { gpu::sp_table_set_len(tab, w) });
+    }
+    self.sub.clear();
+    self.active = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // ZKSumcheckInstanceProof::prove_quad (:428-586, kind 0: A*B over gens_3) and ::prove_cubic_with_additive_term (:588-776,
 // kind 2: A*(B*C - D) over gens_4) share everything but `kind`.
 // Round j: the device binds the tables at r_j and evaluates round j+1 in the same pass (sp_sumcheck_bind_eval_start ..
@@ -63,7 +130,8 @@ impl ZKSumcheckInstanceProof {
     };
 
     let mut ev = vec![Scalar::zero(); 3];
-    gpu::ok(unsafe { gpu::sp_sumcheck_eval(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs_mut(&mut ev)) });
+    let mut rs = if on_host { ResidueShards::split(&tabs) } else { ResidueShards { ctxs: Vec::new(), sub: Vec::new(), active: false } };
+    if rs.active { rs.eval(kind, &mut ev); } else { gpu::ok(unsafe { gpu::sp_sumcheck_eval(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs_mut(&mut ev)) }); }
     let mut claim_per_round = *claim;
     let mut poly = make_poly(&ev, &claim_per_round);
     assert_eq!(poly.as_vec().len(), nn);
@@ -93,9 +161,17 @@ impl ZKSumcheckInstanceProof {
       };
       // bind every table at r_j (:485-486 / :673-676), fused with the next round's evaluations (:460-469 / :624-652)
       let len = unsafe { gpu::sp_table_len(tabs[0]) };
-      let (comm_eval, delta, pending);
+      let (comm_eval, delta, mut pending);
+      let mut resharded = false; // the shards have just handed their last entries back: the next evaluation is a call of its own
       if on_host {
-        if len >= 4 {
+        if rs.active && rs.sub_len() >= 4 {
+          rs.bind_eval_start(kind, &r_j);
+          pending = true;
+        } else if rs.active {
+          rs.bind_last_and_gather(&r_j, &tabs);
+          resharded = true;
+          pending = false;
+        } else if len >= 4 {
           gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_start(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs1(&r_j)) });
           pending = true;
         } else {
@@ -159,7 +235,12 @@ impl ZKSumcheckInstanceProof {
         let cm2 = commit_rows(&rows2, 2, Some(&[std::ptr::null(), ahead.as_ref().unwrap().wait(j).rb_h()]));
         Cy = cm2[0];
         beta = cm2[1];
-        if pending { gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_collect(gpu::ctx(), gpu::limbs_mut(&mut ev)) }); }
+        if pending && rs.active { rs.bind_eval_collect(kind, &mut ev); }
+        else if pending { gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_collect(gpu::ctx(), gpu::limbs_mut(&mut ev)) }); }
+        if resharded && more {
+          gpu::ok(unsafe { gpu::sp_sumcheck_eval(gpu::ctx(), kind, tabs.as_ptr(), tabs.len(), gpu::limbs_mut(&mut ev)) });
+          pending = true;
+        }
         next = if more {
           assert!(pending);
           let np = make_poly(&ev, &eval);

@@ -121,5 +121,5 @@ def test_rust_seams_call_what_the_driver_calls():
     seams = calls(glob.glob(os.path.join(ROOT, "rust_shim", "seams", "*.rs")) + [os.path.join(ROOT, "rust_shim", "src", "gpu_tail.rs.in")])
     assert len(driver) >= 55
     assert driver - seams == set(), f"called by the C++ driver, by no Rust seam: {sorted(driver - seams)}"
-    # what only the Rust side touches: helpers of its own handle types
-    assert seams - driver <= {"sp_gens_upload", "sp_table_download"}, f"called by a seam, never by the driver: {sorted(seams - driver)}"
+    # what only the Rust side touches: helpers of its own handle types (the C++ side keeps its shard contexts in shard.cc)
+    assert seams - driver <= {"sp_gens_upload", "sp_table_download", "sp_ctx_device"}, f"called by a seam, never by the driver: {sorted(seams - driver)}"
