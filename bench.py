@@ -105,6 +105,14 @@ def cpu_baseline(log2_cons, threads=1):
     out = {"value": N / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
            "sample": f"oracle SNARK::prove, produce_synthetic_r1cs 2^{log2_cons}, {dt:.2f} s on {threads} thread(s) of {model} ({os.cpu_count()} logical cores)"}
     # the oracle's MSM next to the README's dalek figures: 2^s scalars in polycommit, 8 * 2^s in the derefs commitment
+    # the same oracle at the metric's own size (2^20), timed once off-line: profiles/oracle_snark_2p20_timing.py
+    try:
+        ft = json.load(open(os.path.join(ROOT, "profiles", "r3_oracle_snark_2p20_timing.json")))
+        one = [r for r in ft["runs"] if r["threads"] == 1][0]
+        out["at_metric_size"] = {"log2_cons": 20, "seconds": one["seconds"], "constraints_per_s": one["constraints_per_s"], "threads": 1, "cpu": ft["cpu_model"],
+                                 "proof_sha256": one["proof_sha256"], "source": "profiles/r3_oracle_snark_2p20_timing.json (build container, not this box)"}
+    except (OSError, KeyError, IndexError, ValueError):
+        pass
     if tm[0] > 0 and tm[6] > 0:
         out["us_per_scalar"] = {"polycommit": tm[0] / N * 1e6, "commit_nondet_witness": tm[6] / (8 * N) * 1e6, "readme_i7_1065G7": README_US_PER_SCALAR}
     return out
