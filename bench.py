@@ -367,7 +367,7 @@ def main():
         f = fam[dom]
         avg_ms = f["ms"] / f["launches"]
         ach = (f["alg_bytes"] / f["launches"]) / (avg_ms * 1e-3) / 1e9
-        pmc, pmc_note = None, "no PMC file for these kernel sources and this instance size: collect with profiles/collect_r2.sh + profiles/pmc_summarize.py"
+        pmc, pmc_note = None, "no PMC file for these kernel sources and this instance size: collect with profiles/collect_r3.sh + profiles/pmc_summarize.py"
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pj.get("kernel_source_digest") == kernel_source_digest() and pj.get("log2_cons", 20) == s and dom in pj:
@@ -401,7 +401,7 @@ def main():
             e = {"shape": f'{sh["rows"]} x {sh["cols"]}', "what": nm[0], "launch_ms": round(lms, 4), "window_bits": wb_eval if nm[2] else wb_sat, "mixed_additions": madds,
                  "achieved_G_per_s": round(madds / lms / 1e6, 2)}
             if sh["background"]:   # k_msm_rows_bg holds SPARTAN_BG_EIGHTHS/8 of the CUs (one persistent 1024-thread workgroup each)
-                e["cu_share"] = int(os.environ.get("SPARTAN_BG_EIGHTHS", "4")) / 8
+                e["cu_share"] = int(os.environ.get("SPARTAN_BG_EIGHTHS", "5")) / 8  # core.hip ctx_init: share of the CUs the persistent background MSM is launched on
             if ceil:
                 e["frac"] = round(madds / lms / 1e6 / ceil["pt_madd_G_per_s"], 3)
                 if sh["background"] and e["cu_share"] > 0:
