@@ -387,7 +387,7 @@ def main():
             # scalars that are actually non-zero: the derefs polynomial holds 6 * 2^s values, its top quarter is padding
             rows_row_half = 3 * N // R
             named[(1 << (s // 2), 1 << (s - s // 2), False)] = ("witness commit (poly_vars, + one blind per row)", N + (1 << (s // 2)), False)
-            named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, half of the CUs)", 3 * N, True)
+            named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, SPARTAN_BG_EIGHTHS/8 of the CUs)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, True)] = ("derefs commit, column half (+ zero padding rows; background stream behind the row half)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (+ zero padding rows)", 3 * N, True)
         alu_shapes = []
