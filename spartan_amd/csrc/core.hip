@@ -897,7 +897,8 @@ static std::list<GensCacheEntry> g_gens_cache;
 // latency-bound kernels that run next to a background commit ("the derefs window"); swept at 2^20
 // (profiles/r2_window_width_sweep.txt) the proof is fastest with 14 bits for the 4098-point evaluation stream (61 GB) and
 // 15 bits for the 1025-point one (27 GB). So the width is chosen by proof time, not by launch time:
-//   * 15 bits while the set's table stays under SPARTAN_MSM_WIDE_GB (default 32),
+//   * 15 bits while the set's table stays under SPARTAN_MSM_WIDE_GB (default 64: the 2049-point stream of a 2^22 instance, 55 GB, keeps them —
+//     72.7 -> 71.3 ms per proof — the 4098-point one of 2^20, 110 GB, does not),
 //   * otherwise the widest of 14/13/12/10/8 that fits the budget SPARTAN_MSM_TABLE_GB (default 128 per set),
 //   * and never more than the free device memory less a reserve for the proof's own tables (24 GB, applied only to
 //     tables that are themselves large: a 1.5 MB table set must not be refused because another process holds the HBM).
@@ -908,7 +909,7 @@ static int choose_wbits(size_t n) {
     int v = atoi(e);
     if (v >= 4 && v <= 15) return v;
   }
-  double budget = 128.0, wide = 32.0;
+  double budget = 128.0, wide = 64.0;
   if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }
   if (const char* e = getenv("SPARTAN_MSM_WIDE_GB")) { double v = atof(e); if (v > 0) wide = v; }
   size_t free_b = 0, total_b = 0;
