@@ -65,15 +65,29 @@ for ni, n0 in ((16, 512), (16, 64), (4, 512)):
 
 # ---------------------------------------------------------------- k_ipa_round
 orc = load_oracle()
-for n in (4096, 1024):
-    g = capi.Gens(ctx, compressed=gens_bytes(orc, n + 1, b"gens_r1cs_eval"))  # n generators, Q base, h
+import numpy as np
+g_big = capi.Gens(ctx, compressed=gens_bytes(orc, 4096 + 1, b"gens_r1cs_eval"))  # the 4096-generator set: also the background MSM's
+rows_bg = 768
+Zbg = np.random.default_rng(3).integers(0, 2**64, size=(rows_bg * 4096, 4), dtype=np.uint64); Zbg[:, 3] &= np.uint64((1 << 60) - 1)
+tbg = capi.Table.upload(ctx, Zbg.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), rows_bg * 4096)
+lab = [(0, 1, "first workgroup: start -> scalar a'[i] s'[p] (folds + product)"), (1, 2, "digit + table entry gathered (HBM)"), (2, 3, "entry -> extended point (1 F_p mult), radix-2^25.5"),
+       (3, 4, "LDS tree over 256 points (8 levels)"), (4, 5, "partial sum out, fence, ticket"), (0, 5, "first workgroup, whole"),
+       (8, 9, "reducing workgroup: fence + load of the row's partials"), (9, 10, "LDS tree over the partials"), (10, 11, "convert + store to the host page"),
+       (0, 11, "first stamp -> row sum stored (critical path of the launch)")]
+for n, under_bg in ((4096, False), (1024, False), (1024, True)):
+    g = g_big if n == 4096 else capi.Gens(ctx, compressed=gens_bytes(orc, n + 1, b"gens_r1cs_sat"))  # n generators, Q base, h
     a = mont_bulk(fast_scalars(rng, n)); b = mont_bulk(fast_scalars(rng, n))
     ipa = vp()
     assert lib.sp_ipa_begin(ctx.h, g.h, sz(0), sz(n), sz(n), sz(n + 1), fq1(7), a, b, ctypes.byref(ipa)) == 0
+    job = vp()
     L = (ctypes.c_uint8 * 32)(); R = (ctypes.c_uint8 * 32)()
     rows, host = [], []
     k = n
     while k >= 2:
+        if k == n // 2 and under_bg:  # after the first round (it builds the host-side tables of Q and h: milliseconds, once per generator set):
+            # the derefs row half as the prover starts it, 768 x 4096 on the background stream (5/8 of the CUs), ~5.5 ms
+            assert lib.sp_commit_rows_dev_begin(ctx.h, g_big.h, sz(0), tbg.h, sz(0), sz(rows_bg), sz(4096), ctypes.byref(job)) == 0
+            time.sleep(0.0003)
         t0 = time.perf_counter()
         assert lib.sp_ipa_round_lr(ipa, fq1(rng.randrange(Q)), fq1(rng.randrange(Q)), L, R) == 0
         host.append((time.perf_counter() - t0) * 1e6)
@@ -81,13 +95,13 @@ for n in (4096, 1024):
         u = rng.randrange(Q)
         assert lib.sp_ipa_round_fold(ipa, fq1(u), fq1(pow(u, Q - 2, Q))) == 0
         k //= 2
+    if under_bg:
+        sink = (ctypes.c_uint8 * (32 * rows_bg))()
+        assert lib.sp_job_wait(job, sink) == 0
     lib.sp_ipa_free(ipa)
-    print("==== k_ipa_round, n = %d generators (%d-bit windows), %d rounds; host time of sp_ipa_round_lr per round: %s us" %
-          (n, g.window_bits(), len(rows), " ".join("%.0f" % h for h in host)))
-    lab = [(0, 1, "first workgroup: start -> scalar a'[i] s'[p] (folds + product)"), (1, 2, "digit + table entry gathered (HBM)"), (2, 3, "entry -> extended point (1 F_p mult), radix-2^25.5"),
-           (3, 4, "LDS tree over 256 points (8 levels)"), (4, 5, "partial sum out, fence, ticket"), (0, 5, "first workgroup, whole"),
-           (8, 9, "reducing workgroup: fence + load of the row's partials"), (9, 10, "LDS tree over the partials"), (10, 11, "convert + store to the host page"),
-           (0, 11, "first stamp -> row sum stored (critical path of the launch)")]
+    print("==== k_ipa_round, n = %d generators (%d-bit windows)%s, %d rounds; host time of sp_ipa_round_lr per round: %s us" %
+          (n, g.window_bits(), " WHILE the background MSM (768 x 4096) runs" if under_bg else "", len(rows), " ".join("%.0f" % h for h in host)))
     show("  per round (medians over the rounds):", rows, lab)
-    g.free()
+    if g is not g_big: g.free()
+tbg.free(); g_big.free()
 ctx.close()
