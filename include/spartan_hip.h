@@ -224,6 +224,10 @@ int32_t sp_sparse_eval_table(sp_ctx* ctx, const sp_sparse* const* ms, const uint
                              sp_table** out);
 /* evaluate_with_tables (sparse_mlpoly.rs:429-438): sum tx[row] * ty[col] * val. */
 int32_t sp_sparse_evaluate(sp_ctx* ctx, const sp_sparse* m, const sp_table* tx, const sp_table* ty, uint64_t out[4]);
+/* The same for up to four matrices at once, queued on a low-priority stream and collected with sp_job_wait (32 bytes per matrix, in
+ * order): SNARK::prove (src/lib.rs:393-400) starts R1CSInstance::evaluate as soon as ry is known and collects the three values after
+ * the witness opening. tx and ty must outlive the job. */
+int32_t sp_sparse_evaluate_begin(sp_ctx* ctx, const sp_sparse* const* ms, size_t count, const sp_table* tx, const sp_table* ty, sp_job** out);
 
 /* ---- inner-product argument: BulletReductionProof::prove (src/nizk/bullet.rs:32-132) -----------------
  * The folded generators G^(k) are never materialised: G^(k)[i] = sum_p s_k[p] * G[p*n_k + i] with

@@ -51,16 +51,33 @@ impl SNARK {
     let overlap = std::env::var_os("SPARTAN_NO_OVERLAP").is_none();
     let ry_len = inst.inst.get_num_vars().log_2() + 1;
     let mut early: Option<DerefsEarly> = None;
+    let mut rx_seen: Vec<Scalar> = Vec::new();
     let mut on_rx = |rx: &[Scalar]| {
+      rx_seen = rx.to_vec();
       early = Some(SparseMatPolyEvalProof::derefs_early_begin(&decomm.decomm.dense, &gens.gens_r1cs_eval.gens.gens_derefs, rx, ry_len));
+    };
+    // R1CSInstance::evaluate (r1cs.rs:300-303) needs rx, ry only: queued on a low-priority stream when the second sum-check ends
+    // (sp_sparse_evaluate_begin), it runs in the idle time of the witness opening; collected below with sp_job_wait
+    let eval_ahead = overlap && std::env::var_os("SPARTAN_NO_EVAL_AHEAD").is_none();
+    let mut ahead: Option<(gpu::Table, gpu::Table, gpu::CommitJob)> = None;
+    let mut on_ry = |ry: &[Scalar]| {
+      let (tx, ty) = (gpu::Table::eq(&rx_seen), gpu::Table::eq(ry));
+      let ms = [inst.inst.A.dev.as_ref().unwrap().0 as *const gpu::sp_sparse, inst.inst.B.dev.as_ref().unwrap().0 as *const gpu::sp_sparse,
+                inst.inst.C.dev.as_ref().unwrap().0 as *const gpu::sp_sparse];
+      let mut job = std::ptr::null_mut();
+      gpu::ok(unsafe { gpu::sp_sparse_evaluate_begin(gpu::ctx(), ms.as_ptr(), 3, tx.0, ty.0, &mut job) });
+      ahead = Some((tx, ty, gpu::CommitJob { job, rows: 3 }));
     };
     let (r1cs_sat_proof, rx, ry) = {
       let src = match &vars.dev { Some(t) => gpu::VarsSource::Resident(t), None => gpu::VarsSource::Host(&vars.assignment) };
       R1CSProof::prove_gpu(&inst.inst, src, &inputs.assignment, &gens.gens_r1cs_sat, transcript, random_tape,
-        ProveHooks { transcript_prefix: &mut prefix, on_rx: if overlap { Some(&mut on_rx) } else { None }, on_ry: None })
+        ProveHooks { transcript_prefix: &mut prefix, on_rx: if overlap { Some(&mut on_rx) } else { None }, on_ry: if eval_ahead { Some(&mut on_ry) } else { None } })
     };
     let inst_evals = {
-      let (Ar, Br, Cr) = inst.inst.evaluate_dev(&rx, &ry); // 3 x sp_sparse_evaluate
+      let (Ar, Br, Cr) = match ahead.take() {
+        Some((_tx, _ty, job)) => { let v = job.wait_scalars(); (v[0], v[1], v[2]) } // sp_job_wait: 3 x 32 bytes of Montgomery limbs
+        None => inst.inst.evaluate_dev(&rx, &ry), // 3 x sp_sparse_evaluate
+      };
       Ar.append_to_transcript(b"Ar_claim", transcript);
       Br.append_to_transcript(b"Br_claim", transcript);
       Cr.append_to_transcript(b"Cr_claim", transcript);

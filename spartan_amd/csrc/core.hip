@@ -745,6 +745,7 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
     HIPCHK(hipStreamCreateWithPriority(&c->stream_side, hipStreamNonBlocking, hi));
     HIPCHK(hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithPriority(&c->stream_bg, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream_low, hipStreamNonBlocking, lo));
     // background MSMs: one 1024-thread workgroup per CU on half of the CUs (k_msm_rows_bg). Measured at 2^20 with the
     // derefs row half in the background, share in eighths 2 / 3 / 4 / 5 / 6 / 8 -> 63.1 / 59.2 / 58.0 / 59.0 / 61.5 / 62.5 ms
     // per proof (63.3 without the overlap): less and the MSM is not done when it is needed, more and the second
@@ -792,6 +793,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->side_ev) (void)hipEventDestroy(c->side_ev);
   if (c->stream_side) (void)hipStreamDestroy(c->stream_side);
   if (c->stream_bg) (void)hipStreamDestroy(c->stream_bg);
+  if (c->stream_low) (void)hipStreamDestroy(c->stream_low);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1175,13 +1177,6 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
 }
 
 // ---- background commit (overlaps a throughput-bound MSM with the latency-bound rounds that follow on the main stream)
-struct sp_job {
-  sp_ctx* ctx;
-  uint8_t* scratch;
-  size_t scratch_bytes, rows, out_off;
-  hipEvent_t done;
-  hipStream_t stream;  // the stream the job runs on (background, or the main stream for sp_commit_rows_dev_start)
-};
 int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t rows, size_t cols,
                                  sp_job** out) {
   if (!c || !g || !Z || !out || rows == 0 || cols == 0 || g_off + cols > g->n || z_off + rows * cols > Z->cap) return SP_EINVAL;

@@ -49,12 +49,22 @@ struct ProfShape {
   uint64_t n = 0;
 };
 
+// a queued job collected later with sp_job_wait: 32 * rows result bytes at scratch + out_off once `done` has fired
+struct sp_job {
+  sp_ctx* ctx;
+  uint8_t* scratch;
+  size_t scratch_bytes, rows, out_off;
+  hipEvent_t done;
+  hipStream_t stream;  // the stream the job runs on (a background stream, or the main stream for sp_commit_rows_dev_start)
+};
+
 struct sp_ctx {
   int dev;
   hipStream_t stream;
   hipStream_t stream_side;  // same priority as `stream`: small commitments that run NEXT TO a sum-check kernel of the same round
   hipEvent_t side_ev;
   hipStream_t stream_bg;  // lower-priority background stream: throughput MSMs overlapped with latency-bound rounds
+  hipStream_t stream_low = nullptr;  // a second low-priority stream: short streaming jobs (sp_sparse_evaluate_begin) that must not queue behind a background MSM
   bool device_encode;     // SPARTAN_DEVICE_ENCODE: small commitments are encoded by the device too (100 us instead of 3 us each)
   int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
   size_t bg_lds;          // dynamic LDS each of them claims (a whole CU's)

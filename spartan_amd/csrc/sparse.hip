@@ -54,6 +54,32 @@ __global__ void __launch_bounds__(256) k_sparse_eval(const uint32_t* __restrict_
   if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
 }
 
+// several matrices in one launch (grid.y = matrix): partials[m * gridDim.x + blk]
+struct SparseMany {
+  const uint32_t *row[4], *col[4];
+  const Fq* val[4];
+  size_t nnz[4];
+};
+__global__ void __launch_bounds__(256) k_sparse_eval_many(SparseMany M, const Fq* __restrict__ tx, const Fq* __restrict__ ty, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  const int m = blockIdx.y;
+  const uint32_t* __restrict__ row = M.row[m];
+  const uint32_t* __restrict__ col = M.col[m];
+  const Fq* __restrict__ val = M.val[m];
+  Fq acc[1] = {fq_zero()};
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < M.nnz[m]; e += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fq_add(acc[0], fq_mul(fq_mul(ld_fq(tx + row[e]), ld_fq(ty + col[e])), ld_fq(val + e)));
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(partials + (size_t)m * gridDim.x + blockIdx.x, acc[0]);
+}
+__global__ void __launch_bounds__(256) k_sparse_sums(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out) {  // block per matrix
+  __shared__ Fq sm[256];
+  Fq acc[1] = {fq_zero()};
+  for (size_t b = threadIdx.x; b < nblk; b += 256) acc[0] = fq_add(acc[0], ld_fq(partials + (size_t)blockIdx.x * nblk + b));
+  block_sum_fq<1>(acc, sm);
+  if (threadIdx.x == 0) st_fq(out + blockIdx.x, acc[0]);
+}
+
 template <typename T>
 static int32_t dev_put(sp_ctx* c, T** d, const std::vector<T>& h) {
   size_t bytes = sizeof(T) * (h.size() ? h.size() : 1);
@@ -152,6 +178,50 @@ int32_t sp_sparse_evaluate(sp_ctx* c, const sp_sparse* m, const sp_table* tx, co
                        (const Fq*)m->csr_val, m->nnz, (const Fq*)tx->d, (const Fq*)ty->d, partials);
   }
   return reduce_and_fetch(c, partials, nblk, 1, out);
+}
+
+// R1CSInstance::evaluate (r1cs.rs:300-303) of up to four matrices, queued on a low-priority stream of its own and collected with
+// sp_job_wait (32 bytes per matrix): SNARK::prove starts it as soon as the second sum-check has fixed ry, and the kernels fill the
+// idle time of the witness opening (an inner-product argument: launch-sized kernels and host trips) instead of standing on the
+// critical path behind it. tx, ty must stay alive until the job has been waited for.
+int32_t sp_sparse_evaluate_begin(sp_ctx* c, const sp_sparse* const* ms, size_t count, const sp_table* tx, const sp_table* ty, sp_job** out) {
+  if (!c || !ms || !tx || !ty || !out || count == 0 || count > 4) return SP_EINVAL;
+  SparseMany M;
+  memset(&M, 0, sizeof M);
+  size_t max_nnz = 1;
+  double bytes = 0;
+  for (size_t k = 0; k < count; k++) {
+    if (!ms[k] || tx->len < ms[k]->num_rows || ty->len < ms[k]->num_cols) return SP_EINVAL;
+    M.row[k] = ms[k]->csr_row; M.col[k] = ms[k]->csr_col; M.val[k] = ms[k]->csr_val; M.nnz[k] = ms[k]->nnz;
+    if (ms[k]->nnz > max_nnz) max_nnz = ms[k]->nnz;
+    bytes += (double)ms[k]->nnz * (8 + 96);
+  }
+  HIPCHK(hipSetDevice(c->dev));
+  if (!c->stream_low) return SP_EHIP;
+  const size_t nblk = grid_for(max_nnz, 1024);
+  sp_job* j = new (std::nothrow) sp_job();
+  if (!j) return SP_ENOMEM;
+  j->ctx = c; j->rows = count; j->stream = c->stream_low; j->scratch = nullptr;
+  j->out_off = 32 * nblk * count;
+  j->scratch_bytes = j->out_off + 32 * count;
+  int32_t rc = pool_alloc(c, j->scratch_bytes, (void**)&j->scratch);
+  if (rc != SP_OK) { delete j; return rc; }
+  hipEvent_t ready;
+  if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&j->done, hipEventDisableTiming) != hipSuccess) {
+    pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP;
+  }
+  (void)hipEventRecord(ready, c->stream);  // tx, ty as produced by what is queued on the main stream
+  (void)hipStreamWaitEvent(c->stream_low, ready, 0);
+  {
+    ProfScope ps(c, PF_SPARSE, bytes, c->stream_low);
+    hipLaunchKernelGGL(k_sparse_eval_many, dim3((unsigned)nblk, (unsigned)count), dim3(256), 0, c->stream_low, M, (const Fq*)tx->d, (const Fq*)ty->d, (Fq*)j->scratch);
+    hipLaunchKernelGGL(k_sparse_sums, dim3((unsigned)count), dim3(256), 0, c->stream_low, (const Fq*)j->scratch, nblk, (Fq*)(j->scratch + j->out_off));
+  }
+  (void)hipEventRecord(j->done, c->stream_low);
+  (void)hipEventDestroy(ready);
+  if (hipGetLastError() != hipSuccess) { (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  *out = j;
+  return SP_OK;
 }
 
 }  // extern "C"
