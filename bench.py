@@ -387,6 +387,8 @@ def main():
             # scalars that are actually non-zero: the derefs polynomial holds 6 * 2^s values, its top quarter is padding
             rows_row_half = 3 * N // R
             named[(1 << (s // 2), 1 << (s - s // 2), False)] = ("witness commit (poly_vars, + one blind per row)", N + (1 << (s // 2)), False)
+            if (1 << (s // 2)) % 1024 == 0:  # host assignment: four row chunks, each launched behind its PCIe copy (sp_commit_rows_upload_start)
+                named[((1 << (s // 2)) // 4, 1 << (s - s // 2), False)] = ("witness commit, one of four row chunks (each launched behind its PCIe copy)", (N + (1 << (s // 2))) // 4, False)
             named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, SPARTAN_BG_EIGHTHS/8 of the CUs)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, True)] = ("derefs commit, column half (+ zero padding rows; background stream behind the row half)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (+ zero padding rows)", 3 * N, True)

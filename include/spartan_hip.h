@@ -109,6 +109,11 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* ctx, const sp_gens* g, size_t g_off, co
  * this context until it has waited for this job. */
 int32_t sp_commit_rows_dev_start(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows,
                                  size_t cols, const uint64_t* blinds, sp_job** out);
+/* The same commitment when the rows are still in host memory (the assignment SNARK::prove is handed, src/lib.rs:339-344): the rows
+ * are copied into Z[z_off, z_off + rows*cols) in chunks and each chunk's additions are launched behind its copy, so the MSM overlaps
+ * the PCIe transfer; one reduction and encode at the end. Collected with sp_job_wait; src must stay valid until the call returns. */
+int32_t sp_commit_rows_upload_start(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, sp_table* Z, size_t z_off, const uint64_t* src, size_t rows,
+                                    size_t cols, const uint64_t* blinds, sp_job** out);
 int32_t sp_job_wait(sp_job* job, uint8_t* out /*32*rows*/);
 /* Small/irregular commits (Scalar::commit, UniPoly::commit, the Sigma-protocol commitments of
  * src/nizk/mod.rs, the per-round L/R of src/nizk/bullet.rs:83-97 re-expressed over the ORIGINAL generators):

@@ -30,15 +30,31 @@ impl R1CSProof {
     assert!(input.len() < num_vars);
     // polycommit (:160-171): the padded assignment as a zero-filled device table with the given prefix written into it
     let poly_vars = DensePolynomial::from_dev(gpu::Table::alloc_zeroed(num_vars)); // sp_table_alloc
-    match vars {
-      gpu::VarsSource::Resident(t) => gpu::ok(unsafe { gpu::sp_table_copy(c, poly_vars.dev.as_ref().unwrap().0, 0, t.0, 0, t.len()) }),
-      gpu::VarsSource::Host(v) => gpu::ok(unsafe { gpu::sp_table_write(c, poly_vars.dev.as_ref().unwrap().0, 0, gpu::limbs(v), v.len()) }),
-    }
     let ell = poly_vars.get_num_vars();
     let (left_num_vars, _) = EqPolynomial::compute_factored_lens(ell);
     let L_size = left_num_vars.pow2();
+    // a host assignment of full length goes up and is committed in one call: the additions of a chunk of rows run while the next chunk
+    // crosses PCIe (sp_commit_rows_upload_start); otherwise upload / copy first, then commit
+    let upload_commit = matches!(&vars, gpu::VarsSource::Host(v) if v.len() == num_vars) && L_size > 8;
+    match &vars {
+      gpu::VarsSource::Resident(t) => gpu::ok(unsafe { gpu::sp_table_copy(c, poly_vars.dev.as_ref().unwrap().0, 0, t.0, 0, t.len()) }),
+      gpu::VarsSource::Host(v) if !upload_commit => gpu::ok(unsafe { gpu::sp_table_write(c, poly_vars.dev.as_ref().unwrap().0, 0, gpu::limbs(v), v.len()) }),
+      _ => {}
+    }
     let blinds_vars = PolyCommitmentBlinds { blinds: random_tape.random_vector(b"poly_blinds", L_size) };
-    let job = if L_size > 8 { Some(poly_vars.commit_start(Some(&blinds_vars.blinds), &gens.gens_pc.gens.gens_n, 0, L_size)) } else { None };
+    let job = if upload_commit {
+      let (g, v) = (&gens.gens_pc.gens.gens_n, match &vars { gpu::VarsSource::Host(v) => *v, _ => unreachable!() });
+      let mut job = std::ptr::null_mut();
+      gpu::ok(unsafe {
+        gpu::sp_commit_rows_upload_start(c, g.dev.g, g.dev.G[0] as usize, g.dev.h as usize, poly_vars.dev.as_ref().unwrap().0, 0, gpu::limbs(v), L_size, g.n,
+                                         gpu::limbs(&blinds_vars.blinds), &mut job)
+      });
+      Some(gpu::CommitJob { job, rows: L_size })
+    } else if L_size > 8 {
+      Some(poly_vars.commit_start(Some(&blinds_vars.blinds), &gens.gens_pc.gens.gens_n, 0, L_size))
+    } else {
+      None
+    };
     (hooks.transcript_prefix)(transcript);
     transcript.append_protocol_name(R1CSProof::protocol_name());
     input.append_to_transcript(b"input", transcript);

@@ -1052,7 +1052,8 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
 // (encode) or, with encode = false, 128*rows bytes of extended points
 static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows,
                         size_t cols, size_t g_off, const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* scratch, uint8_t* dout,
-                        bool encode = true, uint8_t* sums_extra = nullptr /* 128*rows bytes for the row sums, or null */) {
+                        bool encode = true, uint8_t* sums_extra = nullptr /* 128*rows bytes for the row sums, or null */, bool do_msm = true,
+                        bool do_reduce = true) {
   size_t total = rows * cols;
   Pt* partial = (Pt*)scratch;
   Pt10* partial2 = (Pt10*)(scratch + m.part_bytes);
@@ -1063,7 +1064,8 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
   Pt* sums = (Pt*)sums_extra;
   (void)prof;
   auto scope = [&](int fam, double bytes) { return ProfScope(c, fam, bytes, st); };  // HIP events on the stream the kernels run on
-  if (m.windowed) {
+  if (!do_msm) {
+  } else if (m.windowed) {
     ProfScope ps = scope(PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * m.P));
     size_t nthreads = rows * m.P;
     hipLaunchKernelGGL(k_msm_windows, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, dZ, z_stride, rows, cols, (const Niels*)g->table,
@@ -1088,6 +1090,7 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
                            (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
     }
   }
+  if (!do_reduce) return;
   if (m.two_pass) {
     {
       ProfScope ps = scope(PF_MSM_REDUCE_PASS, (double)(rows * m.P * sizeof(Pt)) + (double)(rows * m.nchunks * sizeof(Pt10)));
@@ -1234,6 +1237,71 @@ int32_t sp_commit_rows_dev_start(sp_ctx* c, const sp_gens* g, size_t g_off, size
               j->scratch + j->out_off + out_al);
   (void)hipEventRecord(j->done, c->stream);
   if (hipGetLastError() != hipSuccess) { (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  *out = j;
+  return SP_OK;
+}
+// The same commit with the rows still in HOST memory (the satisfying assignment SNARK::prove is handed: src/lib.rs:339-344): the rows
+// are copied into Z[z_off..] in four chunks and the MSM of a chunk is launched behind its copy, so the additions of chunk k run while
+// chunk k + 1 crosses PCIe (32 MB at 2^20: 0.65 ms of copy, 0.87 ms of MSM); one reduction + encode over all rows at the end.
+// Collected with sp_job_wait like the other forms. Shapes the chunking does not fit (few rows, rows not a multiple of 1024, the
+// lookup form) take copy-then-commit.
+int32_t sp_commit_rows_upload_start(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, sp_table* Z, size_t z_off, const uint64_t* src, size_t rows,
+                                    size_t cols, const uint64_t* blinds, sp_job** out) {
+  if (!c || !g || !Z || !src || !out || rows <= SP_HOST_ENCODE_ROWS || cols == 0 || g_off + cols > g->n || (blinds && h_idx >= g->n) ||
+      z_off + rows * cols > Z->cap)
+    return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr);
+  static const size_t nch = [] { const char* e = getenv("SPARTAN_UPLOAD_CHUNKS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)4; }();
+  static const bool chunked_on = getenv("SPARTAN_NO_UPLOAD_OVERLAP") == nullptr;  // A/B switch
+  if (!chunked_on || m.windowed || rows % (256 * nch) != 0) {
+    HIPCHK(hipMemcpyAsync(Z->d + z_off, src, 32 * rows * cols, hipMemcpyHostToDevice, c->stream));
+    return sp_commit_rows_dev_start(c, g, g_off, h_idx, Z, z_off, rows, cols, blinds, out);
+  }
+  const Fq* dbl = nullptr;
+  if (blinds) {
+    SPCHK(ensure_dstage(c, 32 * rows));
+    SPCHK(stage_in(c, 0, blinds, 32 * rows));
+    dbl = (const Fq*)c->dstage;
+  }
+  sp_job* j = new (std::nothrow) sp_job();
+  if (!j) return SP_ENOMEM;
+  j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream;
+  size_t out_al = (32 * rows + 255) & ~(size_t)255;
+  j->out_off = m.part_bytes + m.part2_bytes;
+  j->scratch_bytes = j->out_off + out_al + sizeof(Pt) * rows;
+  int32_t rc = pool_alloc(c, j->scratch_bytes, (void**)&j->scratch);
+  if (rc != SP_OK) { delete j; return rc; }
+  if (hipEventCreateWithFlags(&j->done, hipEventDisableTiming) != hipSuccess) { pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  const size_t rch = rows / nch;
+  // copies on the side stream, back to back; the additions of a chunk on the main stream, behind that chunk's copy
+  hipEvent_t ready = nullptr;
+  hipError_t e = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ready, c->stream);  // Z as left by what the main stream has queued (its zero fill)
+  if (e == hipSuccess) e = hipStreamWaitEvent(c->stream_side, ready, 0);
+  if (ready) (void)hipEventDestroy(ready);
+  for (size_t k = 0; k < nch && e == hipSuccess; k++) {
+    const size_t r0 = k * rch;
+    // (a copy from pageable memory returns when the data has left the host buffer)
+    e = hipMemcpyAsync(Z->d + z_off + r0 * cols, src + 4 * r0 * cols, 32 * rch * cols, hipMemcpyHostToDevice, c->stream_side);
+    hipEvent_t copied = nullptr;  // one event per chunk (an event re-recorded while a wait on it is pending is not something to rely on)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(copied, c->stream_side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, copied, 0);
+    if (copied) (void)hipEventDestroy(copied);
+    if (e == hipSuccess)
+      msm_enqueue(c, c->stream, true, m, g, Z->d + z_off + r0 * cols, cols, rch, cols, g_off, nullptr, dbl ? dbl + r0 : nullptr, h_idx,
+                  j->scratch + r0 * m.P * sizeof(Pt), nullptr, true, nullptr, true, false);
+  }
+  if (e == hipSuccess)
+    msm_enqueue(c, c->stream, true, m, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, dbl, h_idx, j->scratch, j->scratch + j->out_off, true,
+                j->scratch + j->out_off + out_al, false, true);
+  (void)hipEventRecord(j->done, c->stream);
+  if (e != hipSuccess || hipGetLastError() != hipSuccess) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j;
+    return SP_EHIP;
+  }
   *out = j;
   return SP_OK;
 }

@@ -907,8 +907,6 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   if (vars_resident) {  // a VarsAssignment: device-to-device
     REQUIRE(sp_table_len(vars_resident) == nvars_given);
     if (nvars_given) SPX(sp_table_copy(c, poly_vars.h, 0, vars_resident, 0, nvars_given));
-  } else if (nvars_given) {
-    SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
   }
   FqVec blinds_vars = tape.random_vector("poly_blinds", pow2(lv / 2));
   {
@@ -916,7 +914,12 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
     const MultiCommitGens& g = gens.gens_pc.gens.gens_n;
     sp_job* job = nullptr;
     bool async = Ls > 8 && !commit_shard_active(c) && g.n() == Rs;
-    if (async) SPX(sp_commit_rows_dev_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, Ls, Rs, U(blinds_vars), &job));
+    // a host assignment of full length: the upload and the commitment in one call (the additions of a chunk of rows run while the
+    // next chunk crosses PCIe); otherwise upload, then commit
+    const bool upload_commit = async && !vars_resident && nvars_given == num_vars;
+    if (!vars_resident && nvars_given && !upload_commit) SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
+    if (upload_commit) SPX(sp_commit_rows_upload_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, vars[0].l, Ls, Rs, U(blinds_vars), &job));
+    else if (async) SPX(sp_commit_rows_dev_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, Ls, Rs, U(blinds_vars), &job));
     try {
       if (transcript_prefix) (*transcript_prefix)();
       t.append_protocol_name("R1CS proof");
