@@ -222,6 +222,12 @@ def test_sparse_matrix_products_large(ctx):
         o4 = (ctypes.c_uint64 * 4)()
         assert capi.lib.sp_sparse_evaluate(ctx.h, h, trx.h, ty.h, o4) == 0
         assert from_mont_bulk(o4, 1)[0] == sum(rx[r_] * z[c_] * v_ for r_, c_, v_ in zip(rows, cols, vals)) % Q
+    # the three evaluations as one queued job on the low-priority stream (what SNARK::prove starts when ry is known): same values
+    job = vp()
+    assert capi.lib.sp_sparse_evaluate_begin(ctx.h, (vp * 3)(*hs), sz(3), trx.h, ty.h, ctypes.byref(job)) == 0
+    o12 = (ctypes.c_uint64 * 12)()
+    assert capi.lib.sp_job_wait(job, ctypes.cast(o12, ctypes.POINTER(ctypes.c_uint8))) == 0
+    assert from_mont_bulk(o12, 3) == [sum(rx[r_] * z[c_] * v_ for r_, c_, v_ in zip(rows, cols, vals)) % Q for rows, cols, vals in mats]
     for h in hs:
         capi.lib.sp_sparse_free(h)
     for t in (tz, trx, ty):
@@ -529,3 +535,32 @@ def test_grid_rounds_per_launch_match_reference_arithmetic(ctx, ell, nbind, kd):
         assert tables[0] == 2 ** 64 - 1 and tables[1] == 0
     for t in tA + tB + tCseq + [tCpar]:
         t.free()
+
+
+def test_commit_rows_upload_start_equals_commit_of_the_uploaded_table(ctx):
+    """sp_commit_rows_upload_start (the host assignment of SNARK::prove: row chunks committed behind their PCIe copies, one
+    reduction at the end) returns the commitments sp_commit_rows_dev returns for the same rows already in HBM, with and without
+    blinds, and leaves the rows in the destination table; 1024 x 256 takes the chunked path, 40 x 256 the copy-then-commit path."""
+    import hashlib
+    import numpy as np
+    from spartan_amd import capi
+    cols = 256
+    g = capi.Gens(ctx, uniform=hashlib.shake_256(b"upload_commit").digest(64 * (cols + 1)))
+    rng = np.random.default_rng(5)
+    for rows, with_blinds in ((1024, True), (1024, False), (40, True)):
+        Z = rng.integers(0, 2**64, size=(rows * cols, 4), dtype=np.uint64); Z[:, 3] &= np.uint64((1 << 60) - 1)
+        Z[7 * cols:8 * cols] = 0                                                    # an all-zero row
+        B = rng.integers(0, 2**64, size=(rows, 4), dtype=np.uint64); B[:, 3] &= np.uint64((1 << 60) - 1)
+        zp = Z.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)); bp = B.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)) if with_blinds else None
+        t_ref = capi.Table.upload(ctx, zp, rows * cols)
+        want = (ctypes.c_uint8 * (32 * rows))()
+        assert capi.lib.sp_commit_rows_dev(ctx.h, g.h, sz(0), sz(cols), t_ref.h, sz(0), sz(rows), sz(cols), bp, want) == 0
+        dst = capi.Table.alloc(ctx, rows * cols)
+        job = vp()
+        assert capi.lib.sp_commit_rows_upload_start(ctx.h, g.h, sz(0), sz(cols), dst.h, sz(0), zp, sz(rows), sz(cols), bp, ctypes.byref(job)) == 0
+        got = (ctypes.c_uint8 * (32 * rows))()
+        assert capi.lib.sp_job_wait(job, got) == 0
+        assert bytes(got) == bytes(want), (rows, with_blinds)
+        assert bytes(dst.download()) == Z.tobytes()
+        t_ref.free(); dst.free()
+    g.free()
