@@ -249,6 +249,10 @@ int32_t sp_ipa_begin_dev(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t n, 
                          const uint64_t blind_a[4], uint8_t commit_a[32], sp_ipa** out);
 int32_t sp_ipa_set_scale(sp_ipa* ipa, const uint64_t q_scale[4]);
 /* bullet.rs:72-100: c_L, c_R, L = <a_L,G_R> + c_L Q + blind_L H, R = <a_R,G_L> + c_R Q + blind_R H, compressed. */
+/* Puts the kernel of the next sp_ipa_round_lr in flight now: it depends on neither that round's blinds nor the scale of Q, so
+ * DotProductProofLog::prove (src/nizk/mod.rs:469-480) launches the first round before it absorbs Cx, Cy and `a` and draws r. No other
+ * call on the context until sp_ipa_round_lr. A no-op when the round does not take the one-launch path. */
+int32_t sp_ipa_round_prelaunch(sp_ipa* ipa);
 int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]);
 /* bullet.rs:105-109: fold a, b (and the generator coefficients s) with the round challenge. */
 int32_t sp_ipa_round_fold(sp_ipa* ipa, const uint64_t u[4], const uint64_t u_inv[4]);

@@ -99,6 +99,8 @@ impl DotProductProofLog {
                             cx.as_mut_ptr(), &mut ipa)
     });
     let ipa = gpu::Ipa(ipa); // sp_ipa_free on drop
+    // the first round's kernel needs neither r nor the blinds: in flight while this core absorbs Cx, Cy and `a` (no device call in between)
+    if gpu::small_msm_on_host() && n >= 2 { gpu::ok(unsafe { gpu::sp_ipa_round_prelaunch(ipa.0) }); }
     let Cx = CompressedGroup::from_slice(&cx);
     Cx.append_to_transcript(b"Cx", transcript);
     let Cy = y.commit_compressed(blind_y, &gens.gens_1);

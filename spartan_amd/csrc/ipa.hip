@@ -21,6 +21,11 @@ struct sp_ipa {
   // last round left behind, from which the next c_L, c_R follow once the fold challenge is recorded
   Fq c0[2], dots[8];
   bool have_c0, have_dots;
+  // sp_ipa_round_prelaunch: the round's kernel is already in flight (it depends on neither the blinds nor Q's scale)
+  bool pre = false;
+  DoneSig pre_sig;
+  unsigned pre_nd = 0;
+  Fq pre_cL, pre_cR;
 };
 // core.hip
 struct IpaRoundArgs {
@@ -199,6 +204,7 @@ extern "C" {
 
 void sp_ipa_free(sp_ipa* ipa) {
   if (!ipa) return;
+  if (ipa->pre) (void)sig_wait(ipa->ctx, ipa->pre_sig);  // a prelaunched round nobody collected still reads the buffers
   pool_release(ipa->ctx, ipa->base, ipa->bytes);  // one allocation backs a, b, a2, b2, s, s2, rows, idx
   delete ipa;
 }
@@ -281,7 +287,8 @@ int32_t sp_ipa_set_scale(sp_ipa* ipa, const uint64_t q_scale[4]) {
 }
 // One launch per round: the kernel looks up and sums the generator columns of both rows and prepares the next round, while
 // the calling thread forms c_L Q + blind_L H and c_R Q + blind_R H (two terms each) from its host-side window tables.
-static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
+// first half of a one-launch round: c_L, c_R from what the previous launch left behind, and the launch itself
+static int32_t ipa_round_start(sp_ipa* ipa, Fq* cL_out, Fq* cR_out, DoneSig* sig_out, unsigned* nd_out) {
   sp_ctx* c = ipa->ctx;
   Fq cL, cR;
   if (ipa->fold_pending && ipa->have_dots) {
@@ -301,11 +308,28 @@ static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uin
   A.fold = ipa->fold_pending ? 1 : 0;
   A.u = ipa->fu; A.u_inv = ipa->fu_inv;
   A.counters = ipa->counters;
-  DoneSig sig;
-  SPCHK(ipa_round_launch(c, ipa->g, &A, &sig));
+  SPCHK(ipa_round_launch(c, ipa->g, &A, sig_out));
   if (ipa->fold_pending) {  // the kernel leaves the folded vectors in the ping-pong buffers
     std::swap(ipa->a, ipa->a2); std::swap(ipa->b, ipa->b2); std::swap(ipa->s, ipa->s2);
     ipa->fold_pending = false;
+  }
+  *cL_out = cL; *cR_out = cR; *nd_out = A.nd;
+  return SP_OK;
+}
+static bool ipa_round_fusable(const sp_ipa* ipa) {
+  const sp_ctx* c = ipa->ctx;
+  return ipa_fused() && !c->device_encode && ipa->n_cur <= 16384 && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0));
+}
+static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
+  sp_ctx* c = ipa->ctx;
+  Fq cL, cR;
+  DoneSig sig;
+  unsigned nd = 0;
+  if (ipa->pre) {
+    cL = ipa->pre_cL; cR = ipa->pre_cR; sig = ipa->pre_sig; nd = ipa->pre_nd;
+    ipa->pre = false;
+  } else {
+    SPCHK(ipa_round_start(ipa, &cL, &cR, &sig, &nd));
   }
   // meanwhile, on this core: the two-term tails of both rows
   const uint32_t qh[2] = {(uint32_t)ipa->q_idx, (uint32_t)ipa->h_idx};
@@ -331,19 +355,30 @@ static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uin
     const Fq* dp = (const Fq*)(hres(c) + 1024);
     for (int k = 0; k < 8; k++) {
       Fq acc = dp[k];
-      for (unsigned b = 1; b < A.nd; b++) acc = fq_add(acc, dp[(size_t)b * 8 + k]);
+      for (unsigned b = 1; b < nd; b++) acc = fq_add(acc, dp[(size_t)b * 8 + k]);
       ipa->dots[k] = acc;
     }
     ipa->have_dots = true;
   }
   return SP_OK;
 }
+// The kernel of the next round depends on neither the round's blinds nor the scale of Q (those enter the two-term tails the calling
+// thread adds): it can be put in flight before the caller has them — DotProductProofLog::prove launches the first round, then absorbs
+// Cx, Cy and the 4096 scalars of `a` (0.15 ms of Keccak) and draws r. No other call on the context until sp_ipa_round_lr (the kernel
+// writes the result page). Does nothing when the round would not take the one-launch path.
+int32_t sp_ipa_round_prelaunch(sp_ipa* ipa) {
+  if (!ipa || ipa->n_cur < 2) return SP_EINVAL;
+  HIPCHK(hipSetDevice(ipa->ctx->dev));
+  if (ipa->pre || !ipa_round_fusable(ipa)) return SP_OK;
+  SPCHK(ipa_round_start(ipa, &ipa->pre_cL, &ipa->pre_cR, &ipa->pre_sig, &ipa->pre_nd));
+  ipa->pre = true;
+  return SP_OK;
+}
 int32_t sp_ipa_round_lr(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
   if (!ipa || !blind_L || !blind_R || !L_out || !R_out || ipa->n_cur < 2) return SP_EINVAL;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
-  if (ipa_fused() && !c->device_encode && ipa->n_cur <= 16384 && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0)))
-    return ipa_round_fused(ipa, blind_L, blind_R, L_out, R_out);
+  if (ipa->pre || ipa_round_fusable(ipa)) return ipa_round_fused(ipa, blind_L, blind_R, L_out, R_out);
   ipa->have_c0 = ipa->have_dots = false;
   {
     ProfScope ps(c, PF_IPA, 32.0 * 4 * (double)ipa->n0);

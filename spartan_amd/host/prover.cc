@@ -798,6 +798,9 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
   sp_ipa* ipa = nullptr;
   CP Cx;
   SPX(sp_ipa_begin_dev(c, gn.g, gn.G[0], n, g1.G[0], gn.h, x.h, U(a), U(blind_x), Cx.data(), &ipa));
+  // the first round's kernel needs neither r nor the blinds: in flight while this core absorbs Cx, Cy and `a` (no device call in between:
+  // Cy comes from the host-side engine)
+  if (small_msm_on_host() && n >= 2 && sp_ipa_round_prelaunch(ipa) != SP_OK) { sp_ipa_free(ipa); throw Error("sp_ipa_round_prelaunch failed"); }
   DotProductProofLog p;
   Fq blind_hat, r;
   CP Cy;

@@ -4,7 +4,7 @@ import ctypes, os
 from .capi import SpartanHipError, LIB_PATH, sz, vp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_PATH = os.path.join(_HERE, "lib", "libspartan_host.so")
+HOST_PATH = os.environ.get("SPARTAN_HOST_LIB") or os.path.join(_HERE, "lib", "libspartan_host.so")  # override: diagnostic builds (e.g. -DSPZ_HOSTPROF)
 if not os.path.exists(HOST_PATH):
     raise SpartanHipError(f"{HOST_PATH} not built: run __graft_entry__.build()")
 ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
