@@ -68,6 +68,7 @@ struct Triple {
   Fq *a, *b, *c;
   Fq* c_out;  // where this instance writes the bound C (non-null for exactly one instance per distinct C table)
 };
+struct TripleInline { Triple t[24]; };  // up to 24 instances in the kernel arguments (T == null) instead of the host-mapped page: see Bind2Inline
 __device__ __forceinline__ void cubic_point(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c0, const Fq& c1, Fq (&e)[3]) {
   // the line through (0, x0), (1, x1) at 2 and 3: x1 + d, x1 + 2d with d = x1 - x0 (three modular additions per table)
   Fq da = fq_sub(a1, a0), db = fq_sub(b1, b0), dc = fq_sub(c1, c0);
@@ -78,9 +79,9 @@ __device__ __forceinline__ void cubic_point(const Fq& a0, const Fq& a1, const Fq
   e[2] = fq_add(e[2], fq_mul(fq_mul(a3, b3), c3));
 }
 // grid (nblk, ninst): partials[(inst*nblk + blk)*3 + {0,1,2}]
-__global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __restrict__ T, size_t half, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __restrict__ T, TripleInline IN, size_t half, Fq* __restrict__ partials) {
   __shared__ Fq sm[256];
-  Triple t = T[blockIdx.y];
+  Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
     cubic_point(ld_fq(t.a + i), ld_fq(t.a + half + i), ld_fq(t.b + i), ld_fq(t.b + half + i), ld_fq(t.c + i), ld_fq(t.c + half + i), e);
@@ -90,9 +91,9 @@ __global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __rest
     st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]);
   }
 }
-__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* __restrict__ T, TripleInline IN, size_t quarter, Fq r, Fq* __restrict__ partials) {
   __shared__ Fq sm[256];
-  Triple t = T[blockIdx.y];
+  Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quarter; i += (size_t)gridDim.x * blockDim.x) {
     Fq lo[3], hi[3];
@@ -121,11 +122,11 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* _
 // Latency form of the fused round for short tables (quarter <= a few hundred): the ~12 dependent field
 // multiplications of one index are spread over 8 lanes (six do one bind each, then three do one evaluation point
 // each), so a round costs ~3 multiplications of latency instead of 12. Block = 32 indices x 8 roles; grid (nblk, ninst).
-__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, TripleInline IN, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
   __shared__ Fq bound[32][6];  // [index][table*2 + half]
   __shared__ Fq lv[32][3][3];  // [index][table][t = 0, 2, 3]: the bound pair's line
   __shared__ Fq red[3][32];
-  Triple t = T[blockIdx.y];
+  Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   int li = threadIdx.x >> 3, role = threadIdx.x & 7;
   size_t i = (size_t)blockIdx.x * 32 + li;
   bool live = i < quarter;
@@ -162,9 +163,9 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __re
 }
 // Latency form of k_cubic_eval_batched (the first round of a layer's sum-check, half <= 8192): four lanes per index, lanes
 // 0..2 evaluate t = 0, 2, 3 with one instruction stream; block = 64 indices; grid (nblk, ninst).
-__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, size_t half, Fq* __restrict__ partials, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, TripleInline IN, size_t half, Fq* __restrict__ partials, DoneSig sig) {
   __shared__ Fq red[3][64];
-  Triple t = T[blockIdx.y];
+  Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   int li = threadIdx.x >> 2, role = threadIdx.x & 3;
   size_t i = (size_t)blockIdx.x * 64 + li;
   Fq e = fq_zero();
@@ -217,7 +218,13 @@ __device__ __forceinline__ Fq line_at(const Fq& u, const Fq& v, int t) {  // the
 }
 // dump != nullptr (only when the outputs describe tables of at most 8 entries): the tables themselves go out as well,
 // dump[(instance * 3 + table) * 8 + z] — the caller finishes the last <= 3 rounds of the sum-check on its own core.
-__global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
+// Up to 24 instances travel in the kernel arguments (T == null): the table pointers and the weights are then scalar loads from the
+// kernarg segment instead of a read of the host-mapped page over PCIe at the head of every workgroup.
+struct Bind2Inline {
+  Triple2 t[24];
+  Fq w[24];
+};
+__global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, Bind2Inline IN, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
                                                           Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig) {
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
@@ -225,8 +232,8 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
   __shared__ Fq lv[8][3][6][3];   // [group][table][line V, W, P, U, P + U, P - U][t = 0, 2, 3]
   DoneSig kt = sig; if (blockIdx.x != 0 || blockIdx.y != 0) kt.kt = nullptr;
   SP_KT(kt, 0);
-  const Triple2 t = T[blockIdx.y];
-  const Fq wv = weights ? ld_fq(weights + blockIdx.y) : fq_zero();  // from the host-mapped page: requested now, needed last
+  const Triple2 t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
+  const Fq wv = !weights ? fq_zero() : (T ? ld_fq(weights + blockIdx.y) : IN.w[blockIdx.y]);  // from the host-mapped page (T != null): requested now, needed last
   const int grp = threadIdx.x >> 5, lane = threadIdx.x & 31;
   const size_t n2 = len >> nbind;                  // length of the tables the outputs describe (nbind = 0, 1 or 2 binds first)
   const size_t np = n2 < 4 ? n2 : 4, ng = n2 / np; // entries per group, groups
@@ -616,7 +623,8 @@ int32_t sp_product_tree_many(sp_ctx* c, sp_table* const* stores, size_t count, s
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
-static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t* len_out, bool bind_c) {
+static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t* len_out, bool bind_c, TripleInline* IN,
+                             const Triple** Tdev) {
   if (!c || !A || !B || !C || ninst == 0 || ninst > 64) return SP_EINVAL;
   size_t len = A[0] ? A[0]->len : 0;
   std::vector<Triple> T(ninst);
@@ -635,7 +643,14 @@ static int32_t batched_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, 
       }
     }
   }
-  stage_small(c, 0, T.data(), sizeof(Triple) * ninst);
+  static const bool inline_args = getenv("SPARTAN_NO_INLINE_ARGS") == nullptr;  // A/B switch
+  if (inline_args && ninst <= 24) {
+    memcpy(IN->t, T.data(), sizeof(Triple) * ninst);
+    *Tdev = nullptr;
+  } else {
+    stage_small(c, 0, T.data(), sizeof(Triple) * ninst);
+    *Tdev = (const Triple*)c->hmap;
+  }
   *len_out = len;
   return SP_OK;
 }
@@ -671,7 +686,9 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   if (!out) return SP_EINVAL;
   size_t len;
   HIPCHK(hipSetDevice(c ? c->dev : 0));
-  SPCHK(batched_setup(c, A, B, C, ninst, &len, false));
+  TripleInline IN;
+  const Triple* Tdev = nullptr;
+  SPCHK(batched_setup(c, A, B, C, ninst, &len, false, &IN, &Tdev));
   size_t half = len / 2;
   bool tiny = half <= 8192;
   size_t nblk = tiny ? (half + 63) / 64 : grid_for(half, 256);
@@ -681,8 +698,8 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* const*
   DoneSig sig = sig_make(c, on_host ? nblk * ninst : ninst);
   {
     ProfScope ps(c, PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, 6.0 * (double)half * (double)ninst);
-    if (tiny) hipLaunchKernelGGL(k_cubic_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials, on_host ? sig : sig_none());
-    else hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, half, partials);
+    if (tiny) hipLaunchKernelGGL(k_cubic_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, Tdev, IN, half, partials, on_host ? sig : sig_none());
+    else hipLaunchKernelGGL(k_cubic_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, Tdev, IN, half, partials);
   }
   return batched_finish(c, partials, nblk, ninst, out, sig);
 }
@@ -694,7 +711,9 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   if (!c) return SP_EINVAL;
   for (size_t k = 0; k < ninst && C; k++)
     if (C[k] && C[k]->len < 4) return SP_EINVAL;
-  SPCHK(batched_setup(c, A, B, C, ninst, &len, true));
+  TripleInline IN;
+  const Triple* Tdev = nullptr;
+  SPCHK(batched_setup(c, A, B, C, ninst, &len, true, &IN, &Tdev));
   if (len < 4) return SP_EINVAL;
   size_t quarter = len / 4;
   bool tiny = quarter <= 8192;  // one index per 8 lanes while the round is latency-bound (512 / 2048 / 8192 / 32768 measured: 45.3 / 45.0 / 44.8 / 45.6 ms per proof)
@@ -706,10 +725,10 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   {
     ProfScope ps(c, PF_SC_BIND_EVAL, (96.0 + 32.0) * (double)len * (double)ninst, nullptr, 12.0 * (double)quarter * (double)ninst);
     if (tiny)
-      hipLaunchKernelGGL(k_cubic_bind_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
+      hipLaunchKernelGGL(k_cubic_bind_eval_tiny, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, Tdev, IN, quarter,
                          limbs(r), partials, on_host ? sig : sig_none());
     else
-      hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple*)c->hmap, quarter,
+      hipLaunchKernelGGL(k_cubic_bind_eval_batched, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, Tdev, IN, quarter,
                          limbs(r), partials);
   }
   // A_k and B_k are now bound in place (distinct tables assumed for A and B); each distinct C was bound into its
@@ -765,8 +784,17 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
       }
     }
   }
-  stage_small(c, 0, T.data(), sizeof(Triple2) * ninst);
-  const Fq* dweights = weights ? (const Fq*)stage_small(c, sizeof(Triple2) * 64, weights, 32 * ninst) : nullptr;
+  static const bool inline_args = getenv("SPARTAN_NO_INLINE_ARGS") == nullptr;  // A/B switch
+  const bool inl = inline_args && ninst <= 24;
+  Bind2Inline IN;
+  const Fq* dweights = nullptr;
+  if (inl) {
+    memcpy(IN.t, T.data(), sizeof(Triple2) * ninst);
+    if (weights) { memcpy(IN.w, weights, 32 * ninst); dweights = (const Fq*)c->hmap; }  // non-null: "weighted"; the values come from IN.w
+  } else {
+    stage_small(c, 0, T.data(), sizeof(Triple2) * ninst);
+    dweights = weights ? (const Fq*)stage_small(c, sizeof(Triple2) * 64, weights, 32 * ninst) : nullptr;
+  }
   size_t np = n2 < 4 ? n2 : 4, ng = n2 / np, nblk = (ng + 7) / 8;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 18 * (nblk + 1) * ninst));
   bool host = 32 * 18 * nblk * ninst <= HOST_SUM_BYTES;
@@ -777,7 +805,7 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
   DoneSig sig = sig_make(c, host ? nblk * ninst : ninst);  // raised by the last kernel of the trip
   {
     ProfScope ps(c, do_bind ? PF_SC_BIND_EVAL : PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, (do_bind ? 36.0 + 36.0 : 36.0) * (double)ng * (double)ninst);
-    hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, (const Triple2*)c->hmap, dweights, len, nbind,
+    hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, inl ? (const Triple2*)nullptr : (const Triple2*)c->hmap, IN, dweights, len, nbind,
                        r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials, dump, host ? sig : sig_none());
   }
   std::vector<Fq> sums(18 * ninst);
