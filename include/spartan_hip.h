@@ -193,6 +193,9 @@ int32_t sp_vecmat(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z,
  * inner-product argument: it never has to visit the host). L is copied before the call returns; the multiplication is queued,
  * not waited for — the table is ready for every later call on ctx (stream order). */
 int32_t sp_vecmat_dev(sp_ctx* ctx, const uint64_t* L, size_t Lsz, const sp_table* Z, sp_table** out);
+/* The same with L a device table (e.g. EqPolynomial::evals of the left half from sp_eq_expand): nothing of L crosses PCIe and the host
+ * does not compute it. Queued, not waited for; L may be freed right after the call. */
+int32_t sp_vecmat_tab(sp_ctx* ctx, const sp_table* L, const sp_table* Z, sp_table** out);
 /* compute_dotproduct / inner_product (nizk/mod.rs:435-438, bullet.rs:233-243) over n elements. */
 int32_t sp_dot(sp_ctx* ctx, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]);
 /* DensePolynomial::evaluate (dense_mlpoly.rs:236-242): <Z, chi(r)> with chi generated on the device. */

@@ -161,8 +161,17 @@ impl PolyEvalProof {
     let (L_size, _R_size) = (left_num_vars.pow2(), right_num_vars.pow2());
     // the sqrt(N)-sized L and R vectors stay on the host (compute_factored_evals, :90-98); L first: the device multiplies
     // while R is computed
-    let L = EqPolynomial::new(r[..left_num_vars].to_vec()).evals();
-    let LZ = poly.bound_dev(&L);
+    // with blinds the host needs L too (LZ_blind); without, L is generated and consumed on the device (sp_eq_expand + sp_vecmat_tab)
+    let (LZ, L) = match blinds_opt {
+      Some(_) => { let L = EqPolynomial::new(r[..left_num_vars].to_vec()).evals(); (poly.bound_dev(&L), L) }
+      None if gpu::shard_ctxs().len() >= 2 => { let L = EqPolynomial::new(r[..left_num_vars].to_vec()).evals(); (poly.bound_dev(&L), L) }
+      None => {
+        let Lt = gpu::Table::eq(&r[..left_num_vars]);
+        let mut lz = std::ptr::null_mut();
+        gpu::ok(unsafe { gpu::sp_vecmat_tab(gpu::ctx(), Lt.0, poly.table().0, &mut lz) });
+        (gpu::Table(lz), Vec::new())
+      }
+    };
     let R = EqPolynomial::new(r[left_num_vars..].to_vec()).evals();
     let LZ_blind: Scalar = match blinds_opt {
       Some(b) => { assert_eq!(b.blinds.len(), L_size); (0..L.len()).map(|i| b.blinds[i] * L[i]).sum() }

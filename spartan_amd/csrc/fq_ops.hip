@@ -619,23 +619,32 @@ int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, u
   SPCHK(fetch_out(c, dres, out, 32 * R));
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
-int32_t sp_vecmat_dev(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, sp_table** out) {
-  if (!c || !L || !Z || !out || Lsz == 0 || Z->len % Lsz) return SP_EINVAL;
-  HIPCHK(hipSetDevice(c->dev));
+static int32_t vecmat_enqueue(sp_ctx* c, const Fq* dL, size_t Lsz, const sp_table* Z, sp_table** out) {
   size_t R = Z->len / Lsz;
-  const void* dL = nullptr;
-  SPCHK(vm_stage(c, L, 32 * Lsz, &dL));  // queued, not waited for: the caller goes on (the chi vector of the other half, the transcript)
   size_t jchunk = vecmat_jchunk(Lsz, R), nchunks = (Lsz + jchunk - 1) / jchunk;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * (nchunks * R + R)));
   SPCHK(table_new(c, R, false, out));
   Fq* partial = (Fq*)c->scratch;
   {
     ProfScope ps(c, PF_VECMAT, 32.0 * (double)Z->len + 32.0 * (double)R, nullptr, (double)Z->len);
-    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, (const Fq*)dL, Lsz,
-                       (const Fq*)Z->d, R, jchunk, partial);
+    hipLaunchKernelGGL(k_vecmat, dim3((unsigned)((R + 63) / 64), (unsigned)nchunks), dim3(256), 0, c->stream, dL, Lsz, (const Fq*)Z->d, R, jchunk, partial);
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, c->stream, (const Fq*)partial, nchunks, R, (*out)->d);
   }
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_vecmat_dev(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, sp_table** out) {
+  if (!c || !L || !Z || !out || Lsz == 0 || Z->len % Lsz) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  const void* dL = nullptr;
+  SPCHK(vm_stage(c, L, 32 * Lsz, &dL));  // queued, not waited for: the caller goes on (the chi vector of the other half, the transcript)
+  return vecmat_enqueue(c, (const Fq*)dL, Lsz, Z, out);
+}
+// The same with L already a device table (the chi vector of the left half generated by sp_eq_expand: PolyEvalProof::prove without
+// blinds never needs it on the host). Queued, not waited for; L may be freed right after the call (its reuse is ordered by the stream).
+int32_t sp_vecmat_tab(sp_ctx* c, const sp_table* L, const sp_table* Z, sp_table** out) {
+  if (!c || !L || !Z || !out || L->len == 0 || Z->len % L->len) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  return vecmat_enqueue(c, (const Fq*)L->d, L->len, Z, out);
 }
 int32_t sp_dot(sp_ctx* c, const sp_table* a, size_t a_off, const sp_table* b, size_t b_off, size_t n, uint64_t out[4]) {
   if (!c || !a || !b || !out || n == 0 || a_off + n > a->cap || b_off + n > b->cap) return SP_EINVAL;

@@ -853,10 +853,12 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
   t.append_protocol_name("polynomial evaluation proof");
   size_t Ls = pow2(r.size() / 2), Rs = pow2(r.size() - r.size() / 2);
   REQUIRE(poly.len() == Ls * Rs);
-  FqVec Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
-  sp_table* lz = nullptr;
   std::vector<sp_ctx*> shards = residue_shard_ctxs(c);
-  if (shards.size() >= 2 && Ls % shards.size() == 0 && !getenv("SPARTAN_NO_RESIDUE_SHARDS")) {
+  const bool shard_bound = shards.size() >= 2 && Ls % shards.size() == 0 && !getenv("SPARTAN_NO_RESIDUE_SHARDS");
+  FqVec Lv;  // the chi vector of the left half on the host: only the blinded opening and the sharded product need it here
+  if (blinds_opt || shard_bound) Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
+  sp_table* lz = nullptr;
+  if (shard_bound) {
     // DensePolynomial::bound sharded by row blocks (the same contiguous rows a sharded commitment gives each shard):
     // shard g multiplies rows [g Ls/W, (g+1) Ls/W) by its slice of L; the W partial vectors (R scalars each) are added in F_q
     const size_t W = shards.size(), per = Ls / W;
@@ -874,6 +876,10 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
     commit_shard_note_gather(c, 32 * Rs * W);
     lz = parts[0].h;
     parts[0].h = nullptr;
+  } else if (!blinds_opt) {
+    // no blinds: L is needed for this product only — generated and consumed on the device (the host copy above is not used)
+    DevTable Lt = tab_eq(c, FqVec(r.begin(), r.begin() + r.size() / 2));
+    SPX(sp_vecmat_tab(c, Lt.h, poly.h, &lz));
   } else {
     SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device; queued, not waited for
   }
