@@ -133,6 +133,13 @@ int32_t sp_host_commit_small(const sp_gens* g, const uint32_t* idx, size_t cols,
                              uint8_t* out /*32*rows*/);
 /* One row left as a point (not encoded): a partial commitment to be added to a later one through `addend`. */
 int32_t sp_host_commit_point(const sp_gens* g, const uint32_t* idx, size_t cols, const uint64_t* S, sp_host_point* out);
+/* Column-sharded commitments (DensePolynomial::commit_inner, src/dense_mlpoly.rs:164-177, when it has fewer rows than
+ * there are shards): sp_commit_rows_partial leaves sum_j Z[r*z_stride + j] * G[g_off + j], j < cols, of rows <= 8 as points (device);
+ * sp_host_points_sum_encode adds the nsets points of every row (pts[set*rows + r]: one set per shard, one for the blind terms from
+ * sp_host_commit_point) and encodes the sums (host). */
+int32_t sp_commit_rows_partial(sp_ctx* ctx, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t z_stride, size_t rows, size_t cols,
+                               sp_host_point* out /*rows*/);
+int32_t sp_host_points_sum_encode(const sp_host_point* pts, size_t nsets, size_t rows, uint8_t* out /*32*rows*/);
 /* The same arithmetic without a device or an sp_gens (CPU tests): npts encoded points, rows x npts scalars. */
 int32_t sp_host_commit_probe(const uint8_t* compressed /*32*npts*/, size_t npts, const uint64_t* S, size_t rows, uint8_t* out);
 /* Look-ahead for the zero-knowledge sum-checks. Inside their round loop nothing but DotProductProof::prove draws from the

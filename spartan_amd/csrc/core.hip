@@ -1113,8 +1113,9 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
 }
 // core: Z on device (row stride in elements), optional idx (device), optional blinds (device); synchronous
 int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride) {
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride, Pt* points_out) {
   if (idx_row_stride && (!didx || rows > SP_HOST_ENCODE_ROWS)) return SP_EINVAL;
+  if (points_out && (rows > SP_HOST_ENCODE_ROWS || c->device_encode)) return SP_EINVAL;  // row sums as points: the few-row path only
   MsmPlan m = msm_plan(g, rows, cols, dblinds != nullptr);
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
@@ -1135,7 +1136,8 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
         SPCHK(sig_wait(c, sig));
         if (hipGetLastError() != hipSuccess) return SP_EHIP;
         const Pt* sums = (const Pt*)hres(c);
-        for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
+        if (points_out) memcpy(points_out, sums, sizeof(Pt) * rows);
+        else for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
         return SP_OK;
       }
       {
@@ -1166,7 +1168,8 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
     Pt sums[SP_HOST_ENCODE_ROWS];
     SPCHK(fetch_small(c, sums, sizeof(Pt) * rows));
     if (hipGetLastError() != hipSuccess) return SP_EHIP;
-    for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
+    if (points_out) memcpy(points_out, sums, sizeof(Pt) * rows);
+    else for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
     return SP_OK;
   }
   bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;
@@ -1340,6 +1343,19 @@ int32_t sp_commit_rows_dev(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_i
     dbl = (const Fq*)c->dstage;
   }
   return msm_launch(c, g, Z->d + z_off, cols, rows, cols, g_off, nullptr, dbl, h_idx, out);
+}
+// A commitment restricted to a run of generators, left as points: sum_j Z[r * z_stride + j] * G[g_off + j], j < cols, for rows <= 8, no
+// blind. The building block of a COLUMN-sharded commitment (the north-star's partial sums): every shard sums its slice of
+// the generators, the W partial points of a row are gathered and added (sp_host_points_sum_encode) — the only way to shard a commitment
+// with fewer rows than shards (Cx of DotProductProofLog, a small instance's witness).
+int32_t sp_commit_rows_partial(sp_ctx* c, const sp_gens* g, size_t g_off, const sp_table* Z, size_t z_off, size_t z_stride, size_t rows, size_t cols,
+                               sp_host_point* out) {
+  if (!c || !g || !Z || !out || rows == 0 || rows > SP_HOST_ENCODE_ROWS || cols == 0 || z_stride < cols || g_off + cols > g->n ||
+      z_off + (rows - 1) * z_stride + cols > Z->cap)
+    return SP_EINVAL;
+  static_assert(sizeof(sp_host_point) == sizeof(Pt), "sp_host_point carries an extended point");
+  HIPCHK(hipSetDevice(c->dev));
+  return msm_launch(c, g, Z->d + z_off, z_stride, rows, cols, g_off, nullptr, nullptr, 0, nullptr, 0, (Pt*)out);
 }
 int32_t sp_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const uint64_t* Z, size_t rows, size_t cols,
                        const uint64_t* blinds, uint8_t* out) {

@@ -171,6 +171,22 @@ int32_t sp_host_commit_point(const sp_gens* g, const uint32_t* idx, size_t cols,
   memcpy(out, &acc, sizeof(Pt));
   return SP_OK;
 }
+// pts[set * rows + r]: adds the `nsets` points of every row and encodes the sums (RFC 9496) — the combine step of a column-sharded
+// commitment (sp_commit_rows_partial: one set per shard, one more for the blind terms), all on the calling thread.
+int32_t sp_host_points_sum_encode(const sp_host_point* pts, size_t nsets, size_t rows, uint8_t* out) {
+  if (!pts || !out || nsets == 0 || rows == 0) return SP_EINVAL;
+  for (size_t r = 0; r < rows; r++) {
+    Pt acc;
+    memcpy(&acc, &pts[r], sizeof(Pt));
+    for (size_t k = 1; k < nsets; k++) {
+      Pt p;
+      memcpy(&p, &pts[k * rows + r], sizeof(Pt));
+      acc = pt_add(acc, p);
+    }
+    pt_compress(acc, out + 32 * r);
+  }
+  return SP_OK;
+}
 // Device-free form for tests: npts compressed points, rows x npts scalars.
 int32_t sp_host_commit_probe(const uint8_t* compressed, size_t npts, const uint64_t* S, size_t rows, uint8_t* out) {
   if (!compressed || !S || !out || npts == 0 || npts > 16) return SP_EINVAL;

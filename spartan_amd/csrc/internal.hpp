@@ -251,7 +251,8 @@ int32_t sync_spin(sp_ctx* c);  // wait for everything queued on the context stre
 int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* out);
 // fixed-base MSM core: Z on device (row stride in elements), optional idx / blinds (device); out on host, synchronous
 extern "C" int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                              const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride = 0);
+                              const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride = 0,
+                              Pt* points_out = nullptr /* rows <= 8: the row sums as extended points instead of encodings */);
 // idx_row_stride: 0 = every row uses idx[0..cols); otherwise row r uses idx[r*idx_row_stride ..] (latency path only)
 
 static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {

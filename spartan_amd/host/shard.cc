@@ -259,6 +259,61 @@ void commit_shard_note_gather(sp_ctx* c, size_t bytes) {
   it->second.stats.bytes += bytes;
 }
 
+// all-gather of `per` bytes from every rank into all[world * per] (rank order) over the context's transport (callback or RCCL)
+static void gather_bytes(ShardState& s, uint8_t* all, size_t per) {
+  const size_t W = (size_t)s.world, lo = per * (size_t)s.rank;
+  if (s.mode == 1) {
+    if (s.gather(s.user, all, per * W, lo, per) != 0) throw Error("commit shard gather failed");
+    return;
+  }
+  size_t need = per + per * W;
+  hip_ok(hipSetDevice(s.dev), "hipSetDevice");
+  if (s.dbuf_bytes < need) {
+    if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
+    s.dbuf = nullptr;
+    hip_ok(hipMalloc((void**)&s.dbuf, need), "hipMalloc");
+    s.dbuf_bytes = need;
+  }
+  hip_ok(hipMemcpyAsync(s.dbuf, all + lo, per, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+  nccl_ok(rccl().AllGather(s.dbuf, s.dbuf + per, per, 1 /*ncclUint8*/, s.comm, s.stream), "ncclAllGather");
+  hip_ok(hipMemcpyAsync(all, s.dbuf + per, per * W, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+  hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+}
+
+// A commitment with fewer rows than shards (Ls <= 8: a small instance's witness, a single-row commit) sharded by COLUMNS — SURVEY 8e's
+// rendering of the north-star's "partial bucket sums": shard k sums the generators [k Rs/W, (k+1) Rs/W) of every row into one partial
+// point per row (sp_commit_rows_partial), the W x Ls points (128 bytes each) are gathered — RCCL has no elliptic-curve reduction, so
+// the "all-reduce" is an all-gather and a local addition — and every rank adds them, adds the blind terms and encodes
+// (sp_host_points_sum_encode): the same points as the unsharded sum, hence the same bytes. Off with SPARTAN_NO_SHARD_COLS=1.
+static bool sharded_commit_cols(ShardState& s, sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs,
+                                const uint64_t* blinds, uint8_t* out /*32*Ls*/) {
+  const size_t W = (size_t)s.world;
+  if (W <= 1 || Ls == 0 || Ls > 8 || Rs % W != 0 || getenv("SPARTAN_NO_SHARD_COLS")) return false;
+  const size_t per = Rs / W;
+  auto chk = [](int32_t rc, const char* what) { if (rc != SP_OK) throw Error(std::string(what) + " failed: " + sp_strerror(rc)); };
+  std::vector<sp_host_point> pts((W + 1) * Ls);  // [shard][row], then the blind terms
+  if (s.mode == 3) {
+    chk(sp_ctx_sync(c), "sp_ctx_sync");
+    for (size_t k = 0; k < W; k++) {
+      sp_ctx* ck = k == 0 ? c : s.vctx[k - 1];
+      chk(sp_commit_rows_partial(ck, g, g_off + k * per, Z, k * per, Rs, Ls, per, &pts[k * Ls]), "sp_commit_rows_partial");
+    }
+  } else {
+    const size_t k = (size_t)s.rank;
+    chk(sp_commit_rows_partial(c, g, g_off + k * per, Z, k * per, Rs, Ls, per, &pts[k * Ls]), "sp_commit_rows_partial");
+    gather_bytes(s, (uint8_t*)pts.data(), sizeof(sp_host_point) * Ls);
+  }
+  size_t nsets = W;
+  if (blinds) {
+    const uint32_t hh[1] = {(uint32_t)h_idx};
+    for (size_t r = 0; r < Ls; r++) chk(sp_host_commit_point(g, hh, 1, blinds + 4 * r, &pts[W * Ls + r]), "sp_host_commit_point");
+    nsets = W + 1;
+  }
+  chk(sp_host_points_sum_encode(pts.data(), nsets, Ls, out), "sp_host_points_sum_encode");
+  s.stats.gathers++; s.stats.bytes += sizeof(sp_host_point) * Ls * W;
+  return true;
+}
+
 // DensePolynomial::commit_inner over the shards of the context; returns false when the commitment is not sharded (no
 // sharding configured, or too few rows per shard) and the caller takes the single-GPU path.
 bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,
@@ -273,6 +328,7 @@ bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx
   ShardState& s = *sp;
   size_t W = (size_t)s.world;
   if (W <= 1 && s.mode != 2) return false;
+  if (Ls <= 8) return sharded_commit_cols(s, c, g, g_off, h_idx, Z, Ls, Rs, blinds, out);  // fewer rows than a shard is worth: by columns
   if (Ls % W != 0 || Ls / W <= 8) return false;  // rows are independent MSMs: shard only when every rank gets a real batch
   size_t per = Ls / W;
   auto chk = [](int32_t rc, const char* what) { if (rc != SP_OK) throw Error(std::string(what) + " failed: " + sp_strerror(rc)); };
@@ -300,23 +356,7 @@ bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx
   }
   size_t lo = per * (size_t)s.rank;
   chk(sp_commit_rows_dev(c, g, g_off, h_idx, Z, lo * Rs, per, Rs, blinds ? blinds + 4 * lo : nullptr, out + 32 * lo), "sp_commit_rows_dev");
-  if (s.mode == 1) {
-    if (s.gather(s.user, out, 32 * Ls, 32 * lo, 32 * per) != 0) throw Error("commit shard gather failed");
-  } else {
-    // RCCL: all-gather of the compressed commitments on device buffers (32*per bytes from each rank, rank order)
-    size_t need = 32 * per + 32 * Ls;
-    hip_ok(hipSetDevice(s.dev), "hipSetDevice");
-    if (s.dbuf_bytes < need) {
-      if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
-      s.dbuf = nullptr;
-      hip_ok(hipMalloc((void**)&s.dbuf, need), "hipMalloc");
-      s.dbuf_bytes = need;
-    }
-    hip_ok(hipMemcpyAsync(s.dbuf, out + 32 * lo, 32 * per, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
-    nccl_ok(rccl().AllGather(s.dbuf, s.dbuf + 32 * per, 32 * per, 1 /*ncclUint8*/, s.comm, s.stream), "ncclAllGather");
-    hip_ok(hipMemcpyAsync(out, s.dbuf + 32 * per, 32 * Ls, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
-    hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
-  }
+  gather_bytes(s, out, 32 * per);  // the compressed commitments, 32*per bytes from each rank, rank order
   s.stats.gathers++; s.stats.bytes += 32 * Ls;
   return true;
 }

@@ -1,7 +1,7 @@
 """Row-sharded commitments end to end: two lock-step ranks share the single GPU of the test box and
 exchange commitment bytes over gloo (RCCL refuses two ranks on one device; on an 8-GPU node the same code runs with the
 `nccl` backend). bench.py --shard-commits itself compares every sharded proof with the unsharded bytes."""
-import json, os, socket, subprocess, sys
+import ctypes, json, os, socket, subprocess, sys
 
 import pytest
 
@@ -154,3 +154,61 @@ def test_rccl_transport_inside_the_library_single_rank():
     assert ctx.shard_stats()["gathers"] >= 1
     ctx.set_commit_shard_virtual(1)
     enc.free(); gens.free(); inst.free(); ctx.close()
+
+
+def test_column_sharded_commitment_of_a_small_instance_is_byte_identical():
+    """SURVEY §8e, the north-star's "partial sums": a commitment with fewer rows than a shard is worth (2^6 constraints: the witness is
+    8 rows x 8 columns) is sharded by COLUMNS — every shard sums its slice of the generators into one partial point per row
+    (sp_commit_rows_partial), the points are gathered and added, the blind terms added and the sums encoded
+    (sp_host_points_sum_encode). Same points, same bytes; SPARTAN_NO_SHARD_COLS=1 is the single-GPU path for comparison."""
+    from spartan_amd import prover as P
+    s = 6
+    N = 1 << s
+    ctx = P.Ctx(0)
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    ngens = P.NIZKGens(ctx, N, N, 10)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", s)
+    ref = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    nref = P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, ngens, b"nizk_example", tape)
+    ctx.set_commit_shard_virtual(4)
+    ctx.shard_stats(reset=True)
+    assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
+    st = ctx.shard_stats()
+    assert st["gathers"] >= 1 and st["bytes"] >= 4 * 8 * 128          # the witness commitment: 4 shards x 8 rows x one 128-byte point
+    assert P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, ngens, b"nizk_example", tape) == nref
+    ctx.set_commit_shard_virtual(1)
+    enc.free(); gens.free(); ngens.free(); inst.free(); ctx.close()
+
+
+def test_commit_rows_partial_and_sum_encode_equal_the_whole_commitment():
+    """the two entry points of the column-sharded form against sp_commit_rows_dev: 5 rows x 96 columns in three slices of 32 columns,
+    blind terms through sp_host_commit_point"""
+    import hashlib
+    import numpy as np
+    from spartan_amd import capi
+    from tests.helpers import sz, vp
+    ctx = capi.Ctx(0)
+    rows, cols, W = 5, 96, 3
+    g = capi.Gens(ctx, uniform=hashlib.shake_256(b"cols_partial").digest(64 * (cols + 1)))
+    rng = np.random.default_rng(9)
+    Z = rng.integers(0, 2**64, size=(rows * cols, 4), dtype=np.uint64); Z[:, 3] &= np.uint64((1 << 60) - 1)
+    B = rng.integers(0, 2**64, size=(rows, 4), dtype=np.uint64); B[:, 3] &= np.uint64((1 << 60) - 1)
+    zp = Z.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)); bp = B.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    t = capi.Table.upload(ctx, zp, rows * cols)
+    want = (ctypes.c_uint8 * (32 * rows))()
+    assert capi.lib.sp_commit_rows_dev(ctx.h, g.h, sz(0), sz(cols), t.h, sz(0), sz(rows), sz(cols), bp, want) == 0
+    pts = (ctypes.c_uint64 * (16 * rows * (W + 1)))()
+    base = ctypes.addressof(pts)
+    per = cols // W
+    for k in range(W):
+        assert capi.lib.sp_commit_rows_partial(ctx.h, g.h, sz(k * per), t.h, sz(k * per), sz(cols), sz(rows), sz(per), ctypes.c_void_p(base + 128 * rows * k)) == 0
+    hidx = (ctypes.c_uint32 * 1)(cols)
+    for r in range(rows):
+        assert capi.lib.sp_host_commit_point(g.h, hidx, sz(1), ctypes.cast(ctypes.c_void_p(B.ctypes.data + 32 * r), ctypes.POINTER(ctypes.c_uint64)),
+                                             ctypes.c_void_p(base + 128 * (rows * W + r))) == 0
+    got = (ctypes.c_uint8 * (32 * rows))()
+    assert capi.lib.sp_host_points_sum_encode(ctypes.c_void_p(base), sz(W + 1), sz(rows), got) == 0
+    assert bytes(got) == bytes(want)
+    t.free(); g.free(); ctx.close()
