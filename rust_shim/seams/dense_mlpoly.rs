@@ -30,6 +30,25 @@ impl DensePolynomial {
     let d = &gens.dev;
     let t = self.table();
     let mut out = vec![0u8; 32 * L_size];
+    let shards = gpu::shard_ctxs();
+    let w = shards.len();
+    if w >= 2 && L_size <= 8 && R_size % w == 0 {
+      // fewer rows than a shard is worth -> sharded by COLUMNS (C++ rendering: sharded_commit_cols, spartan_amd/host/shard.cc).
+      // Shard k sums the generators [k R/W, (k+1) R/W) of every row into one partial point per row; the points are added here
+      // together with the blind terms and encoded.
+      let per = R_size / w;
+      let mut pts = vec![gpu::sp_host_point { w: [0u64; 16] }; (w + 1) * L_size];
+      gpu::ok(unsafe { gpu::sp_ctx_sync(gpu::ctx()) });
+      for k in 0..w {
+        gpu::ok(unsafe { gpu::sp_commit_rows_partial(shards[k], d.g, d.G[0] as usize + k * per, t.0, k * per, R_size, L_size, per, pts[k * L_size..].as_mut_ptr()) });
+      }
+      let hh = [d.h];
+      for r in 0..L_size {
+        gpu::ok(unsafe { gpu::sp_host_commit_point(d.g, hh.as_ptr(), 1, gpu::limbs1(&blinds[r]), &mut pts[w * L_size + r]) });
+      }
+      gpu::ok(unsafe { gpu::sp_host_points_sum_encode(pts.as_ptr(), w + 1, L_size, out.as_mut_ptr()) });
+      return PolyCommitment { C: out.chunks_exact(32).map(CompressedGroup::from_slice).collect() };
+    }
     gpu::ok(unsafe {
       gpu::sp_commit_rows_dev(gpu::ctx(), d.g, d.G[0] as usize, d.h as usize, t.0, 0, L_size, R_size, gpu::limbs(blinds), out.as_mut_ptr())
     });

@@ -102,7 +102,7 @@ def test_rust_seams_call_only_declared_symbols():
 
 
 def test_rust_seams_call_what_the_driver_calls():
-    """The measured path must be the drop-in's path: the set of C-ABI entry points the C++ host driver calls (prover.cc + spark.inc,
+    """The measured path must be the drop-in's path: the set of C-ABI entry points the C++ host driver calls (prover.cc + spark.inc + shard.cc,
     every switch included) equals the set the Rust seam bodies call (rust_shim/seams/*.rs + the hand-written tail of gpu.rs). An entry
     point the driver needs and no seam calls would mean the Rust crate cannot run the path that bench.py times."""
     import re, glob
@@ -117,7 +117,7 @@ def test_rust_seams_call_what_the_driver_calls():
             found |= {m for m in re.findall(r"\b(sp_\w+)\s*\(", src) if m in declared}
         return found
     host = os.path.join(ROOT, "spartan_amd", "host")
-    driver = calls([os.path.join(host, "prover.cc"), os.path.join(host, "spark.inc")])
+    driver = calls([os.path.join(host, "prover.cc"), os.path.join(host, "spark.inc"), os.path.join(host, "shard.cc")])
     seams = calls(glob.glob(os.path.join(ROOT, "rust_shim", "seams", "*.rs")) + [os.path.join(ROOT, "rust_shim", "src", "gpu_tail.rs.in")])
     assert len(driver) >= 55
     assert driver - seams == set(), f"called by the C++ driver, by no Rust seam: {sorted(driver - seams)}"
