@@ -16,7 +16,9 @@ inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=4)
 gens = P.SNARKGens(ctx, N, N, 10, N)
 enc = P.SNARK.encode(ctx, inst, gens)
 ctx.set_commit_shard(dist, "cpu")
+ctx.shard_stats(reset=True)
 proofs = [P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", None) for _ in range(2)]
+assert ctx.shard_stats()["gathers"] >= 2, "no commitment went through the transport"
 box = [None, None]
 dist.all_gather_object(box, proofs)
 if rank == 0:

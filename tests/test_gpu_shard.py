@@ -116,14 +116,17 @@ def test_residue_shards_can_be_switched_off_and_nizk_matches():
     gens.free(); inst.free(); ctx.close()
 
 
-def test_sharded_proving_with_an_os_entropy_tape():
+@pytest.mark.parametrize("s", [10, 6])
+def test_sharded_proving_with_an_os_entropy_tape(s):
     """tape_seed=None (the production setting) with lock-step ranks: rank 0 draws the RandomTape seed and the commit transport
-    hands it to the others — otherwise every rank would blind its row slice with its own tape (round-2 advisor finding)."""
+    hands it to the others — otherwise every rank would blind its row slice with its own tape (round-2 advisor finding).
+    s = 10: the witness commitment is sharded by rows (16 per rank); s = 6: by columns (8 rows: partial points gathered and added),
+    both over the callback transport of two real processes."""
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_seed_worker.py"), "10"], env=env, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_seed_worker.py"), str(s)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
