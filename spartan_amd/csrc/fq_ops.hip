@@ -41,12 +41,22 @@ constexpr size_t EQ_SMALL_ELL = 13;
 // are grouped: the low 8 index bits split 4 + 4 into two 16-entry tables built by 32 threads (3 multiplications deep),
 // the block's high bits (<= 5) are multiplied out by one more thread, then hi*ta (16 threads) and one multiplication per
 // entry: at most 6 deep. The product of the same factors in another order is the same field element.
-__global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ out) {
+// The three product chains (the two 16-entry tables and the block's high bits) run in three different wavefronts: as branches of ONE
+// wavefront they were executed one after the other (10 dependent multiplications instead of 4: 14 -> ~8 us per table, 70+ tables per
+// proof). The challenge vector travels in the kernel arguments (r_host == null) instead of being read from the host-mapped page.
+struct EqR { Fq r[13]; };
+__global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, EqR rin, size_t ell, Fq* __restrict__ out) {
   __shared__ Fq r[16];
   __shared__ Fq ta[16], tb[16];
   __shared__ Fq hi;
-  const int t = threadIdx.x;
-  if (t < (int)ell) r[t] = ld_fq(r_host + t);
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  if (r_host) {
+    if (t < (int)ell) r[t] = ld_fq(r_host + t);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 13; k++)
+      if (t == k) r[k] = rin.r[k];
+  }
   __syncthreads();
   const int nlo = ell < 8 ? (int)ell : 8, nb = nlo / 2, na = nlo - nb, nhi = (int)ell - nlo;
   auto factor = [&](int k, bool bit) {  // chi factor of variable k: r[k] or 1 - r[k]
@@ -55,18 +65,17 @@ __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ 
     for (int w = 0; w < 4; w++) f.l[w] = bit ? rk.l[w] : f.l[w];
     return f;
   };
-  if (t < 16) {
+  if (wave == 0 && lane < 16) {
     Fq acc = fq_one();
-    if (t < (1 << na))
-      for (int k = 0; k < na; k++) { Fq f = factor(nhi + k, (t >> (na - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
-    ta[t] = acc;
-  } else if (t < 32) {
-    int u = t - 16;
+    if (lane < (1 << na))
+      for (int k = 0; k < na; k++) { Fq f = factor(nhi + k, (lane >> (na - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
+    ta[lane] = acc;
+  } else if (wave == 1 && lane < 16) {
     Fq acc = fq_one();
-    if (u < (1 << nb))
-      for (int k = 0; k < nb; k++) { Fq f = factor(nhi + na + k, (u >> (nb - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
-    tb[u] = acc;
-  } else if (t == 32) {
+    if (lane < (1 << nb))
+      for (int k = 0; k < nb; k++) { Fq f = factor(nhi + na + k, (lane >> (nb - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
+    tb[lane] = acc;
+  } else if (wave == 2 && lane == 0) {
     Fq acc = fq_one();
     for (int k = 0; k < nhi; k++) { Fq f = factor(k, (blockIdx.x >> (nhi - 1 - k)) & 1); acc = k ? fq_mul(acc, f) : f; }
     hi = acc;
@@ -340,9 +349,14 @@ int32_t reduce_and_fetch(sp_ctx* c, Fq* partials, size_t nblk, int K, uint64_t* 
 extern "C" {
 
 // (a one-chain-per-entry kernel, ell multiplications deep, measured the same per proof as this 4+4 product form: removed)
-static void launch_eq_small(sp_ctx* c, const Fq* dr, size_t ell, Fq* out) {
+// r_host: the same ell scalars on the host (ell <= 13: they go into the kernel arguments); dr: their copy in the host-mapped page (the fallback)
+static void launch_eq_small(sp_ctx* c, const Fq* dr, const uint64_t* r_host, size_t ell, Fq* out) {
   size_t len = (size_t)1 << ell;
-  hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, dr, ell, out);
+  static const bool inline_args = getenv("SPARTAN_NO_INLINE_ARGS") == nullptr;  // A/B switch
+  EqR in;
+  const bool inl = inline_args && r_host && ell <= 13;
+  if (inl) memcpy(in.r, r_host, 32 * ell);
+  hipLaunchKernelGGL(k_eq_expand_small, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, inl ? (const Fq*)nullptr : dr, in, ell, out);
 }
 int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
   if (!c || !r || !out || ell == 0 || ell > 40) return SP_EINVAL;
@@ -361,14 +375,14 @@ int32_t sp_eq_expand(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
     ProfScope ps(c, PF_EQ_EXPAND, 32.0 * (double)len);
     dim3 blk(256);
     if (ell <= EQ_SMALL_ELL) {
-      launch_eq_small(c, dr, ell, (*out)->d);
+      launch_eq_small(c, dr, r, ell, (*out)->d);
     } else {
       size_t hi_ell = ell - ell / 2, lo_ell = ell / 2, nhi = (size_t)1 << hi_ell, nlo = (size_t)1 << lo_ell;
       Fq* tmp = nullptr;  // [chi(r_hi) | chi(r_lo)]; handed back to the pool right away: reuse is ordered by the stream
       int32_t rc = pool_alloc(c, 32 * (nhi + nlo), (void**)&tmp);
       if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; return rc; }
-      launch_eq_small(c, dr, hi_ell, tmp);
-      launch_eq_small(c, dr + hi_ell, lo_ell, tmp + nhi);
+      launch_eq_small(c, dr, r, hi_ell, tmp);
+      launch_eq_small(c, dr + hi_ell, r + 4 * hi_ell, lo_ell, tmp + nhi);
       hipLaunchKernelGGL(k_eq_outer, dim3((unsigned)grid_for(len, 4096)), blk, 0, c->stream, (const Fq*)tmp, (const Fq*)(tmp + nhi), (int)lo_ell, len,
                          (*out)->d);
       pool_release(c, tmp, 32 * (nhi + nlo));
