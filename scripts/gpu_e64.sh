@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing experiment: 64-byte table entries in the row MSM (libspartan_hip_e64.so computes wrong points; only the times mean anything)
+# timing experiment: 64-byte table entries in the row MSM (make -C spartan_amd/csrc e64 builds libspartan_hip_e64.so, which computes wrong points; only the times mean anything)
 R=$(pwd); O=$R/gpurun_out/$1; mkdir -p $O
 for rep in 1 2; do
 for b in 14 15; do
