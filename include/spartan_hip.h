@@ -111,7 +111,8 @@ int32_t sp_commit_rows_dev_start(sp_ctx* ctx, const sp_gens* g, size_t g_off, si
                                  size_t cols, const uint64_t* blinds, sp_job** out);
 /* The same commitment when the rows are still in host memory (the assignment SNARK::prove is handed, src/lib.rs:339-344): the rows
  * are copied into Z[z_off, z_off + rows*cols) in chunks and each chunk's additions are launched behind its copy, so the MSM overlaps
- * the PCIe transfer; one reduction and encode at the end. Collected with sp_job_wait; src must stay valid until the call returns. */
+ * the PCIe transfer; one reduction and encode at the end. Collected with sp_job_wait; src must stay valid and unmodified until
+ * sp_job_wait has returned (the runtime may still be reading it when this call returns). */
 int32_t sp_commit_rows_upload_start(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, sp_table* Z, size_t z_off, const uint64_t* src, size_t rows,
                                     size_t cols, const uint64_t* blinds, sp_job** out);
 int32_t sp_job_wait(sp_job* job, uint8_t* out /*32*rows*/);
