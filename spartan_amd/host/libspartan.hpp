@@ -62,6 +62,8 @@ ShardStats commit_shard_stats(Ctx& c, bool reset);
 bool commit_shard_active(sp_ctx* c);
 std::vector<sp_ctx*> residue_shard_ctxs(sp_ctx* c);  // virtual shards: [c, sub-contexts...]; empty when none
 void commit_shard_note_gather(sp_ctx* c, size_t bytes);
+bool commit_shard_transport(sp_ctx* c, int* rank, int* world);  // callback / RCCL transport configured: this rank's place among the lock-step ranks
+void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per);   // all-gather of `per` bytes per rank over that transport (rank order)
 double rccl_allgather_probe(sp_ctx* c, size_t bytes, int iters);  // us per H2D + ncclAllGather + D2H + sync of `bytes` per rank
 bool commit_shard_shared_seed(sp_ctx* c, Fq* seed);  // multi-rank transports only: rank 0's OS-entropy draw, handed to every rank
 void commit_shard_forget(sp_ctx* c);

@@ -515,39 +515,60 @@ struct ZkAhead {
 // rounds run unsharded. Same field values as the unsharded rounds — sums of the same terms — hence the same proof bytes.
 struct ResidueShards {
   sp_ctx* owner = nullptr;
-  std::vector<sp_ctx*> ctxs;
-  std::vector<std::vector<DevTable>> sub;  // [shard][table]
+  std::vector<sp_ctx*> ctxs;               // virtual shards: every residue class lives on a context of this process
+  std::vector<std::vector<DevTable>> sub;  // [shard][table]; with a multi-process transport: [0] = this rank's residue class
   std::vector<std::vector<sp_table*>> h;
-  bool active = false;
-  size_t ntab = 0;
+  bool active = false, remote = false;     // remote: one residue class per lock-step rank, partial sums over the commit transport
+  size_t ntab = 0, W = 0, me = 0;
   void split(sp_ctx* c, const std::vector<sp_table*>& tabs) {
+    size_t len = tabs.empty() ? 0 : sp_table_len(tabs[0]);
+    if (getenv("SPARTAN_NO_RESIDUE_SHARDS")) return;
     ctxs = residue_shard_ctxs(c);
-    size_t W = ctxs.size(), len = tabs.empty() ? 0 : sp_table_len(tabs[0]);
-    if (W < 2 || (W & (W - 1)) || len < 4 * W || getenv("SPARTAN_NO_RESIDUE_SHARDS")) return;
+    int rank = 0, world = 0;
+    if (ctxs.size() >= 2) {
+      W = ctxs.size();
+    } else if (getenv("SPARTAN_RESIDUE_TRANSPORT") && commit_shard_transport(c, &rank, &world)) {
+      // SURVEY 8e over real ranks: every rank has the full tables (it computed them like every other rank) and keeps only its residue
+      // class from here on; a round's partial sums travel over the transport the sharded commitments use (96 bytes per rank). Opt-in:
+      // at 2^20 the exchange (26 us over RCCL) costs more than the round it shortens
+      W = (size_t)world; me = (size_t)rank; remote = true;
+      ctxs.assign(1, c);
+    } else {
+      return;
+    }
+    if (W < 2 || (W & (W - 1)) || len < 4 * W) { remote = false; return; }
     owner = c; ntab = tabs.size();
     SPX(sp_ctx_sync(c));  // the tables as produced by everything queued on the owning context
-    sub.resize(W); h.resize(W);
-    for (size_t g = 0; g < W; g++)
+    const size_t nloc = remote ? 1 : W;
+    sub.resize(nloc); h.resize(nloc);
+    for (size_t g = 0; g < nloc; g++)
       for (sp_table* t : tabs) {
         sp_table* o = nullptr;
-        SPX(sp_table_residue_split(ctxs[g], t, W, g, &o));
+        SPX(sp_table_residue_split(ctxs[g], t, W, remote ? me : g, &o));
         sub[g].emplace_back(ctxs[g], o);
         h[g].push_back(o);
       }
     active = true;
   }
   size_t sub_len() const { return sp_table_len(h[0][0]); }
-  void add_partials(uint64_t* ev, const std::vector<std::array<uint64_t, 12>>& parts, int n) {
+  // parts: the partial sums of the residue classes held here; the others come over the transport. ev = their sum (F_q: exact, any order).
+  void add_partials(uint64_t* ev, std::vector<std::array<uint64_t, 12>>& parts, int n) {
+    if (remote) {
+      std::vector<std::array<uint64_t, 12>> all(W);
+      all[me] = parts[0];
+      commit_shard_gather(owner, (uint8_t*)all.data(), sizeof(all[0]));
+      parts.swap(all);
+    }
     for (int k = 0; k < n; k++) {
       Fq acc = fq_zero();
       for (auto& p : parts) { Fq x; memcpy(x.l, &p[4 * k], 32); acc += x; }
       memcpy(ev + 4 * k, acc.l, 32);
     }
-    commit_shard_note_gather(owner, 32 * (size_t)n * parts.size());
+    if (!remote) commit_shard_note_gather(owner, 32 * (size_t)n * parts.size());
   }
   void eval(int kind, uint64_t* ev) {
     std::vector<std::array<uint64_t, 12>> parts(ctxs.size());
-    for (size_t g = 0; g < ctxs.size(); g++) SPX(sp_sumcheck_eval(ctxs[g], kind, h[g].data(), ntab, parts[g].data()));
+    for (size_t g = 0; g < ctxs.size(); g++) { parts[g].fill(0); SPX(sp_sumcheck_eval(ctxs[g], kind, h[g].data(), ntab, parts[g].data())); }
     add_partials(ev, parts, kind == 0 ? 2 : 3);
   }
   void bind_eval_start(int kind, const Fq& r) {  // every shard's bind + next evaluation in flight together (own streams)
@@ -555,21 +576,28 @@ struct ResidueShards {
   }
   void bind_eval_collect(int kind, uint64_t* ev) {
     std::vector<std::array<uint64_t, 12>> parts(ctxs.size());
-    for (size_t g = 0; g < ctxs.size(); g++) SPX(sp_sumcheck_bind_eval_collect(ctxs[g], parts[g].data()));
+    for (size_t g = 0; g < ctxs.size(); g++) { parts[g].fill(0); SPX(sp_sumcheck_bind_eval_collect(ctxs[g], parts[g].data())); }
     add_partials(ev, parts, kind == 0 ? 2 : 3);
   }
   // sub-tables of two entries: bind them to one and hand the W survivors of every table back to the owner's tables
   void bind_last_and_gather(const Fq& r, std::vector<sp_table*>& tabs) {
-    size_t W = ctxs.size();
     std::vector<FqVec> heads(W, FqVec(ntab));
-    for (size_t g = 0; g < W; g++) SPX(sp_table_bind_top_heads(ctxs[g], h[g].data(), ntab, U(r), U(heads[g])));
+    if (remote) {
+      SPX(sp_table_bind_top_heads(owner, h[0].data(), ntab, U(r), U(heads[me])));
+      FqVec all(W * ntab);
+      memcpy(&all[me * ntab], heads[me].data(), 32 * ntab);
+      commit_shard_gather(owner, (uint8_t*)all.data(), 32 * ntab);
+      for (size_t g = 0; g < W; g++) memcpy(heads[g].data(), &all[g * ntab], 32 * ntab);
+    } else {
+      for (size_t g = 0; g < W; g++) SPX(sp_table_bind_top_heads(ctxs[g], h[g].data(), ntab, U(r), U(heads[g])));
+    }
     for (size_t t = 0; t < ntab; t++) {
       FqVec v(W);
       for (size_t g = 0; g < W; g++) v[g] = heads[g][t];
       SPX(sp_table_write(owner, tabs[t], 0, U(v), W));
       SPX(sp_table_set_len(tabs[t], W));
     }
-    commit_shard_note_gather(owner, 32 * ntab * W);
+    if (!remote) commit_shard_note_gather(owner, 32 * ntab * W);
     sub.clear(); h.clear();
     active = false;
   }

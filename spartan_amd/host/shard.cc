@@ -280,6 +280,27 @@ static void gather_bytes(ShardState& s, uint8_t* all, size_t per) {
   hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
 }
 
+// The multi-process transports (callback, RCCL) as seen by the residue-sharded sum-checks of prover.cc: this rank's place among the
+// lock-step ranks, and an all-gather of `per` bytes per rank (all[world * per], rank order; this rank's slice is filled in by the caller).
+bool commit_shard_transport(sp_ctx* c, int* rank, int* world) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c);
+  if (it == g_state.end() || (it->second.mode != 1 && it->second.mode != 2) || it->second.world <= 1) return false;
+  *rank = it->second.rank; *world = it->second.world;
+  return true;
+}
+void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per) {
+  ShardState* sp = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_state.find(c);
+    if (it == g_state.end() || (it->second.mode != 1 && it->second.mode != 2)) throw Error("commit_shard_gather: no multi-process transport");
+    sp = &it->second;
+  }
+  gather_bytes(*sp, all, per);
+  sp->stats.gathers++; sp->stats.bytes += per * (size_t)sp->world;
+}
+
 // A commitment with fewer rows than shards (Ls <= 8: a small instance's witness, a single-row commit) sharded by COLUMNS — SURVEY 8e's
 // rendering of the north-star's "partial bucket sums": shard k sums the generators [k Rs/W, (k+1) Rs/W) of every row into one partial
 // point per row (sp_commit_rows_partial), the W x Ls points (128 bytes each) are gathered — RCCL has no elliptic-curve reduction, so

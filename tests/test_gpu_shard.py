@@ -215,3 +215,21 @@ def test_commit_rows_partial_and_sum_encode_equal_the_whole_commitment():
     assert capi.lib.sp_host_points_sum_encode(ctypes.c_void_p(base), sz(W + 1), sz(rows), got) == 0
     assert bytes(got) == bytes(want)
     t.free(); g.free(); ctx.close()
+
+
+def test_residue_sharded_sumchecks_over_the_process_transport():
+    """SURVEY §8e K3/K4 over REAL ranks (not only virtual shards): two processes, each keeping one residue class of the ZK sum-check
+    tables, the rounds' partial sums (96 bytes per rank) and the final hand-back over the callback transport. Opt-in
+    (SPARTAN_RESIDUE_TRANSPORT=1: at 2^20 the exchange costs more than the round); the proofs equal the unsharded ones."""
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARTAN_RESIDUE_TRANSPORT="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "residue_transport_worker.py"), "12"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    assert "RESIDUE_TRANSPORT_OK" in outs[0]
