@@ -12,10 +12,14 @@
 //     (code bytes * 115 / 128 >= input bytes); each block is dynamic-Huffman (static below 48 input bytes), or stored when the
 //     coded form is not smaller; code lengths by the in-place minimum-redundancy algorithm over the frequency-sorted symbols
 //     (stable: ties by symbol index), limited to 15 / 7 bits by the Kraft fix-up, code-length alphabet run-length packed as tdefl does.
-// What can be pinned here is pinned (tests/test_host_transcript.py): the stream inflates (Python zlib) to exactly the bincode of the
-// shape the oracle serialises, for every block type. Equality with miniz_oxide's bytes needs the one Rust run this environment
-// cannot do (scripts/compare_with_libspartan.sh prints both digests); the header bytes are the one documented variable:
-// miniz_oxide >= 0.4 derives them from the level (0x78 0x9C), miniz and miniz_oxide 0.3 write 0x78 0x01 (old_header).
+// PINNED AGAINST THE REAL C MINIZ (tests/test_host_transcript.py::test_deflater_equals_real_miniz): libtorch_cpu.so in this image bundles
+// miniz 3.0.2 and exports mz_compress2; at every lazy-parsing level (4..10, i.e. 16/32/128/256/512/768/1500 probes — level 6 is what
+// flate2's Compression::default() selects) the WHOLE zlib stream of this file, header and Adler-32 included, equals miniz's on the bincode
+// of synthetic R1CS shapes 2^4..2^16 (multi-block, dynamic Huffman), random data (stored blocks), text, and block-boundary inputs. The
+// stream also inflates (Python zlib) to exactly the bincode the oracle serialises. What stays unpinned is only that miniz_oxide (a
+// line-by-line Rust port of tdefl) equals miniz; scripts/compare_with_libspartan.sh prints both digests. The header bytes are the one
+// documented variable: miniz >= 2.2 and miniz_oxide >= 0.4 derive FLEVEL from the probe count (level 6: 0x78 0x9C), older ones write
+// 0x78 0x01 (the `old_header` argument — an explicit API parameter, spz_instance_set_digest_header, never an environment switch).
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -47,6 +51,7 @@ struct Tdefl {
   unsigned max_probes[2];
   uint32_t adler = 1;
   bool old_header = false;
+  unsigned probes = 128;  // tdefl flags & 0xFFF: s_tdefl_num_probes[level] = {0, 1, 6, 32, 16, 32, 128, 256, 512, 768, 1500}; 128 = level 6
 
   void put(unsigned b, unsigned l) {
     bitbuf |= (uint64_t)b << bits_in;
@@ -238,7 +243,16 @@ struct Tdefl {
   }
   void flush_block(bool finish) {
     // (the flag byte that was opened but holds no code is given back: code_bytes -= (flags_left == 8) — nothing reads it afterwards)
-    if (block_index == 0) { put(0x78, 8); put(old_header ? 0x01 : 0x9C, 8); }
+    if (block_index == 0) {
+      // miniz >= 2.2 / miniz_oxide >= 0.4: FLEVEL recovered from the probe count (index in s_tdefl_num_probes), FCHECK makes the 16 bits a multiple of 31
+      static const unsigned num_probes[11] = {0, 1, 6, 32, 16, 32, 128, 256, 512, 768, 1500};
+      unsigned i = 0, flevel = 3;
+      for (; i < 11; i++) if (num_probes[i] == probes) break;
+      if (i < 2) flevel = 0; else if (i < 6) flevel = 1; else if (i == 6) flevel = 2;
+      unsigned header = (0x78u << 8) | (flevel << 6);
+      header += 31 - (header % 31);
+      put(0x78, 8); put(old_header ? 0x01 : (header & 0xFF), 8);
+    }
     put(finish ? 1 : 0, 1);
     const size_t saved_out = out.size();
     const uint64_t saved_buf = bitbuf;
@@ -297,7 +311,7 @@ struct Tdefl {
   void run(const uint8_t* src, size_t n) {
     memset(dict, 0, sizeof dict); memset(next, 0, sizeof next); memset(hash, 0, sizeof hash); memset(count, 0, sizeof count);
     memset(codes, 0, sizeof codes); memset(sizes, 0, sizeof sizes);
-    const unsigned flags = 128;  // probes; lazy parsing
+    const unsigned flags = probes;  // lazy parsing (levels >= 4; the greedy parser of levels 1..3 is not restated)
     max_probes[0] = 1 + ((flags & 0xFFF) + 2) / 3;
     max_probes[1] = 1 + (((flags & 0xFFF) >> 2) + 2) / 3;
     // Adler-32 of the whole input (tdefl updates it per call; the value at the end is the same)
@@ -361,11 +375,13 @@ struct Tdefl {
 };
 }  // namespace
 
-std::vector<uint8_t> zlib_level6_miniz(const uint8_t* data, size_t n, bool old_header) {
+std::vector<uint8_t> zlib_miniz_probes(const uint8_t* data, size_t n, unsigned probes, bool old_header) {
   std::unique_ptr<Tdefl> d(new Tdefl());
   d->old_header = old_header;
+  d->probes = probes & 0xFFF;
   d->run(data, n);
   return std::move(d->out);
 }
+std::vector<uint8_t> zlib_level6_miniz(const uint8_t* data, size_t n, bool old_header) { return zlib_miniz_probes(data, n, 128, old_header); }
 
 }  // namespace spz

@@ -143,7 +143,10 @@ int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint
   }
 }
 void spz_seed_scalar(const char* domain, uint64_t seed, uint64_t out[4]) { Fq s = seed_scalar(domain, seed); memcpy(out, s.l, 32); }
-void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->digest.assign(d, d + n); }
+void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->set_digest(d, n); }
+// zlib header variant of the COMPUTED digest: 0 = 0x78 0x9C (miniz >= 2.2, miniz_oxide >= 0.4: FLEVEL from the level), 1 = 0x78 0x01 (older).
+// An explicit parameter of the instance (not an environment switch); call before the digest is first used.
+void spz_instance_set_digest_header(void* inst, int old_header) { ((Instance*)inst)->digest_old_header = old_header != 0; }
 // R1CSShape::get_digest (r1cs.rs:154-158): the zlib stream; and the bincode it compresses (for the round-trip tests)
 size_t spz_instance_digest(void* inst, uint8_t* out, size_t cap) {
   const std::vector<uint8_t>& d = ((Instance*)inst)->compute_digest();
@@ -158,6 +161,12 @@ size_t spz_instance_shape_bincode(void* inst, uint8_t* out, size_t cap) {
 // the deflater alone (CPU tests): zlib_level6_miniz of arbitrary bytes
 size_t spz_zlib_level6(const uint8_t* data, size_t n, int old_header, uint8_t* out, size_t cap) {
   std::vector<uint8_t> z = zlib_level6_miniz(data, n, old_header != 0);
+  if (out && cap >= z.size()) memcpy(out, z.data(), z.size());
+  return z.size();
+}
+// the same deflater at another tdefl probe count (miniz levels 4..10 = 16/32/128/256/512/768/1500): pinned per level against the real miniz
+size_t spz_zlib_probes(const uint8_t* data, size_t n, unsigned probes, int old_header, uint8_t* out, size_t cap) {
+  std::vector<uint8_t> z = zlib_miniz_probes(data, n, probes, old_header != 0);
   if (out && cap >= z.size()) memcpy(out, z.data(), z.size());
   return z.size();
 }

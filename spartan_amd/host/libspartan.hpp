@@ -15,6 +15,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/spartan_hip.h"
@@ -62,10 +63,13 @@ ShardStats commit_shard_stats(Ctx& c, bool reset);
 bool commit_shard_active(sp_ctx* c);
 std::vector<sp_ctx*> residue_shard_ctxs(sp_ctx* c);  // virtual shards: [c, sub-contexts...]; empty when none
 void commit_shard_note_gather(sp_ctx* c, size_t bytes);
-bool commit_shard_transport(sp_ctx* c, int* rank, int* world);  // callback / RCCL transport configured: this rank's place among the lock-step ranks
+// callback / RCCL transport configured: this rank's place among the lock-step ranks, and the table length (log2) from which a sum-check is
+// residue-sharded over it (resolved once when the sharding was configured, identical on every rank: shard.cc, check_switches_agree)
+bool commit_shard_transport(sp_ctx* c, int* rank, int* world, int* residue_min_log2 = nullptr);
+bool commit_shard_residue_off(sp_ctx* c);  // SPARTAN_NO_RESIDUE_SHARDS as resolved when the sharding was configured
 void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per);   // all-gather of `per` bytes per rank over that transport (rank order)
 double rccl_allgather_probe(sp_ctx* c, size_t bytes, int iters);  // us per H2D + ncclAllGather + D2H + sync of `bytes` per rank
-bool commit_shard_shared_seed(sp_ctx* c, Fq* seed);  // multi-rank transports only: rank 0's OS-entropy draw, handed to every rank
+bool commit_shard_shared_seed(sp_ctx* c, Fq* seed);  // multi-rank transports only: a hash of every rank's OS-entropy contribution, the same on every rank
 void commit_shard_forget(sp_ctx* c);
 bool sharded_commit_rows(sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs, const uint64_t* blinds,
                          uint8_t* out);
@@ -138,11 +142,17 @@ struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the m
   std::vector<SparseEntry> A, B, C;
   sp_sparse *dA = nullptr, *dB = nullptr, *dC = nullptr;
   // R1CSShapeDigest bytes: zlib(level 6)(bincode(shape)) (r1cs.rs:154-158), absorbed by NIZK::prove (lib.rs:514). Computed on first
-  // use by compute_digest() (deflate.cc: a restatement of miniz's level-6 tdefl, what flate2's rust_backend runs); a caller that
-  // holds the bytes of a real libspartan Instance may set them instead.
-  std::vector<uint8_t> digest;
+  // use by compute_digest() (deflate.cc: a restatement of miniz's level-6 tdefl, what flate2's rust_backend runs — byte-identical to the
+  // real C miniz 3.0.2 on the test corpus); a caller that holds the bytes of a real libspartan Instance may set them instead
+  // (set_digest). The computation is guarded: concurrent NIZK::prove calls over one Instance compute it once; a caller that wants the
+  // deflate of a large shape (~6 s at 2^20) out of its first prove calls compute_digest() right after construction, as the reference's
+  // Instance::new does (lib.rs:228).
+  mutable std::vector<uint8_t> digest;
+  bool digest_old_header = false;  // zlib header 0x78 0x01 (miniz < 2.2, miniz_oxide 0.3) instead of 0x78 0x9C; set before the first compute_digest()
+  mutable std::mutex digest_mu;
   std::vector<uint8_t> shape_bincode() const;  // bincode(R1CSShape): r1cs.rs:18-26, sparse_mlpoly.rs:19-38
-  const std::vector<uint8_t>& compute_digest();
+  const std::vector<uint8_t>& compute_digest() const;
+  void set_digest(const uint8_t* d, size_t n);
   // Instance::new (lib.rs:121-228): padding of num_cons / num_vars and the column shift are applied here.
   Instance(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const std::vector<SparseEntry>& A,
            const std::vector<SparseEntry>& B, const std::vector<SparseEntry>& C);
@@ -169,6 +179,8 @@ Fq seed_scalar(const char* domain, uint64_t seed);
 
 // zlib stream of `data` as miniz's tdefl produces it at level 6 (deflate.cc). old_header: 0x78 0x01 (miniz, miniz_oxide 0.3) instead of 0x78 0x9C
 std::vector<uint8_t> zlib_level6_miniz(const uint8_t* data, size_t n, bool old_header = false);
+// the same compressor at another probe count (tdefl flags & 0xFFF: 16/32/128/256/512/768/1500 = miniz levels 4..10); tests pin each against miniz
+std::vector<uint8_t> zlib_miniz_probes(const uint8_t* data, size_t n, unsigned probes, bool old_header = false);
 
 // ---- proof structs: field order == bincode order (same as the reference's serde derives) ----
 struct PolyCommitment { std::vector<CP> C; };                                   // dense_mlpoly.rs:38-41

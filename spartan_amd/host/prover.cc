@@ -254,12 +254,22 @@ std::vector<uint8_t> Instance::shape_bincode() const {
   }
   return b;
 }
-const std::vector<uint8_t>& Instance::compute_digest() {
+const std::vector<uint8_t>& Instance::compute_digest() const {
+  std::lock_guard<std::mutex> lk(digest_mu);
   if (digest.empty()) {
+    static std::once_flag said;
+    std::call_once(said, [] {
+      fprintf(stderr, "spartan_host: R1CSShapeDigest computed by the in-tree deflater (deflate.cc: byte-identical to miniz 3.0.2 level 6 on the test corpus; "
+                      "equality with miniz_oxide is the port's claim) — pass the digest of a libspartan Instance with set_digest to bypass it\n");
+    });
     std::vector<uint8_t> sb = shape_bincode();
-    digest = zlib_level6_miniz(sb.data(), sb.size(), getenv("SPARTAN_ZLIB_OLD_HEADER") != nullptr);
+    digest = zlib_level6_miniz(sb.data(), sb.size(), digest_old_header);
   }
   return digest;
+}
+void Instance::set_digest(const uint8_t* d, size_t n) {
+  std::lock_guard<std::mutex> lk(digest_mu);
+  digest.assign(d, d + n);
 }
 
 Fq seed_scalar(const char* domain, uint64_t seed) {
@@ -519,18 +529,29 @@ struct ResidueShards {
   std::vector<std::vector<DevTable>> sub;  // [shard][table]; with a multi-process transport: [0] = this rank's residue class
   std::vector<std::vector<sp_table*>> h;
   bool active = false, remote = false;     // remote: one residue class per lock-step rank, partial sums over the commit transport
+  bool in_flight = false;                  // a bind + evaluation has been started on every shard context and not collected yet
   size_t ntab = 0, W = 0, me = 0;
+  // An exception between bind_eval_start and the collect (a failed commitment on the proving core, one shard's collect failing) must
+  // not leave pend_eval armed on the persistent sub-contexts — every later sp_sumcheck_bind_eval_start on them would return SP_EINVAL.
+  void drain() {
+    if (!in_flight) return;
+    in_flight = false;
+    uint64_t sink[12];
+    for (sp_ctx* x : ctxs) (void)sp_sumcheck_bind_eval_collect(x, sink);
+  }
+  ~ResidueShards() { drain(); }
   void split(sp_ctx* c, const std::vector<sp_table*>& tabs) {
     size_t len = tabs.empty() ? 0 : sp_table_len(tabs[0]);
-    if (getenv("SPARTAN_NO_RESIDUE_SHARDS")) return;
+    if (commit_shard_residue_off(c)) return;  // (the switches were resolved when the sharding was configured, the same on every rank)
     ctxs = residue_shard_ctxs(c);
-    int rank = 0, world = 0;
+    int rank = 0, world = 0, min_log2 = 64;
     if (ctxs.size() >= 2) {
       W = ctxs.size();
-    } else if (getenv("SPARTAN_RESIDUE_TRANSPORT") && commit_shard_transport(c, &rank, &world)) {
+    } else if (commit_shard_transport(c, &rank, &world, &min_log2) && min_log2 < 64 && len >= ((size_t)1 << min_log2)) {
       // SURVEY 8e over real ranks: every rank has the full tables (it computed them like every other rank) and keeps only its residue
-      // class from here on; a round's partial sums travel over the transport the sharded commitments use (96 bytes per rank). Opt-in:
-      // at 2^20 the exchange (26 us over RCCL) costs more than the round it shortens
+      // class from here on; a round's partial sums travel over the transport the sharded commitments use (96 bytes per rank). Chosen by
+      // TABLE LENGTH: the exchange (26 us over RCCL) must be shorter than the round it shortens — tables of >= 2^22 entries (DESIGN.md,
+      // section 6); SPARTAN_RESIDUE_MIN_LOG2 moves the threshold, SPARTAN_RESIDUE_TRANSPORT=1 is the old "always"
       W = (size_t)world; me = (size_t)rank; remote = true;
       ctxs.assign(1, c);
     } else {
@@ -572,11 +593,19 @@ struct ResidueShards {
     add_partials(ev, parts, kind == 0 ? 2 : 3);
   }
   void bind_eval_start(int kind, const Fq& r) {  // every shard's bind + next evaluation in flight together (own streams)
+    in_flight = true;  // (set first: a start that fails half-way leaves the earlier shards armed, and drain() disarms them)
     for (size_t g = 0; g < ctxs.size(); g++) SPX(sp_sumcheck_bind_eval_start(ctxs[g], kind, h[g].data(), ntab, U(r)));
   }
   void bind_eval_collect(int kind, uint64_t* ev) {
     std::vector<std::array<uint64_t, 12>> parts(ctxs.size());
-    for (size_t g = 0; g < ctxs.size(); g++) { parts[g].fill(0); SPX(sp_sumcheck_bind_eval_collect(ctxs[g], parts[g].data())); }
+    int32_t first_bad = SP_OK;  // every shard is collected before anything is thrown
+    for (size_t g = 0; g < ctxs.size(); g++) {
+      parts[g].fill(0);
+      int32_t rc = sp_sumcheck_bind_eval_collect(ctxs[g], parts[g].data());
+      if (rc != SP_OK && first_bad == SP_OK) first_bad = rc;
+    }
+    in_flight = false;
+    SPX(first_bad);
     add_partials(ev, parts, kind == 0 ? 2 : 3);
   }
   // sub-tables of two entries: bind them to one and hand the W survivors of every table back to the owner's tables
@@ -713,7 +742,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         const sp_host_point* add[1] = {&aj.be_h};
         comm_eval = commit_rows(row, 1, add)[0];
         delta = aj.delta;
-      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); rs.drain(); throw; }
     } else {
       FqVec rows1(2 * W, fq_zero());
       rows1[nn + 1] = eval; rows1[nn + 2] = blinds_evals[j];
@@ -758,7 +787,7 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         rows2[W + nn + 1] = dp;
         const sp_host_point* add2[2] = {nullptr, &ahead.wait(j).rb_h};
         cm2 = commit_rows(rows2, 2, add2);
-      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); throw; }
+      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); rs.drain(); throw; }
       if (pending && rs.active) rs.bind_eval_collect(kind, ev);
       else if (pending) SPX(sp_sumcheck_bind_eval_collect(c, ev));
       if (resharded && more) { SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev)); pending = true; }
@@ -1091,13 +1120,13 @@ VarsAssignment::VarsAssignment(Ctx& ctx, const Fq* vars, size_t n_) : c(ctx.h), 
 NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& inputs, const NIZKGens& gens, Transcript& t,
                  const Fq* tape_seed, ProveTimes* tm, const sp_table* vars_resident) {  // lib.rs:501-546
   double t0 = now_s();
-  const_cast<Instance&>(inst).compute_digest();  // lib.rs:514 absorbs inst.digest (r1cs.rs:154-158); computed once per instance
+  const std::vector<uint8_t>& digest = inst.compute_digest();  // lib.rs:514 absorbs inst.digest (r1cs.rs:154-158); computed once per instance, under its lock
   Fq shared_seed;  // lock-step ranks of a sharded proof must share one tape: rank 0 draws it (shard.cc)
   if (!tape_seed && commit_shard_shared_seed(ctx.h, &shared_seed)) tape_seed = &shared_seed;
   RandomTape tape = tape_seed ? RandomTape("proof", *tape_seed) : RandomTape("proof");  // random.rs:11-18
   std::function<void()> prefix = [&]() {
     t.append_protocol_name("Spartan NIZK proof");
-    t.append_message("R1CSShapeDigest", inst.digest.data(), inst.digest.size());
+    t.append_message("R1CSShapeDigest", digest.data(), digest.size());
   };
   NIZK P;
   P.r1cs_sat_proof = r1cs_prove(ctx.h, inst, vars, nvars_given, inputs, gens.gens_r1cs_sat, t, tape, &P.rx, &P.ry, tm, nullptr, &prefix, nullptr, vars_resident);

@@ -80,10 +80,25 @@ struct ShardState {
   size_t dbuf_bytes = 0;
   std::vector<sp_ctx*> vctx;     // virtual: sub-contexts 1..W-1 (shard 0 runs on the owning context)
   ShardStats stats;
+  // Switches that decide whether a rank ENTERS a collective. They are read from the environment ONCE, when the sharding is configured,
+  // kept here, and — for the multi-process transports — compared across the ranks before the first proof (a rank whose environment
+  // differs would otherwise deadlock in ncclAllGather or diverge from the others' transcripts).
+  bool no_shard_cols = false;    // SPARTAN_NO_SHARD_COLS: few-row commitments are not column-sharded
+  bool no_residue = false;       // SPARTAN_NO_RESIDUE_SHARDS: sum-check tables are never residue-sharded
+  bool device_encode = false;    // SPARTAN_DEVICE_ENCODE (read by sp_ctx_create too): sp_commit_rows_partial is unavailable -> no column sharding
+  int residue_min_log2 = 22;     // multi-process transports: tables of >= 2^k entries are residue-sharded (SPARTAN_RESIDUE_MIN_LOG2; DESIGN.md section 6:
+                                 // a round must outlast the ~26 us exchange, i.e. >= 2^22 entries per table; 0 = always, 64 = never)
 };
 std::mutex g_mu;
 std::map<sp_ctx*, ShardState> g_state;
 
+void read_switches(ShardState& s) {
+  s.no_shard_cols = getenv("SPARTAN_NO_SHARD_COLS") != nullptr;
+  s.no_residue = getenv("SPARTAN_NO_RESIDUE_SHARDS") != nullptr;
+  s.device_encode = getenv("SPARTAN_DEVICE_ENCODE") != nullptr;
+  if (const char* e = getenv("SPARTAN_RESIDUE_MIN_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 64) s.residue_min_log2 = v; }
+  if (getenv("SPARTAN_RESIDUE_TRANSPORT")) s.residue_min_log2 = 0;  // the round-3 opt-in: every sum-check, whatever its size
+}
 void release(ShardState& s) {
   if (s.comm || s.dbuf || s.stream) (void)hipSetDevice(s.dev);
   for (sp_ctx* v : s.vctx) sp_ctx_destroy(v);
@@ -94,6 +109,21 @@ void release(ShardState& s) {
   s.dbuf = nullptr;
   if (s.stream) (void)hipStreamDestroy(s.stream);
   s.stream = nullptr;
+}
+
+void gather_bytes(ShardState& s, uint8_t* all, size_t per);
+// every lock-step rank must have resolved the switches the same way: one 8-byte exchange when the sharding is configured
+void check_switches_agree(ShardState& s) {
+  if (s.world <= 1) return;
+  const size_t W = (size_t)s.world;
+  std::vector<uint8_t> all(8 * W, 0);
+  uint8_t* mine = &all[8 * (size_t)s.rank];
+  mine[0] = s.no_shard_cols; mine[1] = s.no_residue; mine[2] = s.device_encode; mine[3] = (uint8_t)s.residue_min_log2; mine[4] = 0xA5;
+  gather_bytes(s, all.data(), 8);
+  for (size_t r = 0; r < W; r++)
+    if (memcmp(&all[8 * r], mine, 8) != 0)
+      throw Error("set_commit_shard: rank " + std::to_string(r) + " resolved the sharding switches (SPARTAN_NO_SHARD_COLS / SPARTAN_NO_RESIDUE_SHARDS / "
+                  "SPARTAN_DEVICE_ENCODE / SPARTAN_RESIDUE_MIN_LOG2) differently from rank " + std::to_string(s.rank) + ": the ranks would not enter the same collectives");
 }
 
 }  // namespace
@@ -114,9 +144,12 @@ void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* 
   commit_shard_forget(c.h);
   if (world <= 1) return;
   if (!gather || rank < 0 || rank >= world) throw Error("set_commit_shard: bad arguments");
-  std::lock_guard<std::mutex> lk(g_mu);
-  ShardState& s = g_state[c.h];
+  ShardState s;
   s.mode = 1; s.rank = rank; s.world = world; s.gather = gather; s.user = user;
+  read_switches(s);
+  check_switches_agree(s);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_state[c.h] = s;
 }
 void rccl_unique_id(uint8_t out[128]) {
   need_rccl();
@@ -135,8 +168,10 @@ void set_commit_shard_rccl(Ctx& c, int rank, int world, const uint8_t unique_id[
   memcpy(id.internal, unique_id, 128);
   hip_ok(hipSetDevice(s.dev), "hipSetDevice");  // the communicator and its stream belong to the context's GPU, whatever the calling thread had current
   hip_ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+  read_switches(s);
   try {
     nccl_ok(rccl().CommInitRank(&s.comm, world, id, rank), "ncclCommInitRank");
+    check_switches_agree(s);
   } catch (...) {
     release(s);
     throw;
@@ -149,6 +184,7 @@ void set_commit_shard_virtual(Ctx& c, int nshards) {
   if (nshards <= 1) return;
   ShardState s;
   s.mode = 3; s.rank = 0; s.world = nshards;
+  read_switches(s);
   int dev = s.dev = sp_ctx_device(c.h);
   for (int k = 1; k < nshards; k++) {
     sp_ctx* v = nullptr;
@@ -169,9 +205,13 @@ ShardStats commit_shard_stats(Ctx& c, bool reset) {
 
 // A RandomTape seed shared by the lock-step ranks of a sharded proof. With the production setting (no caller seed) every
 // rank would seed its tape from its own OS entropy: each would blind its row slice with its own tape, the gathered
-// commitment would mix blinds of different tapes and the ranks' transcripts would diverge. So rank 0 draws the seed and the
-// transport that moves the commitments moves it to the others (callback: one gather; RCCL: one all-gather of 32 bytes).
-// The seed fixes every blind of the proof: it is secret, single-use, and never leaves the node's ranks.
+// commitment would mix blinds of different tapes and the ranks' transcripts would diverge. So the ranks agree on one seed:
+// EVERY rank contributes 64 bytes of OS entropy, the contributions travel over the transport that moves the commitments
+// (callback: one gather; RCCL: one all-gather), and the seed is from_bytes_wide(SHAKE256("spartan_amd shared tape seed" || all)):
+// no single rank (and no transport slot left unfilled) can fix it, and an all-zero or short gather is refused.
+// CONTRACT of the transport (set_commit_shard's callback, the RCCL communicator): the seed material fixes every blind of the proof —
+// whoever reads it can recover the witness from the proof — so the transport must be confidential and node-local (xGMI / shared
+// memory between the ranks of one node; never a network hop). The buffers are wiped after use.
 // Returns false when no multi-rank transport is configured (single GPU, virtual shards): the caller seeds as usual.
 bool commit_shard_shared_seed(sp_ctx* c, Fq* seed) {
   ShardState* sp = nullptr;
@@ -182,27 +222,39 @@ bool commit_shard_shared_seed(sp_ctx* c, Fq* seed) {
     sp = &it->second;
   }
   ShardState& s = *sp;
-  size_t W = (size_t)s.world;
-  std::vector<uint8_t> buf(32 * W, 0);
-  if (s.rank == 0) { Fq x = RandomTape::os_random_scalar(); memcpy(buf.data(), x.l, 32); }
-  if (s.mode == 1) {
-    if (s.gather(s.user, buf.data(), 32 * W, 32 * (size_t)s.rank, 32) != 0) throw Error("commit shard gather failed (tape seed)");
-  } else {
-    hip_ok(hipSetDevice(s.dev), "hipSetDevice");
-    size_t need = 32 + 32 * W;
-    if (s.dbuf_bytes < need) {
-      if (s.dbuf) hip_ok(hipFree(s.dbuf), "hipFree");
-      s.dbuf = nullptr;
-      hip_ok(hipMalloc((void**)&s.dbuf, need), "hipMalloc");
-      s.dbuf_bytes = need;
-    }
-    hip_ok(hipMemcpyAsync(s.dbuf, buf.data() + 32 * (size_t)s.rank, 32, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
-    nccl_ok(rccl().AllGather(s.dbuf, s.dbuf + 32, 32, 1 /*ncclUint8*/, s.comm, s.stream), "ncclAllGather");
-    hip_ok(hipMemcpyAsync(buf.data(), s.dbuf + 32, 32 * W, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
-    hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+  const size_t W = (size_t)s.world, per = 64;
+  std::vector<uint8_t> buf(per * W, 0);
+  {
+    Fq a = RandomTape::os_random_scalar(), b = RandomTape::os_random_scalar();
+    memcpy(&buf[per * (size_t)s.rank], a.l, 32);
+    memcpy(&buf[per * (size_t)s.rank + 32], b.l, 32);
+    volatile uint64_t* wa = a.l; volatile uint64_t* wb = b.l;
+    for (int i = 0; i < 4; i++) { wa[i] = 0; wb[i] = 0; }
   }
-  memcpy(seed->l, buf.data(), 32);  // rank 0's draw
-  s.stats.gathers++; s.stats.bytes += 32 * W;
+  gather_bytes(s, buf.data(), per);
+  bool ok = true;
+  for (size_t r = 0; r < W && ok; r++) {
+    bool zero = true;
+    for (size_t k = 0; k < per; k++) zero = zero && buf[per * r + k] == 0;
+    ok = !zero;  // a slot nobody filled: a transport that returned success without moving that rank's bytes
+  }
+  if (ok) {
+    Shake256 sh;
+    static const char dom[] = "spartan_amd shared tape seed";
+    sh.absorb(dom, sizeof dom - 1);
+    sh.absorb(buf.data(), buf.size());
+    uint8_t wide[64];
+    sh.squeeze(wide, 64);
+    uint64_t w[8];
+    memcpy(w, wide, 64);
+    *seed = sp::fq_from_u512(w);
+    volatile uint8_t* vw = wide; for (size_t i = 0; i < 64; i++) vw[i] = 0;
+    volatile uint64_t* v8 = w; for (int i = 0; i < 8; i++) v8[i] = 0;
+  }
+  volatile uint8_t* vb = buf.data(); for (size_t i = 0; i < buf.size(); i++) vb[i] = 0;
+  if (s.mode == 2 && s.dbuf) (void)hipMemset(s.dbuf, 0, s.dbuf_bytes < per * (W + 1) ? s.dbuf_bytes : per * (W + 1));
+  if (!ok) throw Error("commit shard transport returned an unfilled tape-seed slot: the ranks cannot agree on a RandomTape seed");
+  s.stats.gathers++; s.stats.bytes += per * W;
   return true;
 }
 
@@ -260,7 +312,8 @@ void commit_shard_note_gather(sp_ctx* c, size_t bytes) {
 }
 
 // all-gather of `per` bytes from every rank into all[world * per] (rank order) over the context's transport (callback or RCCL)
-static void gather_bytes(ShardState& s, uint8_t* all, size_t per) {
+namespace {
+void gather_bytes(ShardState& s, uint8_t* all, size_t per) {
   const size_t W = (size_t)s.world, lo = per * (size_t)s.rank;
   if (s.mode == 1) {
     if (s.gather(s.user, all, per * W, lo, per) != 0) throw Error("commit shard gather failed");
@@ -279,15 +332,22 @@ static void gather_bytes(ShardState& s, uint8_t* all, size_t per) {
   hip_ok(hipMemcpyAsync(all, s.dbuf + per, per * W, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
   hip_ok(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
 }
+}  // namespace
 
 // The multi-process transports (callback, RCCL) as seen by the residue-sharded sum-checks of prover.cc: this rank's place among the
 // lock-step ranks, and an all-gather of `per` bytes per rank (all[world * per], rank order; this rank's slice is filled in by the caller).
-bool commit_shard_transport(sp_ctx* c, int* rank, int* world) {
+bool commit_shard_transport(sp_ctx* c, int* rank, int* world, int* residue_min_log2) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_state.find(c);
   if (it == g_state.end() || (it->second.mode != 1 && it->second.mode != 2) || it->second.world <= 1) return false;
   *rank = it->second.rank; *world = it->second.world;
+  if (residue_min_log2) *residue_min_log2 = it->second.no_residue ? 64 : it->second.residue_min_log2;
   return true;
+}
+bool commit_shard_residue_off(sp_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_state.find(c);
+  return it != g_state.end() && it->second.no_residue;
 }
 void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per) {
   ShardState* sp = nullptr;
@@ -309,7 +369,9 @@ void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per) {
 static bool sharded_commit_cols(ShardState& s, sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs,
                                 const uint64_t* blinds, uint8_t* out /*32*Ls*/) {
   const size_t W = (size_t)s.world;
-  if (W <= 1 || Ls == 0 || Ls > 8 || Rs % W != 0 || getenv("SPARTAN_NO_SHARD_COLS")) return false;
+  // (device_encode: sp_commit_rows_partial leaves row sums as points for the HOST to add and encode, which that diagnostic setting forbids:
+  // the commitment then takes the unsharded path on every rank, as it did before column sharding existed)
+  if (W <= 1 || Ls == 0 || Ls > 8 || Rs % W != 0 || s.no_shard_cols || s.device_encode) return false;
   const size_t per = Rs / W;
   auto chk = [](int32_t rc, const char* what) { if (rc != SP_OK) throw Error(std::string(what) + " failed: " + sp_strerror(rc)); };
   std::vector<sp_host_point> pts((W + 1) * Ls);  // [shard][row], then the blind terms

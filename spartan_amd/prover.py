@@ -88,6 +88,18 @@ class Instance:
     def set_digest(self, d):
         H.spz_instance_set_digest(self.h, d, sz(len(d)))
 
+    def digest(self):
+        """R1CSShapeDigest (src/r1cs.rs:154-158): the bytes set with set_digest, else computed by the host library (zlib level 6 of bincode(shape))"""
+        H.spz_instance_digest.restype = sz
+        n = H.spz_instance_digest(self.h, None, sz(0))
+        buf = (ctypes.c_uint8 * n)()
+        H.spz_instance_digest(self.h, buf, sz(n))
+        return bytes(buf)
+
+    def set_digest_header(self, old_header):
+        """zlib header variant of the computed digest: False = 0x78 0x9C (miniz >= 2.2, miniz_oxide >= 0.4), True = 0x78 0x01"""
+        H.spz_instance_set_digest_header(self.h, ctypes.c_int(1 if old_header else 0))
+
     def free(self):
         if self.h:
             H.spz_instance_free(self.h); self.h = None

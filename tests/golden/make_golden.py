@@ -15,7 +15,7 @@ Run:  python tests/golden/make_golden.py [--big]   (from the repo root)"""
 import ctypes, hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from tests.helpers import load_oracle, sz, vp, u64x4, gens_bytes
+from tests.helpers import load_oracle, sz, vp, u64x4, gens_bytes, real_miniz_zlib, oracle_shape_bincode
 
 CASES = {"nizk": [(4, 2), (7, 3), (12, 5)], "snark": [(3, 1), (5, 2), (8, 3), (12, 4), (15, 5)]}  # (log2 size, seed)
 BIG_CASES = {"nizk": [(16, 6), (20, 0)], "snark": [(16, 6), (20, 0), (22, 0)]}  # seed 0 = bench.py's instance and tape
@@ -44,9 +44,14 @@ def nizk_case(orc, s, seed):
     inst = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(ni), ctypes.c_uint64(seed)))
     g = vp(orc.orc_nizk_gens_new(sz(N), sz(N), sz(ni)))
     tape = u64x4(); orc.orc_seed_scalar(b"tape", ctypes.c_uint64(seed), tape)
-    d = b"digest-%d" % s
+    # R1CSShapeDigest as the reference forms it (src/r1cs.rs:154-158): zlib level 6 of bincode(shape) — here through the REAL C miniz
+    # bundled in libtorch (tests/helpers.py: real_miniz_zlib), not through the product's deflate.cc: the GPU tests prove with the digest
+    # the product computes itself and must land on these bytes
+    d = real_miniz_zlib(oracle_shape_bincode(orc, inst), 6)
     p = vp(orc.orc_nizk_prove(inst, g, d, sz(len(d)), b"nizk_example", tape, None))
     e = digest_entry(orc, p)
+    e["shape_digest_len"] = len(d)
+    e["shape_digest_sha256"] = hashlib.sha256(d).hexdigest()
     orc.orc_proof_free(p); orc.orc_nizk_gens_free(g); orc.orc_instance_free(inst)
     return e
 
@@ -86,7 +91,7 @@ if __name__ == "__main__":
         for kind, fn in (("nizk", nizk_case), ("snark", snark_case)):
             for s, seed in BIG_CASES[kind]:
                 key = f"s{s}_seed{seed}"
-                if key in big[kind] and "--force" not in sys.argv:
+                if key in big[kind] and "--force" not in sys.argv and not (kind == "nizk" and "shape_digest_sha256" not in big[kind][key]):
                     continue
                 t0 = time.time()
                 big[kind][key] = fn(orc, s, seed)

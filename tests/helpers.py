@@ -108,3 +108,36 @@ def from_mont_bulk(arr, n):
 def fast_scalars(rng, n):
     """n uniform scalars from one getrandbits call per element"""
     return [rng.getrandbits(300) % Q for _ in range(n)]
+
+
+_MINIZ = None
+
+
+def real_miniz_zlib(data, level=6):
+    """zlib stream of `data` from the REAL C miniz (3.0.2, mz_version "11.0.2") that libtorch_cpu.so bundles and exports (mz_compress2):
+    the independent implementation the in-tree deflater (spartan_amd/host/deflate.cc) and the NIZK golden digests are pinned against.
+    flate2's rust_backend runs miniz_oxide, the Rust port of this code; level 6 is Compression::default() (src/r1cs.rs:154-158)."""
+    global _MINIZ
+    if _MINIZ is None:
+        import torch
+        mz = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so"))
+        mz.mz_compress2.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulong), ctypes.c_char_p, ctypes.c_ulong, ctypes.c_int]
+        mz.mz_compress2.restype = ctypes.c_int
+        mz.mz_compressBound.restype = ctypes.c_ulong
+        mz.mz_compressBound.argtypes = [ctypes.c_ulong]
+        mz.mz_version.restype = ctypes.c_char_p
+        _MINIZ = mz
+    mz = _MINIZ
+    cap = mz.mz_compressBound(len(data)) + 64
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_ulong(cap)
+    rc = mz.mz_compress2(out, ctypes.byref(n), bytes(data), len(data), level)
+    assert rc == 0, "mz_compress2 failed: %d" % rc
+    return out.raw[:n.value]
+
+
+def oracle_shape_bincode(orc, inst):
+    n = orc.orc_instance_shape_bincode(inst, None, sz(0))
+    b = (ctypes.c_uint8 * n)()
+    orc.orc_instance_shape_bincode(inst, b, sz(n))
+    return bytes(b)

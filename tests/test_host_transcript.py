@@ -104,7 +104,7 @@ def _zlib6(H, data, old=0):
 
 def test_shape_digest_deflater_round_trips_and_keeps_miniz_parameters(H, orc):
     """R1CSShape::get_digest (src/r1cs.rs:154-158) = zlib(level 6)(bincode(shape)) through flate2's rust_backend, i.e. miniz's tdefl.
-    spartan_amd/host/deflate.cc restates that path; no miniz exists here, so what is pinned is: (1) every stream inflates with an
+    spartan_amd/host/deflate.cc restates that path (byte equality with the real miniz: test_deflater_equals_real_miniz below); here: (1) every stream inflates with an
     independent implementation (Python zlib) to exactly its input — stored, static and dynamic blocks, multi-block inputs, the
     bincode of a synthetic R1CS shape as the ORACLE serialises it; (2) the stream shape miniz documents: header 0x78 0x9C (0x78 0x01
     with the old-header switch), Adler-32 trailer, a stored block for inputs a coded block would expand, blocks closed by the
@@ -132,3 +132,44 @@ def test_shape_digest_deflater_round_trips_and_keeps_miniz_parameters(H, orc):
     z = _zlib6(H, incompressible)
     assert len(z) == len(incompressible) + 2 + 4 + 5 * 2 and z[2] == 0        # two stored blocks (the 31 KiB rule), not final / final
     d = zlib.decompressobj(); d.decompress(_zlib6(H, shape)); assert d.eof
+
+
+def _zlib_probes(H, data, probes, old=0):
+    H.spz_zlib_probes.restype = sz
+    cap = 2 * len(data) + 1024
+    out = (ctypes.c_uint8 * cap)()
+    n = H.spz_zlib_probes(data, sz(len(data)), ctypes.c_uint(probes), ctypes.c_int(old), out, sz(cap))
+    return bytes(out[:n])
+
+
+def test_deflater_equals_real_miniz(H, orc):
+    """THE PIN of the compressed R1CSShapeDigest (src/r1cs.rs:154-158: the digest absorbed by NIZK::prove is the zlib stream itself).
+    libtorch_cpu.so bundles the real C miniz (3.0.2) and exports mz_compress2; flate2's rust_backend is miniz_oxide, the Rust port of
+    the same tdefl. spartan_amd/host/deflate.cc must produce the SAME BYTES — header, every block, Adler-32 — at level 6 (what
+    Compression::default() selects: 128 probes) and, to show the restatement is tdefl itself and not a level-6 coincidence, at every
+    other lazy-parsing level (4, 5, 7, 8, 9, 10 = 16 / 32 / 256 / 512 / 768 / 1500 probes). Corpus: the bincode of synthetic R1CS shapes
+    2^4 .. 2^16 as the oracle serialises them (the real input; up to 9.4 MB, hundreds of dynamic-Huffman blocks), incompressible data
+    (stored blocks), runs, text, tiny inputs (static blocks), inputs around the 31 KiB / 64 K-symbol block rules."""
+    assert real_miniz_zlib(b"")[:2] == b"\x78\x9c"
+    rng = random.Random(11)
+    cases = {"empty": b"", "a": b"a", "hello": b"hello hello hello hello", "zeros": bytes(5000), "rand": bytes(rng.randrange(256) for _ in range(40000)),
+             "runs": b"abcdefghij" * 20000, "rand4": bytes(rng.randrange(4) for _ in range(150000)),
+             "text": open(os.path.join(ROOT, "SURVEY.md"), "rb").read(), "47": bytes(range(47)), "48": bytes(range(48)),
+             "31k": bytes(rng.randrange(16) for _ in range(31 * 1024 + 1)), "64ksym": bytes(rng.randrange(2) for _ in range(70000))}
+    for s in (4, 8, 9, 12, 14, 16):
+        N = 1 << s
+        oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(3)))
+        cases["shape2^%d" % s] = oracle_shape_bincode(orc, oi)
+        orc.orc_instance_free(oi)
+    assert len(cases["shape2^16"]) == 24 + 3 * (24 + 48 * 65536)
+    for name, c in cases.items():
+        want = real_miniz_zlib(c, 6)
+        assert _zlib6(H, c) == want, name                      # the product's digest function, whole stream
+        assert _zlib_probes(H, c, 128) == want, name
+    probes = {4: 16, 5: 32, 7: 256, 8: 512, 9: 768, 10: 1500}
+    for name in ("hello", "rand", "runs", "rand4", "text", "31k", "shape2^4", "shape2^9", "shape2^12", "shape2^14"):
+        for level, pr in probes.items():
+            assert _zlib_probes(H, cases[name], pr) == real_miniz_zlib(cases[name], level), (name, level)
+    # the old-header variant (miniz < 2.2, miniz_oxide 0.3) changes the second byte and nothing else
+    z0, z1 = _zlib6(H, cases["shape2^9"], 0), _zlib6(H, cases["shape2^9"], 1)
+    assert z1[:2] == b"\x78\x01" and z0[:2] == b"\x78\x9c" and z1[2:] == z0[2:]
