@@ -1,0 +1,171 @@
+// Micro-benchmark: the GATHER ceiling of the fixed-base row MSM (VERDICT r3 #2 / "missing" #6).
+//
+// The row MSM (spartan_amd/csrc/core.hip: k_msm_rows) performs, per mixed addition, one gather of a 96-byte affine Niels entry
+// from a window table of 27 GB (1025 points, 15-bit windows) or 61 GB (4098 points, 14-bit windows). A wavefront's 64 lanes are 64
+// ROWS of the same column, so the 64 gathers of a step fall into ONE (point, window) sub-table (tent entries: 1.5 MiB at 15 bits,
+// 0.75 MiB at 14) at uniformly random entries. This program issues exactly that access pattern with NO arithmetic behind it and
+// reports entries/s, so that the MSM's additions/s can be put next to (a) the pt_madd ALU ceiling (bench/ubench_fpmul) and (b) this
+// gather ceiling. Variables: table size, entry stride (96 = packed, status quo: half of the entries straddle two 128-byte lines;
+// 128 = one line per entry), bytes read per entry (96 / 64 / 32), gathers in flight per lane (1, 2, 4), resident waves per SIMD
+// (3 = the MSM's occupancy at 164 VGPRs, 4, 8).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 bench/gather_probe.hip -o bench/gather_probe
+// Run:   ./gather_probe            full sweep, human readable
+//        ./gather_probe --json     the two configurations bench.py needs (27 GB / 61 GB, stride 96, 3 waves, 2 in flight), one JSON line
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) {  // cheap avalanche (lowbias32)
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+// One "step" = every lane gathers one entry of EB bytes from sub-table `st` (wave-uniform) at a lane-random index.
+// K steps are issued before any of their data is consumed (K entries in flight per lane).
+template <int K, int EB>
+__global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ base, uint32_t n_sub, uint32_t sub_entries, uint32_t stride16, int steps,
+                                                uint32_t seed, uint4* __restrict__ out) {
+  extern __shared__ uint8_t occupancy_fence[];  // dynamic LDS sized by the host so that exactly the wanted number of blocks fits a CU
+  const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  constexpr int Q = EB / 16;
+  for (int s = 0; s < steps; s += K) {
+    uint4 v[K][Q];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      uint32_t st = mix(seed ^ (wave * 0x9E3779B1U + (uint32_t)(s + k))) % n_sub;                       // wave-uniform: the (point, window) sub-table
+      uint32_t e = mix((seed * 31u) ^ (wave * 64u + lane) * 0x85EBCA77U ^ (uint32_t)(s + k) * 0xC2B2AE3DU) % sub_entries;  // lane-random entry
+      const uint4* p = base + ((size_t)st * sub_entries + e) * stride16;
+#pragma unroll
+      for (int q = 0; q < Q; q++) v[k][q] = p[q];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int q = 0; q < Q; q++) { acc.x ^= v[k][q].x; acc.y += v[k][q].y; acc.z ^= v[k][q].z; acc.w += v[k][q].w; }
+  }
+  if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) out[wave * 64 + lane] = acc;  // never true in practice: keeps the loads alive
+}
+
+struct Result { double gent_per_s, useful_TBps, line_TBps; float ms; };
+
+template <int K, int EB>
+static Result run(const uint4* base, size_t table_bytes, uint32_t sub_entries, uint32_t stride_bytes, int waves_per_simd, int ncu, int steps, uint4* out) {
+  const uint32_t stride16 = stride_bytes / 16;
+  const size_t n_entries = table_bytes / stride_bytes;
+  const uint32_t n_sub = (uint32_t)(n_entries / sub_entries);
+  const int blocks_per_cu = waves_per_simd;  // a 256-thread block = one wave on each of the 4 SIMDs
+  const size_t lds = (160 * 1024) / blocks_per_cu - 2048;  // only `blocks_per_cu` blocks fit
+  const int grid = ncu * blocks_per_cu;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  CHK(hipFuncSetAttribute((const void*)k_gather<K, EB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    CHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_gather<K, EB>), dim3(grid), dim3(256), lds, 0, base, n_sub, sub_entries, stride16, steps, 1234u + rep, out);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+  const double ent = (double)grid * 256.0 * (double)steps;
+  // 128-byte lines touched per entry: an EB-byte read at offset (k * stride) mod 128
+  double lines = 0;
+  for (int k = 0; k < 128; k++) { size_t off = ((size_t)k * stride_bytes) % 128; lines += (double)((off + EB - 1) / 128 + 1); }
+  lines /= 128.0;
+  Result r;
+  r.ms = best;
+  r.gent_per_s = ent / (best * 1e-3) / 1e9;
+  r.useful_TBps = ent * EB / (best * 1e-3) / 1e12;
+  r.line_TBps = ent * lines * 128.0 / (best * 1e-3) / 1e12;
+  return r;
+}
+
+template <int EB>
+static Result run_k(int K, const uint4* base, size_t tb, uint32_t se, uint32_t sb, int w, int ncu, int steps, uint4* out) {
+  switch (K) {
+    case 1: return run<1, EB>(base, tb, se, sb, w, ncu, steps, out);
+    case 2: return run<2, EB>(base, tb, se, sb, w, ncu, steps, out);
+    default: return run<4, EB>(base, tb, se, sb, w, ncu, steps, out);
+  }
+}
+static Result run_any(int K, int EB, const uint4* base, size_t tb, uint32_t se, uint32_t sb, int w, int ncu, int steps, uint4* out) {
+  switch (EB) {
+    case 32: return run_k<32>(K, base, tb, se, sb, w, ncu, steps, out);
+    case 64: return run_k<64>(K, base, tb, se, sb, w, ncu, steps, out);
+    case 128: return run_k<128>(K, base, tb, se, sb, w, ncu, steps, out);
+    default: return run_k<96>(K, base, tb, se, sb, w, ncu, steps, out);
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool json = argc > 1 && !strcmp(argv[1], "--json");
+  hipDeviceProp_t prop;
+  CHK(hipGetDeviceProperties(&prop, 0));
+  const int ncu = prop.multiProcessorCount;
+  size_t free_b = 0, total_b = 0;
+  CHK(hipMemGetInfo(&free_b, &total_b));
+  // the largest table of the sweep (default 122 GB = the 2^22 instance's evaluation stream; shrunk to what is free)
+  double max_gb = 122.0;
+  if (const char* e = getenv("GATHER_MAX_GB")) max_gb = atof(e);
+  if (json) max_gb = 61.5;
+  if (max_gb * 1e9 > (double)free_b - 8e9) max_gb = ((double)free_b - 8e9) / 1e9;
+  const size_t bytes = (size_t)(max_gb * 1e9) & ~(size_t)0xFFFFF;
+  uint4* base = nullptr; uint4* out = nullptr;
+  CHK(hipMalloc((void**)&base, bytes));
+  CHK(hipMalloc((void**)&out, (size_t)ncu * 8 * 256 * 16 + 4096));
+  CHK(hipMemset(base, 0x5a, bytes));  // touch every page (first-touch mapping) and give the loads non-trivial data
+  CHK(hipDeviceSynchronize());
+  if (json) {
+    // the MSM's own configuration: 96-byte entries at a 96-byte stride, 3 waves per SIMD, 2 entries in flight; 15-bit windows over 27.4 GB, 14-bit over 61.2 GB
+    Result a = run_any(2, 96, base, (size_t)27.4e9, 16384, 96, 3, ncu, 512, out);
+    Result b = run_any(2, 96, base, (size_t)61.2e9, 8192, 96, 3, ncu, 512, out);
+    Result a4 = run_any(4, 96, base, (size_t)27.4e9, 16384, 96, 3, ncu, 512, out);
+    Result b4 = run_any(4, 96, base, (size_t)61.2e9, 8192, 96, 3, ncu, 512, out);
+    printf("{\"unit\": \"G entries/s (96-byte table entries gathered, no arithmetic)\", \"cus\": %d, \"table27GB_wbits15\": {\"inflight2\": %.2f, \"inflight4\": %.2f, \"line_TBps\": %.3f}, "
+           "\"table61GB_wbits14\": {\"inflight2\": %.2f, \"inflight4\": %.2f, \"line_TBps\": %.3f}}\n",
+           ncu, a.gent_per_s, a4.gent_per_s, a4.line_TBps, b.gent_per_s, b4.gent_per_s, b4.line_TBps);
+    return 0;
+  }
+  printf("# gather_probe on %s, %d CUs, table buffer %.1f GB\n", prop.name, ncu, bytes / 1e9);
+  printf("# %-9s %-7s %-6s %-6s %-5s %-3s | %8s %10s %10s %8s\n", "table_GB", "sub_KiB", "stride", "bytes", "waves", "K", "ms", "Gentry/s", "useful_TB/s", "line_TB/s");
+  struct Cfg { double gb; uint32_t sub_entries; uint32_t stride; int eb; int waves; int K; };
+  std::vector<Cfg> cfgs;
+  const double sizes[] = {0.2, 8.0, 27.4, 61.2, 110.0, 122.0};
+  for (double gb : sizes) {
+    if (gb * 1e9 > (double)bytes) continue;
+    for (int waves : {3, 4, 8})
+      for (int K : {1, 2, 4}) {
+        cfgs.push_back({gb, 16384, 96, 96, waves, K});    // status quo (15-bit sub-table)
+        cfgs.push_back({gb, 16384, 128, 96, waves, K});   // one 128-byte line per entry
+      }
+    // entry-size / stride variants at the MSM's occupancy and at 4 waves
+    for (int waves : {3, 4}) {
+      cfgs.push_back({gb, 16384, 128, 128, waves, 2});
+      cfgs.push_back({gb, 16384, 64, 64, waves, 2});
+      cfgs.push_back({gb, 16384, 64, 64, waves, 4});
+      cfgs.push_back({gb, 16384, 32, 32, waves, 4});
+      cfgs.push_back({gb, 8192, 96, 96, waves, 2});       // 14-bit sub-table
+      cfgs.push_back({gb, 1u << 30, 96, 96, waves, 2});   // no sub-table locality at all (one "sub-table" = the whole table)
+    }
+  }
+  for (const Cfg& c : cfgs) {
+    size_t tb = (size_t)(c.gb * 1e9);
+    uint32_t se = c.sub_entries;
+    size_t n_entries = tb / c.stride;
+    if ((size_t)se > n_entries) se = (uint32_t)n_entries;
+    Result r = run_any(c.K, c.eb, base, tb, se, c.stride, c.waves, ncu, 256, out);
+    printf("  %-9.1f %-7.0f %-6u %-6d %-5d %-3d | %8.3f %10.2f %10.3f %8.3f\n", c.gb, (double)se * c.stride / 1024.0, c.stride, c.eb, c.waves, c.K, r.ms, r.gent_per_s,
+           r.useful_TBps, r.line_TBps);
+    fflush(stdout);
+  }
+  return 0;
+}

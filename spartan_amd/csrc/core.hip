@@ -262,6 +262,173 @@ __global__ void __launch_bounds__(1024) k_msm_rows_bg(const Fq* __restrict__ Z, 
   for (size_t lb = (size_t)blockIdx.x * 4 + threadIdx.x / 256; lb < ntiles; lb += (size_t)gridDim.x * 4)
     msm_rows_tile<false>(lb, threadIdx.x % 256, Z, z_row_stride, rows, cols, strip, nstrips, table, g_off, nullptr, nullptr, 0, partial, xcd_map, geom);
 }
+// ---- balanced form of the row MSM (round 4) -----------------------------------------------------------------------------------
+// The strip form above gives a thread a whole number of SCALARS, and the launch a number of workgroups that has nothing to do with the
+// number the chip holds (3 per CU at 164 VGPRs = 768): a 256 x 1024 witness chunk is 1024 workgroups = 1.33 waves of workgroups (the
+// second one a third full: 0.61 of the addition ceiling), the derefs column half 1248 active ones = 1.6 (0.59). Here the unit of work is
+// one (column, window) pair = ONE table lookup + ONE mixed addition: a row's cols x nwin units are cut into nb equal runs, run k of
+// row-block r is one workgroup, and nb is chosen so that the whole launch is (at most) as many workgroups as the chip holds at once —
+// every CU works from the first to the last cycle of the launch and all finish together. A run starts and ends in the middle of a
+// scalar: the signed recoding's carry into its first window is rebuilt from the lower windows (integer work, once per thread).
+// The digit stream runs seamlessly from one scalar into the next, so the two table entries in flight stay in flight across scalars
+// (the strip form drained and refilled its pipeline once per scalar). Lanes are still rows of one column: a wave's 64 gathers of a
+// step fall into one (point, window) sub-table.
+// Short scalars / zero rows (SNARK::encode's address and timestamp vectors, padding rows): when no lane of the wave has a non-zero
+// digit left in the current scalar (ballot), the stream jumps to the next scalar without issuing the remaining gathers.
+struct MsmFlatArgs {
+  const Fq* Z; size_t z_row_stride, rows, cols;
+  const Niels* table; size_t g_off; const uint32_t* idx; const Fq* blinds; size_t h_idx;
+  Pt* partial;          // [rows][nb]
+  unsigned nb, rb_count;  // runs per row; row-blocks of 256 rows
+  MsmGeom geom;
+};
+struct MsmUnit { const MsmEntry* p; bool neg, nz, valid; };
+template <bool AHEAD>  // AHEAD: the next scalar is requested one scalar ahead (8 registers; the 128-register background form does without)
+struct MsmDigitStream {
+  const MsmFlatArgs& A;
+  const size_t row;
+  size_t j, ncol;      // current column (wave-uniform); columns incl. the blind
+  long left;           // units still to hand out (wave-uniform)
+  int w;               // next window of the current scalar (wave-uniform)
+  uint64_t s0, s1, s2, s3;  // the current scalar, canonical, shifted down by w windows
+  int carry;
+  Fq raw_next;         // Montgomery form of column j + 1, requested one scalar ahead
+  const MsmEntry* base;
+  __device__ __forceinline__ MsmDigitStream(const MsmFlatArgs& A_, size_t row_) : A(A_), row(row_) {}
+  __device__ __forceinline__ const Fq* scalar_ptr(size_t jj) const { return jj < A.cols ? A.Z + row * A.z_row_stride + jj : A.blinds + row; }
+  __device__ __forceinline__ void set_base(size_t jj) {
+    size_t pt = jj < A.cols ? (A.idx ? (size_t)A.idx[jj] : A.g_off + jj) : A.h_idx;
+    base = reinterpret_cast<const MsmEntry*>(A.table) + pt * A.geom.pt_entries;
+  }
+  __device__ __forceinline__ void take(const Fq& raw) {
+    Fq s = fq_from_mont(raw);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
+    s0 = s.l[0]; s1 = s.l[1]; s2 = s.l[2]; s3 = s.l[3];
+    carry = 0;
+  }
+  __device__ __forceinline__ void shift() {
+    const int c = A.geom.wbits;
+    s0 = (s0 >> c) | (s1 << (64 - c));
+    s1 = (s1 >> c) | (s2 << (64 - c));
+    s2 = (s2 >> c) | (s3 << (64 - c));
+    s3 >>= c;
+  }
+  __device__ __forceinline__ void open(size_t u0, size_t u1) {
+    const int nwin = A.geom.nwin;
+    ncol = A.cols + (A.blinds ? 1 : 0);
+    left = (long)(u1 - u0);
+    j = u0 / (size_t)nwin;
+    w = (int)(u0 % (size_t)nwin);
+    if (left <= 0) { left = 0; base = reinterpret_cast<const MsmEntry*>(A.table); s0 = s1 = s2 = s3 = 0; carry = 0; raw_next = fq_zero(); return; }
+    take(ld_fq(scalar_ptr(j)));
+    set_base(j);
+    if (AHEAD) raw_next = j + 1 < ncol ? ld_fq(scalar_ptr(j + 1)) : fq_zero();
+    for (int k = 0; k < w; k++) {  // the carry into window w depends on all lower windows
+      int d = (int)(s0 & ((1u << A.geom.wbits) - 1)) + carry;
+      carry = d >= A.geom.tent;
+      shift();
+    }
+  }
+  __device__ __forceinline__ void next(MsmUnit& u) {
+    const int nwin = A.geom.nwin, c = A.geom.wbits;
+    for (;;) {
+      if (left == 0) { u.p = base; u.neg = false; u.nz = false; u.valid = false; return; }
+      if (w == nwin) {
+        j++;
+        if (AHEAD) {
+          take(raw_next);
+          raw_next = j + 1 < ncol ? ld_fq(scalar_ptr(j + 1)) : fq_zero();
+        } else {
+          take(ld_fq(scalar_ptr(j)));
+        }
+        set_base(j);
+        w = 0;
+      }
+      if (__all((s0 | s1 | s2 | s3) == 0 && carry == 0)) {  // nothing left in this scalar on any lane of the wave: no gathers for its upper windows
+        long k = nwin - w;
+        if (k > left) k = left;
+        left -= k;
+        w = nwin;
+        continue;
+      }
+      break;
+    }
+    int d = (int)(s0 & ((1u << c) - 1)) + carry;
+    carry = d >= A.geom.tent;
+    d -= carry << c;
+    uint32_t m = (uint32_t)(d < 0 ? -d : d);
+    u.p = base + (size_t)w * A.geom.tent + (m ? m - 1 : 0);
+    u.neg = d < 0; u.nz = m != 0; u.valid = true;
+    shift();
+    w++; left--;
+  }
+};
+// PIPE 2: two entries in flight, each for the time of two additions (the loop is unrolled twice so that the registers of an entry in
+// flight are never the source of a copy: the compiler's waits then allow the 12 most recent loads to stay outstanding); PIPE 1: rolled,
+// the second entry is copied each step (its load is waited for at the top of the next step: in flight for ONE addition); PIPE 0: one
+// entry in flight, 48 registers less (the 128-register background form)
+template <int PIPE, bool AHEAD>
+__device__ __forceinline__ void msm_flat_tile(const MsmFlatArgs& A, unsigned lb, unsigned tid) {
+  const unsigned rb = lb % A.rb_count, bk = lb / A.rb_count;
+  if (bk >= A.nb) return;
+  const size_t row = (size_t)rb * 256 + tid;
+  const size_t U = (A.cols + (A.blinds ? 1 : 0)) * (size_t)A.geom.nwin;
+  const size_t u0 = U * bk / A.nb, u1 = U * (bk + 1) / A.nb;
+  Pt acc = pt_identity();
+  MsmDigitStream<AHEAD> ds(A, row);
+  ds.open(u0, u1);
+  MsmUnit a;
+  ds.next(a);
+  MsmEntry X = msm_load(a.p);
+  if (PIPE == 0) {
+#pragma unroll 1
+    while (a.valid) {
+      MsmEntry cur = X;
+      MsmUnit ca = a;
+      ds.next(a);
+      X = msm_load(a.p);
+      if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
+    }
+  } else {
+    MsmUnit b;
+    ds.next(b);
+    MsmEntry Y = msm_load(b.p);
+    if (PIPE == 2) {
+#pragma unroll 1
+      while (a.valid) {
+        MsmEntry cur = X;
+        MsmUnit ca = a;
+        ds.next(a);
+        X = msm_load(a.p);
+        if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
+        if (!b.valid) break;
+        cur = Y;
+        ca = b;
+        ds.next(b);
+        Y = msm_load(b.p);
+        if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
+      }
+    } else {
+#pragma unroll 1
+      while (a.valid) {
+        MsmEntry cur = X;
+        MsmUnit ca = a;
+        a = b; X = Y;
+        ds.next(b);
+        Y = msm_load(b.p);
+        if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
+      }
+    }
+  }
+  A.partial[row * A.nb + bk] = acc;
+}
+template <int PIPE>
+__global__ void __launch_bounds__(256) k_msm_flat(MsmFlatArgs A) { msm_flat_tile<PIPE, true>(A, blockIdx.x, threadIdx.x); }
+// background form: persistent 1024-thread workgroups on a share of the CUs (see k_msm_rows_bg)
+__global__ void __launch_bounds__(1024) k_msm_flat_bg(MsmFlatArgs A, unsigned ntiles) {
+  extern __shared__ uint8_t occupancy_fence[];
+  for (unsigned lb = blockIdx.x * 4 + threadIdx.x / 256; lb < ntiles; lb += gridDim.x * 4) msm_flat_tile<0, false>(A, lb, threadIdx.x % 256);
+}
+
 // Latency-bound shapes (Sigma-protocol commits, IPA rounds, single-row commits): one thread per (row, column,
 // window) performs a single table lookup, so the serial chain per thread is one mixed addition instead of 32.
 // partial[row][w*cols + j].  The blind, if any, is column `cols` (generator h_idx).
@@ -291,6 +458,9 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
 // same canonical bytes). All roles run ONE instruction stream — operands are chosen by LDS address and by selects, never
 // by branches — and the code is three multiplication bodies instead of nine (it is fetched cold by these few waves).
 __device__ __forceinline__ Fe10 fe10_pick(const Fe10& a, const Fe10& b, bool take_b) { return fe10_select(a, b, take_b); }
+#ifdef SP_TREE_LDS
+// Round 1-3 form (A/B variant: make variant NAME=treelds FLAGS=-DSP_TREE_LDS): the quad exchanges A, B, C, D through LDS, three block
+// barriers per level.
 __device__ __forceinline__ void pt10_tree_quad(Pt10* sm, Fe10* xch /*[256]*/, size_t n) {
   const int t = threadIdx.x, role = t & 3;
   const Fe10 zero = Fe10{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -335,6 +505,64 @@ __device__ __forceinline__ void pt10_tree_quad(Pt10* sm, Fe10* xch /*[256]*/, si
     }
   }
 }
+#else
+// Round 4 form: the four lanes of a quad are always lanes 4k..4k+3 of ONE wavefront, so A, B, C, D never need LDS or a barrier: they
+// travel by DPP quad_perm moves (v_mov_b32 ... quad_perm:[..], 20 per addition).
+//   stage 1   lane 0: A = (Y1-X1)(Y2-X2)   lane 1: B = (Y1+X1)(Y2+X2)   lane 2: C = T1 (2d T2)   lane 3: D = (2 Z1) Z2
+//   swap with the neighbour (quad_perm [1,0,3,2]): lane 0: E = B - A   lane 1: H = B + A   lane 2: F = D - C   lane 3: G = D + C
+//   fetch the second factor (quad_perm [1,3,0,2]): lane 0: T3 = E H    lane 1: Y3 = H G     lane 2: X3 = F E     lane 3: Z3 = G F
+// The sum of a pair replaces its first point in LDS, written by the quad that read it (the LDS unit executes a wave's accesses in
+// order, and no other quad touches those two points in this level), so a level needs ONE block barrier — before the next level reads
+// points written by other wavefronts — and the levels of at most 16 additions, which live entirely in wavefront 0, need none.
+// Same field elements as the LDS form, hence the same canonical bytes. `xch` is unused (kept for the callers' LDS layout).
+__device__ __forceinline__ Fe10 fe10_quad_perm_1032(const Fe10& a) {
+  Fe10 r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.v[i] = __builtin_amdgcn_mov_dpp(a.v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+  return r;
+}
+__device__ __forceinline__ Fe10 fe10_quad_perm_1302(const Fe10& a) {
+  Fe10 r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.v[i] = __builtin_amdgcn_mov_dpp(a.v[i], 0x8D /* quad_perm [1,3,0,2] */, 0xF, 0xF, true);
+  return r;
+}
+__device__ __forceinline__ void pt10_tree_quad(Pt10* sm, Fe10* /*xch*/, size_t n) {
+  const int t = threadIdx.x, role = t & 3;
+  const Fe10 zero = Fe10{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  const Fe10 k2d = fe10_pick(fe10_one(), fe10_load(fp_D2()), role == 2);  // the factor 2d belongs to C only
+  // field offsets inside Pt10, in units of Fe10: X 0, Y 1, Z 2, T 3
+  const int fsel = role <= 1 ? 1 : (role == 2 ? 3 : 2);  // first field:  Y, Y, T, Z
+  const int gsel = role <= 1 ? 0 : (role == 2 ? 3 : 2);  // second field: X, X, -, Z
+  const int osel = role == 0 ? 3 : (role == 1 ? 1 : (role == 2 ? 0 : 2));  // coordinate this lane produces: T, Y, X, Z
+  int top = 128;
+  while (top > 1 && (size_t)top >= n) top >>= 1;  // no levels that would only add identities
+  for (int s = top; s > 0; s >>= 1) {
+    for (int base = 0; base < s; base += 64) {
+      const int q = base + (t >> 2);
+      const bool act = q < s && (size_t)(q + s) < n;
+      if (act) {  // whole quads are active or not
+        Fe10* P = reinterpret_cast<Fe10*>(sm + q);
+        const Fe10* Q = reinterpret_cast<const Fe10*>(sm + q + s);
+        Fe10 f1 = P[fsel], g1 = P[gsel], f2 = Q[fsel], g2 = Q[gsel];
+        // role 0: f - g | role 1: f + g | role 2: f (T) | role 3: P: Z + Z, Q: Z
+        g1 = fe10_pick(g1, fe10_neg(g1), role == 0);
+        g1 = fe10_pick(g1, zero, role == 2);
+        g2 = fe10_pick(g2, fe10_neg(g2), role == 0);
+        g2 = fe10_pick(g2, zero, role >= 2);
+        Fe10 u = fe10_add(f1, g1), v = fe10_add(f2, g2);
+        Fe10 mine = fe10_mul(u, fe10_mul(v, k2d));               // A | B | C | D
+        Fe10 other = fe10_quad_perm_1032(mine);                    // B | A | D | C
+        Fe10 val = (role & 1) ? fe10_add(mine, other) : fe10_sub(other, mine);  // E | H | F | G
+        Fe10 fac = fe10_quad_perm_1302(val);                       // H | G | E | F
+        P[osel] = fe10_mul(val, fac);                              // T3 = E H | Y3 = H G | X3 = F E | Z3 = G F
+      }
+    }
+    if (s > 16) __syncthreads();  // the next level pairs points written by other wavefronts (additions q and q + s/2 sit 4 s/2 >= 64 lanes apart)
+  }
+  __syncthreads();  // sm[0] is the sum for every thread of the block
+}
+#endif
 
 // Latency path, fused form (rows <= SP_HOST_ENCODE_ROWS): grid (nblk, rows). Thread p of a row looks up the table entry
 // of its (column, window) pair and the block sums its 256 entries in an LDS tree, so a Sigma-protocol commitment is ONE
@@ -893,37 +1121,45 @@ struct GensCacheEntry {
 static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
 
-// Window width of a generator set. The table of a set is n points x ceil(254/c) windows x 2^(c-1) entries x 96 B; wider
-// windows mean fewer mixed additions per committed scalar (17 at 15 bits, 19 at 14, 20 at 13) and every LAUNCH is shortest at
-// the widest width — but the PROOF is not: the gathers of a 110 GB table set miss L2 94 % of the time and slow the
-// latency-bound kernels that run next to a background commit ("the derefs window"); swept at 2^20
-// (profiles/r2_window_width_sweep.txt) the proof is fastest with 14 bits for the 4098-point evaluation stream (61 GB) and
-// 15 bits for the 1025-point one (27 GB). So the width is chosen by proof time, not by launch time:
-//   * 15 bits while the set's table stays under SPARTAN_MSM_WIDE_GB (default 64: the 2049-point stream of a 2^22 instance, 55 GB, keeps them —
-//     72.7 -> 71.3 ms per proof — the 4098-point one of 2^20, 110 GB, does not),
-//   * otherwise the widest of 14/13/12/10/8 that fits the budget SPARTAN_MSM_TABLE_GB (default 128 per set),
+// Window width of a generator set. The table of a set is n points x ceil(254/c) windows x 2^(c-1) entries x 128 B (96 bytes of values
+// per 128-byte line, curve.hpp); wider windows mean fewer mixed additions per committed scalar (17 at 15 bits, 19 at 14, 20 at 13) and
+// every LAUNCH is shortest at the widest width — the PROOF is not necessarily: swept at 2^20 (profiles/r2_window_width_sweep.txt, and
+// again in round 4 with line-aligned entries) 15 bits for the 1025-point stream and 14 bits for the 4098-point one tie with 15 / 15 and
+// hold 65 GB less. So the width is chosen by proof time, not by launch time:
+//   * 15 bits while the set's table stays under SPARTAN_MSM_WIDE_GB (default 80: the 2049-point stream of a 2^22 instance, 73 GB, keeps
+//     them, the 4098-point one of 2^20, 146 GB, does not),
+//   * otherwise the widest of 14/13/12/10/8 that fits the budget SPARTAN_MSM_TABLE_GB (default 170 per set: the 8194-point stream of a 2^22
+//     instance at 14 bits is 163 GB),
 //   * and never more than the free device memory less a reserve for the proof's own tables (24 GB, applied only to
 //     tables that are themselves large: a 1.5 MB table set must not be refused because another process holds the HBM).
-// 2^22: 15 / 14 bits (55 + 122 GB); 2^24: 14 / 12 bits. SPARTAN_MSM_WBITS forces a width (the tests use it to cover several).
-// Returns 0 when not even 8-bit tables fit in free memory.
+// 2^20: 15 / 14 bits (36.5 + 81.6 GB); 2^22: 15 / 14 (73 + 163 GB of the 288); 2^24: 14 / 12. SPARTAN_MSM_WBITS forces a width (the tests
+// use it to cover several). A width below the first choice is reported on stderr (once per set): a silent narrowing would be a
+// performance cliff nobody sees. Returns 0 when not even 8-bit tables fit in free memory.
 static int choose_wbits(size_t n) {
   if (const char* e = getenv("SPARTAN_MSM_WBITS")) {
     int v = atoi(e);
     if (v >= 4 && v <= 15) return v;
   }
-  double budget = 128.0, wide = 64.0;
+  double budget = 170.0, wide = 80.0;
   if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }
   if (const char* e = getenv("SPARTAN_MSM_WIDE_GB")) { double v = atof(e); if (v > 0) wide = v; }
   size_t free_b = 0, total_b = 0;
   double free_gb = 1e9;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) free_gb = (double)free_b / 1e9;
+  int first_choice = 0;  // what the policy picks when memory is no object
   for (int cbits : {15, 14, 13, 12, 10, 8}) {
     MsmGeom g = msm_geom(cbits);
     double gb = (double)n * (double)g.pt_entries * sizeof(Niels) / 1e9;
     if (cbits == 15 && gb > wide) continue;
     if (gb > budget) continue;
+    if (!first_choice) first_choice = cbits;
     double reserve = gb >= 1.0 ? 24.0 : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
-    if (gb + reserve <= free_gb || (cbits == 8 && gb * 1.05 <= free_gb)) return cbits;
+    if (gb + reserve <= free_gb || (cbits == 8 && gb * 1.05 <= free_gb)) {
+      if (cbits < first_choice)
+        fprintf(stderr, "spartan_hip: window tables of %zu generators narrowed from %d to %d bits (%.1f GB of device memory free): %d instead of %d additions per scalar\n",
+                n, first_choice, cbits, free_gb, msm_geom(cbits).nwin, msm_geom(first_choice).nwin);
+      return cbits;
+    }
   }
   return 0;
 }
@@ -1024,10 +1260,26 @@ constexpr size_t SP_HOST_ENCODE_ROWS = 8;  // commitments of up to this many row
 // MSM launch plan: kernel shapes and scratch sizes for a (rows x cols) fixed-base commit
 struct MsmPlan {
   bool windowed, two_pass;
+  int flat;  // 0: strip form; 1 / 2: balanced form (k_msm_flat<0> / <1>), P = runs per row
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
-static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_blinds) {
+// workgroups of 256 threads the chip holds at once for the balanced row MSM (occupancy of the kernel x CUs), per device
+static size_t msm_flat_slots(int pipe) {
+  static size_t slots[2] = {0, 0};
+  if (!slots[pipe]) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 768;
+    hipError_t e = pipe ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<1>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 3;
+    slots[pipe] = (size_t)per_cu * (size_t)prop.multiProcessorCount;
+  }
+  return slots[pipe];
+}
+static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t bg_subblocks = 0 /* background launch: 256-thread tiles it runs at once */,
+                        size_t launch_rows = 0 /* rows per launch when the commit is issued in row chunks (sp_commit_rows_upload_start) */) {
   MsmPlan m;
+  m.flat = 0;
   const size_t NWIN = (size_t)g->geom.nwin;
   size_t total = rows * cols, ncol = cols + (has_blinds ? 1 : 0);
   m.windowed = rows * ncol * NWIN <= ((size_t)1 << 19);  // latency-bound shapes: one addition per thread
@@ -1041,6 +1293,21 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
     if (m.strip > cols) m.strip = cols;
     m.nstrips = (cols + m.strip - 1) / m.strip;
     m.P = m.nstrips;
+    // balanced form (A/B switch SPARTAN_MSM_FLAT: 0 = strip form, 1 = one entry in flight, 2 = two, the default)
+    static const int flat_mode = [] { const char* e = getenv("SPARTAN_MSM_FLAT"); int v = e ? atoi(e) : 2; return v >= 0 && v <= 2 ? v : 2; }();
+    if (launch_rows == 0) launch_rows = rows;
+    // the background launch keeps the strip form by default: its balanced form finishes a 768 x 4096 commit in 4.7 instead of 5.8 ms on 5/8 of
+    // the chip, and the latency-bound kernels next to it (second sum-check, witness opening) then run 2x slower instead of 1.3x — the
+    // proof loses more than the commit gains (profiles/r4_ab_msm_forms.txt); SPARTAN_MSM_FLAT_BG=1 selects it
+    static const bool flat_bg = [] { const char* e = getenv("SPARTAN_MSM_FLAT_BG"); return e && atoi(e) != 0; }();
+    if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && (!bg_subblocks || flat_bg)) {
+      const size_t rb = launch_rows / 256, units = ncol * NWIN;
+      size_t slots = bg_subblocks ? bg_subblocks : msm_flat_slots(flat_mode == 2 ? 1 : 0);
+      static const size_t rounds = [] { const char* e = getenv("SPARTAN_MSM_FLAT_ROUNDS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)1; }();
+      size_t nb = slots * rounds / rb;          // runs per row: the launch is `rounds` full sets of resident workgroups
+      if (nb > units / 4) nb = units / 4;       // at least four additions per thread
+      if (nb >= 1) { m.flat = bg_subblocks ? 1 : flat_mode; m.P = nb; }
+    }
   }
   m.chunk = 1024; m.nchunks = (m.P + m.chunk - 1) / m.chunk;
   m.two_pass = m.P > 2048;
@@ -1077,7 +1344,16 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * g->geom.nwin, shape);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
-    if (st != c->stream && !didx && !dblinds && c->bg_blocks > 0) {
+    if (m.flat) {
+      MsmFlatArgs A{dZ, z_stride, rows, cols, (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, (unsigned)m.P, (unsigned)(rows / 256), g->geom};
+      const unsigned ntiles = A.nb * A.rb_count;
+      if (st != c->stream && c->bg_blocks > 0)
+        hipLaunchKernelGGL(k_msm_flat_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, A, ntiles);
+      else if (m.flat == 2)
+        hipLaunchKernelGGL(k_msm_flat<2>, dim3(ntiles), dim3(256), 0, st, A);
+      else
+        hipLaunchKernelGGL(k_msm_flat<1>, dim3(ntiles), dim3(256), 0, st, A);
+    } else if (st != c->stream && !didx && !dblinds && c->bg_blocks > 0) {
       hipLaunchKernelGGL(k_msm_rows_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
                          (const Niels*)g->table, g_off, partial, xcd_map, nblocks, g->geom);
     } else {
@@ -1187,7 +1463,7 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
                                  sp_job** out) {
   if (!c || !g || !Z || !out || rows == 0 || cols == 0 || g_off + cols > g->n || z_off + rows * cols > Z->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  MsmPlan m = msm_plan(g, rows, cols, false);
+  MsmPlan m = msm_plan(g, rows, cols, false, c->bg_blocks > 0 ? (size_t)c->bg_blocks * 4 : 0);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream_bg;
@@ -1254,9 +1530,9 @@ int32_t sp_commit_rows_upload_start(sp_ctx* c, const sp_gens* g, size_t g_off, s
       z_off + rows * cols > Z->cap)
     return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr);
   static const size_t nch = [] { const char* e = getenv("SPARTAN_UPLOAD_CHUNKS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)4; }();
   static const bool chunked_on = getenv("SPARTAN_NO_UPLOAD_OVERLAP") == nullptr;  // A/B switch
+  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, chunked_on && rows % (256 * nch) == 0 ? rows / nch : 0);
   if (!chunked_on || m.windowed || rows % (256 * nch) != 0) {
     HIPCHK(hipMemcpyAsync(Z->d + z_off, src, 32 * rows * cols, hipMemcpyHostToDevice, c->stream));
     return sp_commit_rows_dev_start(c, g, g_off, h_idx, Z, z_off, rows, cols, blinds, out);

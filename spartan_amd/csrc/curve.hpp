@@ -25,11 +25,16 @@ struct Pt {  // extended coordinates: x = X/Z, y = Y/Z, T = XY/Z
   Fp X, Y, Z, T;
 };
 #ifndef SP_NIELS_ALIGN
-#define SP_NIELS_ALIGN 32
+#define SP_NIELS_ALIGN 128
 #endif
-// affine point prepared for mixed addition: 96 B. SP_NIELS_ALIGN=128 pads an entry to one 128-byte line — measured at 2^20 with 15-bit
-// windows: the 4098-point stream's launches 3.05 -> 3.45 ms and 5.48 -> 6.10 ms (tables 110 -> 146 GB), the 1025-point stream's unchanged:
-// the gathers pay for the size of the table set (address translation, DRAM pages), not for the sectors an entry straddles
+// affine point prepared for mixed addition: 96 bytes of values in a 128-byte slot, so that a table gather touches exactly ONE 128-byte
+// line. Packed at a 96-byte stride (rounds 1-3; -DSP_NIELS_ALIGN=32 rebuilds that layout) half of the entries straddle two lines.
+// Measured in round 4 (bench/gather_probe.hip, profiles/r4_gather_probe.txt: the MSM's access pattern with no arithmetic behind it): 23.5-27.3 G
+// entries/s packed against 30.4-33.6 G/s line-aligned, at every table size from 8 to 110 GB (the size of the table set does not matter;
+// only a 0.2 GB table, resident in the Infinity Cache, is faster); the 1280 x 4096 launch 6.06 -> 5.61 ms at 14-bit windows, 5.99 -> 5.32 at
+// 15; a 2^20 proof 26.3 -> 25.2 ms in the same session (fewer line requests per addition also means less pressure on the latency-bound
+// kernels that run next to the background commit). Round 2 had measured the opposite (3.05 -> 3.45 ms) with a struct copy that moved
+// the 32 bytes of padding through the registers as well: msm_load (msm.hpp) reads the three fields.
 struct alignas(SP_NIELS_ALIGN) Niels {
   Fp yp, ym, t2d;  // y+x, y-x, 2*d*x*y
 };

@@ -94,6 +94,16 @@ SP_HD Niels msm_entry_niels(const MsmEntry& e) {
 typedef Niels MsmEntry;
 SP_HD const Niels& msm_entry_niels(const MsmEntry& e) { return e; }
 #endif
+// the 96 bytes of an entry, field by field (with SP_NIELS_ALIGN=128 a struct copy would also move the 32 bytes of padding)
+SP_HD MsmEntry msm_load(const MsmEntry* p) {
+#ifdef SP_EXP_E64
+  return *p;
+#else
+  MsmEntry e;
+  e.yp = p->yp; e.ym = p->ym; e.t2d = p->t2d;
+  return e;
+#endif
+}
 template <bool PF2>
 SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) {
   if (fq_is_zero(s_mont)) return;
@@ -108,7 +118,7 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
   d -= carry << c;
   uint32_t m = (uint32_t)(d < 0 ? -d : d);
   bool ng = d < 0;
-  MsmEntry cur = base[m ? m - 1 : 0];
+  MsmEntry cur = msm_load(base + (m ? m - 1 : 0));
   if (PF2) {
   // two table entries in flight (PMC: waves of the row MSM wait on memory 43 % of their cycles at every window width — the gathers
   // are latency-, not bandwidth- or translation-bound: profiles/r3_pmc_msm_translation_fabric.txt)
@@ -124,14 +134,14 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
   };
   int d1; uint32_t m1;
   next_digit(d1, m1);
-  MsmEntry nx1 = base[(size_t)(g.nwin > 1 ? 1 : 0) * g.tent + (m1 ? m1 - 1 : 0)];
+  MsmEntry nx1 = msm_load(base + (size_t)(g.nwin > 1 ? 1 : 0) * g.tent + (m1 ? m1 - 1 : 0));
   bool ng1 = d1 < 0;
 #pragma unroll 1
   for (int w = 0; w < g.nwin; w++) {
     int d2; uint32_t m2;
     next_digit(d2, m2);  // window w + 2 (zero past the top: s < 2^253)
     int w2 = (w + 2 < g.nwin) ? w + 2 : g.nwin - 1;
-    MsmEntry nx2 = base[(size_t)w2 * g.tent + (m2 ? m2 - 1 : 0)];
+    MsmEntry nx2 = msm_load(base + (size_t)w2 * g.tent + (m2 ? m2 - 1 : 0));
     if (m != 0) acc = pt_madd(acc, msm_entry_niels(cur), ng);
     cur = nx1; m = m1; ng = ng1;
     nx1 = nx2; m1 = m2; ng1 = d2 < 0;
@@ -148,7 +158,7 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
     dn -= carry << c;
     uint32_t mn = (uint32_t)(dn < 0 ? -dn : dn);
     int wn = (w + 1 < g.nwin) ? w + 1 : w;
-    MsmEntry nxt = base[(size_t)wn * g.tent + (mn ? mn - 1 : 0)];
+    MsmEntry nxt = msm_load(base + (size_t)wn * g.tent + (mn ? mn - 1 : 0));
     if (m != 0) acc = pt_madd(acc, msm_entry_niels(cur), ng);
     cur = nxt;
     m = mn;

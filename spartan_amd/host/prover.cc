@@ -911,7 +911,7 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
   size_t Ls = pow2(r.size() / 2), Rs = pow2(r.size() - r.size() / 2);
   REQUIRE(poly.len() == Ls * Rs);
   std::vector<sp_ctx*> shards = residue_shard_ctxs(c);
-  const bool shard_bound = shards.size() >= 2 && Ls % shards.size() == 0 && !getenv("SPARTAN_NO_RESIDUE_SHARDS");
+  const bool shard_bound = shards.size() >= 2 && Ls % shards.size() == 0 && !commit_shard_residue_off(c);
   FqVec Lv;  // the chi vector of the left half on the host: only the blinded opening and the sharded product need it here
   if (blinds_opt || shard_bound) Lv = eq_evals_host(FqVec(r.begin(), r.begin() + r.size() / 2));
   sp_table* lz = nullptr;
@@ -1077,7 +1077,7 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   {
     std::vector<sp_ctx*> shards = residue_shard_ctxs(c);
     size_t W = shards.size(), lw = W >= 2 ? log_2(W) : 0;
-    if (W >= 2 && ry1.size() > lw + 1 && !getenv("SPARTAN_NO_RESIDUE_SHARDS")) {
+    if (W >= 2 && ry1.size() > lw + 1 && !commit_shard_residue_off(c)) {
       // DensePolynomial::evaluate as W partial dot products over contiguous chunks (chunk g = the top log2 W index
       // bits): <Z, chi(r)> = sum_g chi_g(r[..lw]) <Z_g, chi(r[lw..])>, one scalar per shard gathered and combined here
       SPX(sp_ctx_sync(c));
