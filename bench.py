@@ -76,9 +76,12 @@ PUBLISHED_CPU_CPS = 26797.0  # README.md:375: SNARK::prove 2^20 in 39.130 s on o
 README_US_PER_SCALAR = {"polycommit": 2.59, "commit_nondet_witness": 1.72}  # README.md:354,367 (2^20 and 2^23 committed scalars)
 
 
-def cpu_baseline(log2_cons, threads=1):
-    """The oracle (CPU restatement of the reference prover, oracle/) timed on this box's host cores on a bounded
-    sample of the same workload: SNARK::prove at 2^log2_cons constraints. Checker-side only; never the product path."""
+def cpu_baseline(log2_cons, threads=1, want_digest=False):
+    """The oracle (CPU restatement of the reference prover, oracle/) timed on this box's host cores: SNARK::prove at 2^log2_cons
+    constraints on `threads` OpenMP threads (the reference's `multicore` feature parallelises the same loops: dense_mlpoly.rs:148-162).
+    Checker-side only; never the product path. want_digest: also return the SHA-256 of the oracle's proof bytes (same instance seed 0 and
+    tape seed 100 as the GPU proof of rank 0), so that the timed GPU proof is compared with an oracle proof computed IN THIS RUN."""
+    import hashlib
     from tests import helpers as H
     orc = H.load_oracle()
     N = 1 << log2_cons
@@ -87,11 +90,15 @@ def cpu_baseline(log2_cons, threads=1):
     g = H.vp(orc.orc_snark_gens_new(H.sz(N), H.sz(N), H.sz(10), H.sz(N)))
     e = H.vp(orc.orc_snark_encode(inst, g))
     seed = (ctypes.c_uint64 * 4)()
-    orc.orc_seed_scalar(b"tape", ctypes.c_uint64(0), seed)
+    orc.orc_seed_scalar(b"tape", ctypes.c_uint64(100 if want_digest else 0), seed)
     tm = (ctypes.c_double * 10)()
     t0 = time.time()
     p = H.vp(orc.orc_snark_prove(inst, g, e, b"snark_example", seed, tm))
     dt = time.time() - t0
+    digest = None
+    if want_digest:
+        n = orc.orc_proof_bytes(p, None, H.sz(0)); b = (ctypes.c_uint8 * n)(); orc.orc_proof_bytes(p, b, H.sz(n))
+        digest = hashlib.sha256(bytes(b)).hexdigest()
     orc.orc_proof_free(p); orc.orc_encode_free(e); orc.orc_snark_gens_free(g); orc.orc_instance_free(inst)
     orc.orc_set_threads(ctypes.c_int(1))
     model = ""
@@ -104,17 +111,10 @@ def cpu_baseline(log2_cons, threads=1):
         pass
     out = {"value": N / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
            "sample": f"oracle SNARK::prove, produce_synthetic_r1cs 2^{log2_cons}, {dt:.2f} s on {threads} thread(s) of {model} ({os.cpu_count()} logical cores)"}
-    # the oracle's MSM next to the README's dalek figures: 2^s scalars in polycommit, 8 * 2^s in the derefs commitment
-    # the same oracle at the metric's own size (2^20), timed once off-line: profiles/oracle_snark_2p20_timing.py
-    try:
-        ft = json.load(open(os.path.join(ROOT, "profiles", "r3_oracle_snark_2p20_timing.json")))
-        one = [r for r in ft["runs"] if r["threads"] == 1][0]
-        out["at_metric_size"] = {"log2_cons": 20, "seconds": one["seconds"], "constraints_per_s": one["constraints_per_s"], "threads": 1, "cpu": ft["cpu_model"],
-                                 "proof_sha256": one["proof_sha256"], "source": "profiles/r3_oracle_snark_2p20_timing.json (build container, not this box)"}
-    except (OSError, KeyError, IndexError, ValueError):
-        pass
+    if digest:
+        out["proof_sha256"] = digest
     if tm[0] > 0 and tm[6] > 0:
-        out["us_per_scalar"] = {"polycommit": tm[0] / N * 1e6, "commit_nondet_witness": tm[6] / (8 * N) * 1e6, "readme_i7_1065G7": README_US_PER_SCALAR}
+        out["us_per_scalar"] = {"polycommit": tm[0] / N * 1e6, "commit_nondet_witness": tm[6] / (8 * N) * 1e6, "readme_i7_1065G7": README_US_PER_SCALAR, "threads": threads}
     return out
 
 
@@ -129,6 +129,21 @@ def measured_ceilings():
         out = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()
         return json.loads(out[-1])
     except Exception:  # noqa: BLE001  (no ceilings is reported as null, never guessed)
+        return None
+
+
+def gather_ceiling(table_gb, sub_entries, stride):
+    """Gather ceiling of the row MSM's access pattern on this GPU (bench/gather_probe --json, ~2 s): 96-byte table entries at the table's
+    stride, 64 lanes per (point, window) sub-table, 3 waves per SIMD, no arithmetic. table_gb / sub_entries: the two generator streams."""
+    exe = os.path.join(ROOT, "bench", "gather_probe")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    try:
+        cmd = [exe, "--json", str(stride), "%.1f" % table_gb[0], str(sub_entries[0]), "%.1f" % table_gb[1], str(sub_entries[1])]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=180).stdout.strip().splitlines()
+        return json.loads(out[-1])
+    except Exception:  # noqa: BLE001
         return None
 
 
@@ -246,7 +261,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-cons", type=int, default=20, help="log2 of num_cons = num_vars = num_nz_entries (BASELINE: 20)")
-    ap.add_argument("--cpu-log2-cons", type=int, default=17, help="size of the bounded CPU-baseline sample (2^17: ~15 s of one core)")
+    ap.add_argument("--cpu-log2-cons", type=int, default=20, help="largest size the CPU baseline (oracle, all cores) is run at; at or below it the baseline runs at the metric's own size and its proof is compared with the GPU's")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="OpenMP threads of the all-cores CPU baseline (capped by the logical cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-metrics", action="store_true", help="skip the NIZK::prove / SNARK::encode side measurements")
     ap.add_argument("--concurrent", type=int, default=2, help="also measure K independent proofs in flight on the GPU (0 = skip); reported separately, never as `value`")
@@ -309,6 +325,13 @@ def main():
     proof = None
     raw = ctx.raw()
     ceil = measured_ceilings() if rank == 0 else None
+    gath = None
+    if rank == 0 and not os.environ.get("BENCH_NO_GATHER_PROBE"):
+        wb = [gens.window_bits(0), gens.window_bits(1)]
+        # entries per (point, window) sub-table = 2^(c-1); the stride of a table entry follows from the table's size
+        ent = [(len(gens.stream(k)) // 32) * (-(-254 // wb[k])) * (1 << (wb[k] - 1)) for k in (0, 1)]
+        stride = int(round(gens.table_bytes(0) / ent[0])) if ent[0] else 128
+        gath = gather_ceiling([gens.table_bytes(0) / 1e9, gens.table_bytes(1) / 1e9], [1 << (wb[0] - 1), 1 << (wb[1] - 1)], stride)
     if sharded:
         proof = step()  # unsharded bytes: every sharded proof below must equal them
         shard_transport = enable_sharding(P, ctx, dist, rank, world)
@@ -392,6 +415,7 @@ def main():
             named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, SPARTAN_BG_EIGHTHS/8 of the CUs)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, True)] = ("derefs commit, column half (+ zero padding rows; background stream behind the row half)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (+ zero padding rows)", 3 * N, True)
+            named[((6 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (the zero padding rows of the merged polynomial are not launched)", 3 * N, True)
         alu_shapes = []
         for sh in shapes:
             nm = named.get((sh["rows"], sh["cols"], sh["background"]))
@@ -408,9 +432,20 @@ def main():
                 e["frac"] = round(madds / lms / 1e6 / ceil["pt_madd_G_per_s"], 3)
                 if sh["background"] and e["cu_share"] > 0:
                     e["frac_of_its_cus"] = round(e["frac"] / e["cu_share"], 3)
+                # against the hardware's own multiply-add peak: a mixed addition is 7 F_p multiplications of 72 v_mad_u64_u32 each
+                if ceil.get("v_mad_u64_u32_G_lane_ops_per_s"):
+                    e["v_mad_frac"] = round(madds / lms / 1e6 * 7 * 72 / ceil["v_mad_u64_u32_G_lane_ops_per_s"], 3)
+            if gath:   # one table gather per mixed addition: the pure-gather rate of this table set, same access pattern, no arithmetic
+                gk = gath["b" if nm[2] else "a"]
+                e["gather_ceiling_G_per_s"] = max(gk["inflight1"], gk["inflight2"])
+                e["gather_frac"] = round(madds / lms / 1e6 / e["gather_ceiling_G_per_s"], 3)
             alu_shapes.append(e)
         roofline["alu"] = {"unit": "G mixed additions/s (7 F_p multiplications + 8 additions each)", "ceiling": ceil["pt_madd_G_per_s"] if ceil else None,
-                           "ceiling_source": "bench/ubench_fpmul --json on this GPU, this run: dependent pt_madd chains at full occupancy" if ceil else "bench/ubench_fpmul not built",
+                           "ceiling_at_3_waves_per_simd": ceil.get("pt_madd_G_per_s_3_waves_per_simd") if ceil else None,
+                           "ceiling_source": "bench/ubench_fpmul --json on this GPU, this run: dependent pt_madd chains at full occupancy, and at the row MSM's own occupancy (3 waves per SIMD)" if ceil else "bench/ubench_fpmul not built",
+                           "v_mad_u64_u32_peak_G_lane_ops_per_s": ceil.get("v_mad_u64_u32_G_lane_ops_per_s") if ceil else None,
+                           "gather": gath, "gather_source": "bench/gather_probe --json on this GPU, this run: the row MSM's gathers with no arithmetic behind them (one 96-byte entry per mixed addition)" if gath else "bench/gather_probe not built",
+                           "note": "a launch needs BOTH resources at nearly the same rate (one gather per addition; the two ceilings are within 20 % of each other): `frac` (of the addition ceiling), `gather_frac` and `v_mad_frac` are reported side by side",
                            "additions_per_scalar": {"gens_r1cs_sat": nwin_of[False], "gens_r1cs_eval": nwin_of[True]}, "shapes": alu_shapes,
                            "frac": max([e.get("frac", 0) for e in alu_shapes if "background" not in e["what"]] or [None]),
                            # family-wide: every mixed addition of the step over the CU-time it was given
@@ -460,7 +495,7 @@ def main():
             "roofline": roofline,
             "kernel_ms_per_step": {n: round(v["ms"], 4) for n, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])},
             "gpu_busy_ms_per_step": round(gpu_ms_total, 3),
-            "kernel_ms_note": "per-family totals from one untimed fully-instrumented step; roofline from the timed steps",
+            "kernel_ms_note": "per-family totals from one untimed fully-instrumented step; roofline from the timed steps. Families OVERLAP (the background row-MSM runs under the sum-checks and openings, sparse evaluations on a low-priority stream): the sum exceeds ms_per_step, and event times of kernels that share the chip include what they wait",
             "phases_ms": {k_: round(v * 1e3, 3) for k_, v in phase.items()},
             "us_per_scalar": {"polycommit": round(phase.get("polycommit", 0) / N * 1e6, 5), "commit_nondet_witness": round(phase.get("commit_nondet_witness", 0) / (8 * N) * 1e6, 5),
                               "readme_i7_1065G7_one_core": README_US_PER_SCALAR, "note": "wall time of the phase / committed scalars (2^s and 8 * 2^s, zero padding included as in the README)"},
@@ -483,18 +518,24 @@ def main():
         if world == 1 and not args.no_side_metrics:
             out.update(side_metrics(P, ctx, inst, gens, N, s, tape_seed, max(2, args.steps)))
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(args.cpu_log2_cons)
+            # (1) the oracle at the METRIC'S OWN SIZE on this box, all cores (bounded: ~20-40 s on the GPU box's host): its proof is compared with
+            # the GPU proof timed above — a live check, next to the committed digest
+            nthr = min(os.cpu_count() or 1, args.cpu_threads)
+            cb = cpu_baseline(s if s <= args.cpu_log2_cons else args.cpu_log2_cons, threads=nthr, want_digest=(s <= args.cpu_log2_cons))
+            if "proof_sha256" in cb:
+                out["config"]["matches_oracle_live"] = cb["proof_sha256"] == out["config"]["proof_sha256"]
+                cb["sample"] += "; the oracle's proof of the same instance and tape, computed in this run, " + ("EQUALS" if out["config"]["matches_oracle_live"] else "DIFFERS FROM") + " the GPU proof"
             out["cpu_baseline"] = cb
+            # (2) one core, bounded sample (2^17: ~13 s): the single-thread figure next to the README's
+            one = cpu_baseline(min(s, 17), threads=1)
+            out["cpu_baseline_one_core"] = one
             # when the restatement is slower than the published single-core figure, the published figure is the denominator
-            denom = max(cb["value"], PUBLISHED_CPU_CPS)
+            denom = max(one["value"], PUBLISHED_CPU_CPS)
             out["speedup_vs_cpu_baseline"] = value / denom
-            out["speedup_note"] = ("denominator = published 26 797 constraints/s (README.md:375, one i7-1065G7 core, dalek SIMD): the oracle on this box's core is slower (%.0f c/s)" % cb["value"]
+            out["speedup_note"] = ("denominator = published 26 797 constraints/s (README.md:375, one i7-1065G7 core, dalek SIMD): the oracle on one core of this box is slower (%.0f c/s)" % one["value"]
                                    if denom == PUBLISHED_CPU_CPS else "denominator = the oracle on one core of this box")
-            out["speedup_vs_oracle_one_core_this_box"] = value / cb["value"]
-            # the reference's `multicore` feature parallelises the rows of a commitment (dense_mlpoly.rs:148-162); same sample
-            nthr = min(os.cpu_count() or 1, 32)
-            if nthr > 1:
-                out["cpu_baseline_multicore"] = cpu_baseline(args.cpu_log2_cons, threads=nthr)
+            out["speedup_vs_oracle_one_core_this_box"] = value / one["value"]
+            out["speedup_vs_oracle_all_cores_this_box_same_size"] = value / cb["value"]
         if args.phases:
             print("phases (s):", json.dumps({k_: round(v, 5) for k_, v in phase.items()}), file=sys.stderr)
     else:

@@ -10,7 +10,7 @@
 // (3 = the MSM's occupancy at 164 VGPRs, 4, 8).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 bench/gather_probe.hip -o bench/gather_probe
 // Run:   ./gather_probe            full sweep, human readable
-//        ./gather_probe --json     the two configurations bench.py needs (27 GB / 61 GB, stride 96, 3 waves, 2 in flight), one JSON line
+//        ./gather_probe --json [stride GB_a sub_a GB_b sub_b]   the two table sets of the proof bench.py times, one JSON line
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -116,7 +116,8 @@ int main(int argc, char** argv) {
   // the largest table of the sweep (default 122 GB = the 2^22 instance's evaluation stream; shrunk to what is free)
   double max_gb = 122.0;
   if (const char* e = getenv("GATHER_MAX_GB")) max_gb = atof(e);
-  if (json) max_gb = 61.5;
+  if (json) max_gb = argc > 5 ? atof(argv[5]) + 0.5 : 82.5;
+  if (json && argc > 3 && atof(argv[3]) + 0.5 > max_gb) max_gb = atof(argv[3]) + 0.5;
   if (max_gb * 1e9 > (double)free_b - 8e9) max_gb = ((double)free_b - 8e9) / 1e9;
   const size_t bytes = (size_t)(max_gb * 1e9) & ~(size_t)0xFFFFF;
   uint4* base = nullptr; uint4* out = nullptr;
@@ -125,14 +126,22 @@ int main(int argc, char** argv) {
   CHK(hipMemset(base, 0x5a, bytes));  // touch every page (first-touch mapping) and give the loads non-trivial data
   CHK(hipDeviceSynchronize());
   if (json) {
-    // the MSM's own configuration: 96-byte entries at a 96-byte stride, 3 waves per SIMD, 2 entries in flight; 15-bit windows over 27.4 GB, 14-bit over 61.2 GB
-    Result a = run_any(2, 96, base, (size_t)27.4e9, 16384, 96, 3, ncu, 512, out);
-    Result b = run_any(2, 96, base, (size_t)61.2e9, 8192, 96, 3, ncu, 512, out);
-    Result a4 = run_any(4, 96, base, (size_t)27.4e9, 16384, 96, 3, ncu, 512, out);
-    Result b4 = run_any(4, 96, base, (size_t)61.2e9, 8192, 96, 3, ncu, 512, out);
-    printf("{\"unit\": \"G entries/s (96-byte table entries gathered, no arithmetic)\", \"cus\": %d, \"table27GB_wbits15\": {\"inflight2\": %.2f, \"inflight4\": %.2f, \"line_TBps\": %.3f}, "
-           "\"table61GB_wbits14\": {\"inflight2\": %.2f, \"inflight4\": %.2f, \"line_TBps\": %.3f}}\n",
-           ncu, a.gent_per_s, a4.gent_per_s, a4.line_TBps, b.gent_per_s, b4.gent_per_s, b4.line_TBps);
+    // the MSM's own configuration: ./gather_probe --json [stride table_GB_a sub_entries_a table_GB_b sub_entries_b]
+    // defaults: 96 bytes read per entry at a 128-byte stride, 3 waves per SIMD; 15-bit windows over 36.5 GB, 14-bit over 81.6 GB
+    uint32_t stride = argc > 2 ? (uint32_t)atoi(argv[2]) : 128;
+    double gba = argc > 3 ? atof(argv[3]) : 36.5, gbb = argc > 5 ? atof(argv[5]) : 81.6;
+    uint32_t sea = argc > 4 ? (uint32_t)atoi(argv[4]) : 16384, seb = argc > 6 ? (uint32_t)atoi(argv[6]) : 8192;
+    if (gba * 1e9 > (double)bytes) gba = bytes / 1e9;
+    if (gbb * 1e9 > (double)bytes) gbb = bytes / 1e9;
+    Result a1 = run_any(1, 96, base, (size_t)(gba * 1e9), sea, stride, 3, ncu, 512, out);
+    Result a2 = run_any(2, 96, base, (size_t)(gba * 1e9), sea, stride, 3, ncu, 512, out);
+    Result b1 = run_any(1, 96, base, (size_t)(gbb * 1e9), seb, stride, 3, ncu, 512, out);
+    Result b2 = run_any(2, 96, base, (size_t)(gbb * 1e9), seb, stride, 3, ncu, 512, out);
+    printf("{\"unit\": \"G entries/s (96-byte table entries gathered at a %u-byte stride by 64 lanes per (point, window) sub-table, 3 waves per SIMD, no arithmetic)\", \"cus\": %d, "
+           "\"stride\": %u, \"a\": {\"table_GB\": %.1f, \"sub_entries\": %u, \"inflight1\": %.2f, \"inflight2\": %.2f, \"line_TBps\": %.3f}, "
+           "\"b\": {\"table_GB\": %.1f, \"sub_entries\": %u, \"inflight1\": %.2f, \"inflight2\": %.2f, \"line_TBps\": %.3f}}\n",
+           stride, ncu, stride, gba, sea, a1.gent_per_s, a2.gent_per_s, a1.line_TBps > a2.line_TBps ? a1.line_TBps : a2.line_TBps, gbb, seb, b1.gent_per_s, b2.gent_per_s,
+           b1.line_TBps > b2.line_TBps ? b1.line_TBps : b2.line_TBps);
     return 0;
   }
   printf("# gather_probe on %s, %d CUs, table buffer %.1f GB\n", prop.name, ncu, bytes / 1e9);

@@ -222,6 +222,14 @@ int32_t sp_table_gather(sp_ctx* ctx, sp_table* const* tabs, const size_t* offs, 
  *   sp_table_set_len: the current (bound) length of a table, e.g. W after the W surviving entries of the shards were written back.
  *   sp_table_add_into: dst[k] += src[k] (F_q), equal current lengths. */
 int32_t sp_table_residue_split(sp_ctx* ctx, const sp_table* src, size_t W, size_t g, sp_table** out);
+/* Hand-over of residue-sharded tables (the batched cubic sum-checks of SPARK, src/sumcheck.rs:254-424, sharded like the ZK ones): once the
+ * tables are short enough that a round costs less than the exchange, every shard packs the first `count` entries of its sub-tables —
+ *   sp_tables_pack: out[(t * count + k) * 4 ..] = tabs[t][k], any size (one DMA) —
+ * the buffers are gathered in shard order, and the owner scatters them back into its full tables —
+ *   sp_tables_unpack_residues: tabs[t][k * W + g] = in[((g * ntabs + t) * sub + k) * 4 ..]; every table's current length becomes W * sub
+ *   (<= its capacity; the tables must be distinct). */
+int32_t sp_tables_pack(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, size_t count, uint64_t* out);
+int32_t sp_tables_unpack_residues(sp_ctx* ctx, sp_table* const* tabs, size_t ntabs, size_t W, size_t sub, const uint64_t* in);
 int32_t sp_table_set_len(sp_table* t, size_t len);
 int32_t sp_table_add_into(sp_ctx* ctx, sp_table* dst, const sp_table* src);
 

@@ -226,11 +226,31 @@ impl HashLayerProof {
     let dev = |p: &DensePolynomial| p.dev.as_ref().unwrap().0;
     let ops_tabs: Vec<*mut sp_table> = derefs.row_ops_val.iter().chain(derefs.col_ops_val.iter()).chain(dense.row.ops_addr.iter()).chain(dense.row.read_ts.iter())
       .chain(dense.col.ops_addr.iter()).chain(dense.col.read_ts.iter()).chain(dense.val.iter()).map(dev).collect();
+    // SURVEY 8e (C++ rendering: dot_many_sharded, spark.inc): with W shards, shard g evaluates <chi, T_k> over the contiguous chunk
+    // [g n/W, (g+1) n/W) of every table — views, nothing copied — and the W partial vectors are added (exact F_q sums: same bytes)
+    let dot_many = |chi: *mut sp_table, tabs: &[*mut sp_table], out: &mut [Scalar]| {
+      let ctxs = gpu::shard_ctxs();
+      let (w, n, nt) = (ctxs.len(), unsafe { gpu::sp_table_len(chi) }, tabs.len());
+      if w < 2 || n % w != 0 || n / w < 1024 {
+        gpu::ok(unsafe { gpu::sp_dot_many(gpu::ctx(), chi, tabs.as_ptr(), nt, gpu::limbs_mut(out)) });
+        return;
+      }
+      gpu::ok(unsafe { gpu::sp_ctx_sync(gpu::ctx()) });
+      let per = n / w;
+      let mut all = vec![Scalar::zero(); w * nt];
+      for g in 0..w {
+        let view = |t: *mut sp_table| { let mut v = std::ptr::null_mut(); gpu::ok(unsafe { gpu::sp_table_view(ctxs[g], t, g * per, per, &mut v) }); gpu::Table(v) };
+        let (chi_v, tv): (gpu::Table, Vec<gpu::Table>) = (view(chi), tabs.iter().map(|&t| view(t)).collect());
+        let h: Vec<*mut sp_table> = tv.iter().map(|t| t.0).collect();
+        gpu::ok(unsafe { gpu::sp_dot_many(ctxs[g], chi_v.0, h.as_ptr(), nt, gpu::limbs_mut(&mut all[g * nt..(g + 1) * nt])) });
+      }
+      for k in 0..nt { out[k] = (0..w).map(|g| all[g * nt + k]).sum(); }
+    };
     let mut ev = vec![Scalar::zero(); ops_tabs.len()];
-    gpu::ok(unsafe { gpu::sp_dot_many(gpu::ctx(), chi_ops.0, ops_tabs.as_ptr(), ops_tabs.len(), gpu::limbs_mut(&mut ev)) });
+    dot_many(chi_ops.0, &ops_tabs, &mut ev);
     let mem_tabs = [dev(&dense.row.audit_ts), dev(&dense.col.audit_ts)];
     let mut evm = vec![Scalar::zero(); 2];
-    gpu::ok(unsafe { gpu::sp_dot_many(gpu::ctx(), chi_mem.0, mem_tabs.as_ptr(), 2, gpu::limbs_mut(&mut evm)) });
+    dot_many(chi_mem.0, &mem_tabs, &mut evm);
     let (eval_row_ops_val, eval_col_ops_val) = (ev[0..3].to_vec(), ev[3..6].to_vec());
     // DerefsEvalProof::prove (:124-149) -> prove_single (:79-121): the n-to-1 reduction is O(8) scalars of reference code
     let proof_derefs = DerefsEvalProof::prove(derefs, &eval_row_ops_val, &eval_col_ops_val, rand_ops, &gens.gens_derefs, transcript, random_tape);

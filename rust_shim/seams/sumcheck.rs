@@ -287,6 +287,73 @@ impl ZKSumcheckInstanceProof {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// SURVEY 8e for prove_cubic_batched (C++ rendering: CubicShards, spartan_amd/host/spark.inc): every table of the batch split by index
+// residue over the W shards, the throughput-sized rounds run per shard with the per-instance partial evaluations added here, then
+// every shard packs its sub-tables (sp_tables_pack), the buffers are concatenated in shard order and the owner scatters them back into the
+// full tables (sp_tables_unpack_residues); the latency-sized rounds continue unsharded. LOGIC a maintainer must review (not a mechanical
+// call sequence): the hand-over length, the instance -> sub-table maps, the order of the gathered buffer.
+#[cfg(feature = "gpu")]
+struct CubicShards {
+  ctxs: Vec<*mut gpu::sp_ctx>,
+  full: Vec<*mut sp_table>,                 // every table once: A_i, B_i interleaved, then the distinct C tables
+  sub: Vec<Vec<gpu::Table>>,                // [shard][table of `full`]
+  ia: Vec<usize>, ib: Vec<usize>, ic: Vec<usize>, // per instance: position of its A, B, C in `full`
+  active: bool,
+}
+#[cfg(feature = "gpu")]
+impl CubicShards {
+  fn min_len() -> usize { (2 * gpu::double_round_max_len()).max(64) }
+  fn split(all: &[*mut sp_table], A: &[*mut sp_table], B: &[*mut sp_table], C: &[*mut sp_table]) -> Self {
+    let none = CubicShards { ctxs: Vec::new(), full: Vec::new(), sub: Vec::new(), ia: Vec::new(), ib: Vec::new(), ic: Vec::new(), active: false };
+    let ctxs = gpu::shard_ctxs();
+    let (w, len) = (ctxs.len(), unsafe { gpu::sp_table_len(all[0]) });
+    if w < 2 || (w & (w - 1)) != 0 || len < 4 * Self::min_len() || Self::min_len() / w < 4 { return none; }
+    gpu::ok(unsafe { gpu::sp_ctx_sync(gpu::ctx()) });
+    let pos = |t: *mut sp_table| all.iter().position(|&x| x == t).expect("table of the batch");
+    let sub = (0..w)
+      .map(|g| all.iter().map(|&t| { let mut o = std::ptr::null_mut(); gpu::ok(unsafe { gpu::sp_table_residue_split(ctxs[g], t, w, g, &mut o) }); gpu::Table(o) }).collect())
+      .collect();
+    CubicShards { ctxs, full: all.to_vec(), sub, ia: A.iter().map(|&t| pos(t)).collect(), ib: B.iter().map(|&t| pos(t)).collect(), ic: C.iter().map(|&t| pos(t)).collect(), active: true }
+  }
+  fn sub_len(&self) -> usize { unsafe { gpu::sp_table_len(self.sub[0][0].0) } }
+  fn keep_going(&self) -> bool { self.active && self.sub_len() * self.ctxs.len() / 2 >= Self::min_len() }
+  fn lists(&self, g: usize) -> (Vec<*mut sp_table>, Vec<*mut sp_table>, Vec<*mut sp_table>) {
+    let h = |ix: &Vec<usize>| ix.iter().map(|&k| self.sub[g][k].0).collect::<Vec<_>>();
+    (h(&self.ia), h(&self.ib), h(&self.ic))
+  }
+  fn sum(parts: &[Vec<Scalar>], ev: &mut [Scalar]) { for k in 0..ev.len() { ev[k] = parts.iter().map(|p| p[k]).sum(); } }
+  fn eval(&self, ev: &mut [Scalar]) {
+    let ni = self.ia.len();
+    let mut parts = vec![vec![Scalar::zero(); 3 * ni]; self.ctxs.len()];
+    for g in 0..self.ctxs.len() {
+      let (a, b, c) = self.lists(g);
+      gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(self.ctxs[g], a.as_ptr(), b.as_ptr(), c.as_ptr(), ni, gpu::limbs_mut(&mut parts[g])) });
+    }
+    Self::sum(&parts, ev);
+  }
+  fn bind_eval(&self, r: &Scalar, ev: &mut [Scalar]) {
+    let ni = self.ia.len();
+    let mut parts = vec![vec![Scalar::zero(); 3 * ni]; self.ctxs.len()];
+    for g in 0..self.ctxs.len() {
+      let (a, b, c) = self.lists(g);
+      gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched(self.ctxs[g], a.as_ptr(), b.as_ptr(), c.as_ptr(), ni, gpu::limbs1(r), gpu::limbs_mut(&mut parts[g])) });
+    }
+    Self::sum(&parts, ev);
+  }
+  /// the sub-tables go back into the owner's full tables (current length sub_len * W): in[((g * ntabs + t) * sub + k)]
+  fn hand_back(&mut self) {
+    let (w, sl, nt) = (self.ctxs.len(), self.sub_len(), self.full.len());
+    let mut all = vec![Scalar::zero(); w * nt * sl];
+    for g in 0..w {
+      let h: Vec<*mut sp_table> = self.sub[g].iter().map(|t| t.0).collect();
+      gpu::ok(unsafe { gpu::sp_tables_pack(self.ctxs[g], h.as_ptr(), nt, sl, gpu::limbs_mut(&mut all[g * nt * sl..(g + 1) * nt * sl])) });
+    }
+    gpu::ok(unsafe { gpu::sp_tables_unpack_residues(gpu::ctx(), self.full.as_ptr(), nt, w, sl, gpu::limbs(&all)) });
+    self.sub.clear();
+    self.active = false;
+  }
+}
+
 // SumcheckInstanceProof::prove_cubic_batched (:254-424). comb_func is the cubic product on this path
 // (product_tree.rs:316-318). Long tables: one round per call, the bind at r_j fused with round j+1's evaluations
 // (sp_sumcheck_eval_batched, then sp_sumcheck_bind_eval_batched). Short tables (<= 512 entries: ~290 of the 361 rounds of a 2^20
@@ -474,7 +541,20 @@ impl SumcheckInstanceProof {
       }
     } else {
       // ---- TWO rounds per trip on short tables (the default) ---------------------------------------------------------------
-      if num_rounds > 0 {
+      // the throughput-sized rounds on W residue classes of every table (CubicShards above), until the hand-over length
+      let mut cs = if num_rounds > 0 { CubicShards::split(&all, &A, &B, &C) } else { CubicShards::split(&all[..0], &A[..0], &B[..0], &C[..0]) };
+      if cs.active {
+        cs.eval(&mut ev);
+        evc = combine(&ev);
+        while cs.active {
+          let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+          j += 1;
+          let last = !cs.keep_going();
+          cs.bind_eval(&r_j, &mut ev);
+          evc = combine(&ev);
+          if last { cs.hand_back(); }
+        }
+      } else if num_rounds > 0 {
         let len0 = len_of(A[0]);
         if tail_ok && len0 >= 2 && len0 <= 8 {
           mark(&mut tail);

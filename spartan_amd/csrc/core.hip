@@ -1277,7 +1277,8 @@ static size_t msm_flat_slots(int pipe) {
   return slots[pipe];
 }
 static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t bg_subblocks = 0 /* background launch: 256-thread tiles it runs at once */,
-                        size_t launch_rows = 0 /* rows per launch when the commit is issued in row chunks (sp_commit_rows_upload_start) */) {
+                        size_t launch_rows = 0 /* rows per launch when the commit is issued in row chunks (sp_commit_rows_upload_start) */,
+                        bool shares_chip = false /* a background commit of this context is in flight */) {
   MsmPlan m;
   m.flat = 0;
   const size_t NWIN = (size_t)g->geom.nwin;
@@ -1300,7 +1301,10 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
     // the chip, and the latency-bound kernels next to it (second sum-check, witness opening) then run 2x slower instead of 1.3x — the
     // proof loses more than the commit gains (profiles/r4_ab_msm_forms.txt); SPARTAN_MSM_FLAT_BG=1 selects it
     static const bool flat_bg = [] { const char* e = getenv("SPARTAN_MSM_FLAT_BG"); return e && atoi(e) != 0; }();
-    if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && (!bg_subblocks || flat_bg)) {
+    // a foreground commit that shares the chip with a background one also keeps the strip form: the balanced form is exactly as many
+    // workgroups as an EMPTY chip holds, each as long as the launch — with 5/8 of the CUs taken it would run in three uneven waves of
+    // them (commit_nondet_witness 4.1 -> 4.55 ms), where the strip form's two thousand short workgroups fill whatever is free
+    if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && (bg_subblocks ? flat_bg : !shares_chip)) {
       const size_t rb = launch_rows / 256, units = ncol * NWIN;
       size_t slots = bg_subblocks ? bg_subblocks : msm_flat_slots(flat_mode == 2 ? 1 : 0);
       static const size_t rounds = [] { const char* e = getenv("SPARTAN_MSM_FLAT_ROUNDS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)1; }();
@@ -1392,7 +1396,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride, Pt* points_out) {
   if (idx_row_stride && (!didx || rows > SP_HOST_ENCODE_ROWS)) return SP_EINVAL;
   if (points_out && (rows > SP_HOST_ENCODE_ROWS || c->device_encode)) return SP_EINVAL;  // row sums as points: the few-row path only
-  MsmPlan m = msm_plan(g, rows, cols, dblinds != nullptr);
+  MsmPlan m = msm_plan(g, rows, cols, dblinds != nullptr, 0, 0, c->bg_inflight > 0);
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
   if (rows <= SP_HOST_ENCODE_ROWS) {  // latency path: the device sums, the host core runs the encode chain
@@ -1484,6 +1488,7 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
   (void)hipEventRecord(j->done, c->stream_bg);
   (void)hipEventDestroy(ready);
   if (hipGetLastError() != hipSuccess) { (void)hipEventDestroy(j->done); pool_release(c, j->scratch, j->scratch_bytes); delete j; return SP_EHIP; }
+  c->bg_inflight++;
   *out = j;
   return SP_OK;
 }
@@ -1502,7 +1507,7 @@ int32_t sp_commit_rows_dev_start(sp_ctx* c, const sp_gens* g, size_t g_off, size
     SPCHK(stage_in(c, 0, blinds, 32 * rows));
     dbl = (const Fq*)c->dstage;
   }
-  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr);
+  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, 0, c->bg_inflight > 0);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream;
@@ -1532,7 +1537,7 @@ int32_t sp_commit_rows_upload_start(sp_ctx* c, const sp_gens* g, size_t g_off, s
   HIPCHK(hipSetDevice(c->dev));
   static const size_t nch = [] { const char* e = getenv("SPARTAN_UPLOAD_CHUNKS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)4; }();
   static const bool chunked_on = getenv("SPARTAN_NO_UPLOAD_OVERLAP") == nullptr;  // A/B switch
-  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, chunked_on && rows % (256 * nch) == 0 ? rows / nch : 0);
+  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, chunked_on && rows % (256 * nch) == 0 ? rows / nch : 0, c->bg_inflight > 0);
   if (!chunked_on || m.windowed || rows % (256 * nch) != 0) {
     HIPCHK(hipMemcpyAsync(Z->d + z_off, src, 32 * rows * cols, hipMemcpyHostToDevice, c->stream));
     return sp_commit_rows_dev_start(c, g, g_off, h_idx, Z, z_off, rows, cols, blinds, out);
@@ -1599,6 +1604,7 @@ int32_t sp_job_wait(sp_job* j, uint8_t* out) {
         hipStreamSynchronize(j->stream) != hipSuccess)
       rc = SP_EHIP;
   }
+  if (j->stream == c->stream_bg && c->bg_inflight > 0) c->bg_inflight--;
   // the scratch goes back to the pool, which hands it to main-stream work: make that work wait for the job
   (void)hipStreamWaitEvent(c->stream, j->done, 0);
   (void)hipEventDestroy(j->done);

@@ -741,5 +741,60 @@ int32_t sp_table_add_into(sp_ctx* c, sp_table* dst, const sp_table* src) {
 int32_t sp_table_gather(sp_ctx* c, sp_table* const* tabs, const size_t* offs, size_t ntabs, size_t count, uint64_t* out) {
   return gather_elems(c, tabs, offs, ntabs, count, out);
 }
+// ---- hand-over of residue-sharded sum-check tables (the batched cubic sum-checks of SPARK): when the tables have become short
+// enough that a round costs less than the exchange, every shard packs its sub-tables into one buffer (one DMA), the buffers are gathered
+// (host: in-process for virtual shards, the commit transport between ranks), and the owner scatters them back into the full tables.
+__global__ void __launch_bounds__(256) k_tables_pack(const Fq* const* __restrict__ ptrs, size_t ntabs, size_t count, Fq* __restrict__ out) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntabs * count; t += (size_t)gridDim.x * blockDim.x)
+    st_fq(out + t, ld_fq(ptrs[t / count] + t % count));
+}
+__global__ void __launch_bounds__(256) k_tables_unpack_residues(Fq* const* __restrict__ ptrs, size_t ntabs, size_t W, size_t sub, const Fq* __restrict__ in) {
+  // in[(g * ntabs + t) * sub + k] -> tabs[t][k * W + g]
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < W * ntabs * sub; x += (size_t)gridDim.x * blockDim.x) {
+    size_t k = x % sub, t = (x / sub) % ntabs, g = x / (sub * ntabs);
+    st_fq(ptrs[t] + k * W + g, ld_fq(in + x));
+  }
+}
+int32_t sp_tables_pack(sp_ctx* c, sp_table* const* tabs, size_t ntabs, size_t count, uint64_t* out) {
+  if (!c || !tabs || !out || ntabs == 0 || count == 0) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  std::vector<const Fq*> ptrs(ntabs);
+  for (size_t k = 0; k < ntabs; k++) {
+    if (!tabs[k] || count > tabs[k]->len) return SP_EINVAL;
+    ptrs[k] = tabs[k]->d;
+  }
+  const size_t pb = (8 * ntabs + 255) & ~(size_t)255, db = 32 * ntabs * count;
+  SPCHK(ensure_dstage(c, pb + db));
+  SPCHK(stage_in(c, 0, ptrs.data(), 8 * ntabs));
+  Fq* dout = (Fq*)((uint8_t*)c->dstage + pb);
+  {
+    ProfScope ps(c, PF_MISC, 64.0 * (double)(ntabs * count));
+    hipLaunchKernelGGL(k_tables_pack, dim3((unsigned)grid_for(ntabs * count)), dim3(256), 0, c->stream, (const Fq* const*)c->dstage, ntabs, count, dout);
+  }
+  SPCHK(fetch_out(c, dout, out, db));
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+int32_t sp_tables_unpack_residues(sp_ctx* c, sp_table* const* tabs, size_t ntabs, size_t W, size_t sub, const uint64_t* in) {
+  if (!c || !tabs || !in || ntabs == 0 || W == 0 || sub == 0) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  std::vector<Fq*> ptrs(ntabs);
+  for (size_t k = 0; k < ntabs; k++) {
+    if (!tabs[k] || W * sub > tabs[k]->cap) return SP_EINVAL;
+    for (size_t j = 0; j < k; j++) if (tabs[j] == tabs[k]) return SP_EINVAL;  // every table once
+    ptrs[k] = tabs[k]->d;
+  }
+  const size_t pb = (8 * ntabs + 255) & ~(size_t)255, db = 32 * W * ntabs * sub;
+  SPCHK(ensure_dstage(c, pb + db));
+  SPCHK(stage_in(c, 0, ptrs.data(), 8 * ntabs));
+  SPCHK(stage_in(c, pb, in, db));
+  {
+    ProfScope ps(c, PF_MISC, 64.0 * (double)(W * ntabs * sub));
+    hipLaunchKernelGGL(k_tables_unpack_residues, dim3((unsigned)grid_for(W * ntabs * sub)), dim3(256), 0, c->stream, (Fq* const*)c->dstage, ntabs, W, sub,
+                       (const Fq*)((uint8_t*)c->dstage + pb));
+  }
+  for (size_t k = 0; k < ntabs; k++) tabs[k]->len = W * sub;
+  SPCHK(sync_spin(c));  // the staging buffers are reused by the next call
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
 
 }  // extern "C"

@@ -67,6 +67,7 @@ struct sp_ctx {
   hipStream_t stream_low = nullptr;  // a second low-priority stream: short streaming jobs (sp_sparse_evaluate_begin) that must not queue behind a background MSM
   bool device_encode;     // SPARTAN_DEVICE_ENCODE: small commitments are encoded by the device too (100 us instead of 3 us each)
   int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
+  int bg_inflight = 0;    // background commits queued and not yet collected: while one runs, foreground commits keep the strip form (core.hip, msm_plan)
   size_t bg_lds;          // dynamic LDS each of them claims (a whole CU's)
   // scratch
   void* scratch;

@@ -30,6 +30,10 @@ assert ngot == nref, "sharded NIZK proof differs on rank %d" % rank
 lw = 1
 want_rounds = (s - lw + 1) + (s + 1 - lw + 1)
 assert st["gathers"] >= 2 + want_rounds, (st, want_rounds)
+if os.environ.get("SPARTAN_CUBIC_SHARD_MIN_LEN"):
+    # the batched cubic sum-checks sharded over the two ranks as well (pack -> gather -> scatter hand-over), plus the two chunk-sharded
+    # evaluation batches of the hash layer: strictly more exchanges than the ZK sum-checks alone
+    assert st["gathers"] >= 2 + want_rounds + 2 + 5, (st, want_rounds)
 box = [None, None]
 dist.all_gather_object(box, got)
 assert box[0] == box[1]

@@ -80,14 +80,57 @@ def test_virtual_shards_on_one_gpu_are_byte_identical(s, nshards):
     # exchanges of one proof: the two row-sharded commitments (witness, derefs) + the residue-sharded sum-checks of R1CSProof::prove
     # (one partial-sum gather per round while the shards hold >= 2 entries, one hand-back of the survivors: phase one
     # s - lw + 1, phase two s - lw + 2) + the row-sharded `bound` of the four openings + the chunked evaluate of the witness
+    # + (round 4) the chunk-sharded <chi, T_k> evaluations of HashLayerProof::prove (two exchanges) and the residue-sharded rounds of the
+    # batched cubic sum-checks whose tables are long enough (test_batched_cubic_sumchecks_shard_by_residue counts those exactly)
     lw = nshards.bit_length() - 1
-    assert st["gathers"] == 2 + (s - lw + 1) + (s - lw + 2) + 4 + 1
+    assert st["gathers"] >= 2 + (s - lw + 1) + (s - lw + 2) + 4 + 1 + 2
     assert st["bytes"] > 32 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))
     enc2 = P.SNARK.encode(ctx, inst, gens)    # SNARK::encode's multi_commit shards the same way
     assert enc2.serialize_commitment() == enc.serialize_commitment()
     ctx.set_commit_shard_virtual(1)
     assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
     enc2.free(); enc.free(); gens.free(); inst.free(); ctx.close()
+
+
+@pytest.mark.parametrize("s,nshards,min_len", [(10, 4, 64), (12, 8, 128)])
+def test_batched_cubic_sumchecks_shard_by_residue(s, nshards, min_len):
+    """SURVEY 8e for the phase that dominates the proof (ProductCircuitEvalProofBatched::prove -> prove_cubic_batched, src/product_tree.rs:259-383,
+    src/sumcheck.rs:254-424): every table of a batch split by index residue over W virtual shards, the throughput-sized rounds run per shard
+    with 96 * ninst bytes of partial evaluations exchanged per round, then the sub-tables are packed, gathered and scattered back
+    (sp_tables_pack / sp_tables_unpack_residues) and the latency-sized rounds continue unsharded. SPARTAN_CUBIC_SHARD_MIN_LEN lowers the
+    hand-over length (8192 by default) so that a 2^10 / 2^12 instance has sharded rounds. Bytes must equal the unsharded proof's, and the
+    exchange count must be the formula's."""
+    from spartan_amd import prover as P
+    N = 1 << s
+    ctx = P.Ctx(0)
+    inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
+    gens = P.SNARKGens(ctx, N, N, 10, N)
+    enc = P.SNARK.encode(ctx, inst, gens)
+    tape = P.seed_scalar(b"tape", s)
+    ref = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
+    os.environ["SPARTAN_CUBIC_SHARD_MIN_LEN"] = "1073741824"   # no batched sum-check is long enough: the round-3 exchanges alone
+    try:
+        ctx.set_commit_shard_virtual(nshards)
+        ctx.shard_stats(reset=True)
+        assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
+        base = ctx.shard_stats(reset=True)["gathers"]
+        os.environ["SPARTAN_CUBIC_SHARD_MIN_LEN"] = str(min_len)
+        assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
+        got = ctx.shard_stats(reset=True)["gathers"]
+    finally:
+        del os.environ["SPARTAN_CUBIC_SHARD_MIN_LEN"]
+    # Two product-circuit batches per proof (row/col layers of the ops circuits: leaves 2^s; of the memory circuits: leaves 2^(s+1)); a
+    # layer sum-check over tables of L = 2^k * min_len entries (k >= 2) costs 1 first evaluation + (k + 1) binds + 1 hand-back exchanges
+    def per_circuit(leaves):
+        n, L = 0, leaves // 2
+        while L >= 4 * min_len:
+            n += (L // min_len).bit_length() - 1 + 3
+            L //= 2
+        return n
+    want = per_circuit(N) + per_circuit(2 * N)
+    assert want > 0 and got - base == want, (got, base, want)
+    ctx.set_commit_shard_virtual(1)
+    enc.free(); gens.free(); inst.free(); ctx.close()
 
 
 def test_residue_shards_can_be_switched_off_and_nizk_matches():
@@ -226,7 +269,8 @@ def test_residue_sharded_sumchecks_over_the_process_transport():
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARTAN_RESIDUE_TRANSPORT="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARTAN_RESIDUE_TRANSPORT="1",
+                   SPARTAN_CUBIC_SHARD_MIN_LEN="128")  # (round 4) the batched cubic sum-checks of SPARK and the hash layer's evaluations shard over the two ranks too
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "residue_transport_worker.py"), "12"], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -235,3 +279,27 @@ def test_residue_sharded_sumchecks_over_the_process_transport():
         assert p.returncode == 0, e[-3000:]
         outs.append(o)
     assert "RESIDUE_TRANSPORT_OK" in outs[0]
+
+
+def test_rccl_transport_on_every_visible_gpu():
+    """Armed for the first multi-GPU box (SCALE runs): world = torch.cuda.device_count() lock-step ranks, one GPU each, the library's RCCL
+    transport over xGMI carrying the sharded commitments, the agreed tape seed and — SPARTAN_RESIDUE_TRANSPORT=1, a lowered hand-over length —
+    every residue-sharded sum-check (ZK and batched cubic) and the chunk-sharded evaluations. Skips on a single-GPU box, where the same
+    transport has only ever been driven with a 1-rank communicator (test_rccl_transport_inside_the_library_single_rank)."""
+    import torch
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip("needs >= 2 visible GPUs (one rank per GPU over RCCL)")
+    world = 1 << (world.bit_length() - 1)   # residue classes want a power of two
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARTAN_RESIDUE_TRANSPORT="1",
+                   SPARTAN_CUBIC_SHARD_MIN_LEN="256", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), "14"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    assert "RCCL_MULTI_OK world=%d" % world in outs[0]
