@@ -1304,7 +1304,11 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
     // a foreground commit that shares the chip with a background one also keeps the strip form: the balanced form is exactly as many
     // workgroups as an EMPTY chip holds, each as long as the launch — with 5/8 of the CUs taken it would run in three uneven waves of
     // them (commit_nondet_witness 4.1 -> 4.55 ms), where the strip form's two thousand short workgroups fill whatever is free
-    if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && (bg_subblocks ? flat_bg : !shares_chip)) {
+    // and so does a commit of many row-blocks (SNARK::encode's 4096 x 4096 multi_commit: 16 of them): the balanced form gives every
+    // workgroup the same NUMBER of additions, which is the same TIME only when the scalars are alike — the three row-blocks of `val` are
+    // full-size, the twelve of addresses and timestamps a few bits long, so 144 of the 768 workgroups would do all the work (encode 54 ->
+    // 65 ms); the strip form's two thousand workgroups are handed out as CUs free up
+    if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && launch_rows / 256 <= 4 && (bg_subblocks ? flat_bg : !shares_chip)) {
       const size_t rb = launch_rows / 256, units = ncol * NWIN;
       size_t slots = bg_subblocks ? bg_subblocks : msm_flat_slots(flat_mode == 2 ? 1 : 0);
       static const size_t rounds = [] { const char* e = getenv("SPARTAN_MSM_FLAT_ROUNDS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)1; }();

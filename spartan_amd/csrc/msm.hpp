@@ -140,6 +140,9 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
   for (int w = 0; w < g.nwin; w++) {
     int d2; uint32_t m2;
     next_digit(d2, m2);  // window w + 2 (zero past the top: s < 2^253)
+    // short scalars (SNARK::encode commits addresses and timestamps, a few bits each; sparse_mlpoly.rs:483-503): nothing is left above the
+    // digits in hand — no gathers for the upper windows. (The lanes of a wave are rows of one kind of value, so they leave together.)
+    if ((m | m1 | m2) == 0 && (s.l[0] | s.l[1] | s.l[2] | s.l[3]) == 0 && carry == 0) break;
     int w2 = (w + 2 < g.nwin) ? w + 2 : g.nwin - 1;
     MsmEntry nx2 = msm_load(base + (size_t)w2 * g.tent + (m2 ? m2 - 1 : 0));
     if (m != 0) acc = pt_madd(acc, msm_entry_niels(cur), ng);
@@ -157,6 +160,7 @@ SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__
     carry = dn >= g.tent;
     dn -= carry << c;
     uint32_t mn = (uint32_t)(dn < 0 ? -dn : dn);
+    if ((m | mn) == 0 && (s.l[0] | s.l[1] | s.l[2] | s.l[3]) == 0 && carry == 0) break;  // short scalar: no gathers for the upper windows
     int wn = (w + 1 < g.nwin) ? w + 1 : w;
     MsmEntry nxt = msm_load(base + (size_t)wn * g.tent + (mn ? mn - 1 : 0));
     if (m != 0) acc = pt_madd(acc, msm_entry_niels(cur), ng);
