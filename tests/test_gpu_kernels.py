@@ -393,3 +393,52 @@ def test_dot3_many_matches_reference_arithmetic(ctx):
     for trip in tabs:
         for t in trip:
             t.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SPARTAN_MSM_FLAT": "0"}, {"SPARTAN_MSM_FLAT": "1"}, {"SPARTAN_MSM_FLAT": "2"}, {"SPARTAN_MSM_FLAT": "2", "SPARTAN_MSM_FLAT_BG": "1"},
+                                 {"SPARTAN_MSM_FLAT": "2", "SPARTAN_MSM_WBITS": "13", "SPARTAN_MSM_FLAT_ROUNDS": "3"}])
+def test_row_msm_forms_match_oracle(env):
+    """Every launch form of the fixed-base row MSM (DensePolynomial::commit_inner, src/dense_mlpoly.rs:164-177) against the oracle: the strip
+    form with its short-scalar early exit, the balanced (column, window) form rolled and with two entries in flight, its background
+    variant, another window width with three rounds of workgroups. The form is a per-process choice: tests/msm_forms_worker.py runs in a
+    process of its own per form (11 shapes each: blinds, zero rows, short / high-bit / carry-chain scalars, 1..8 row-blocks)."""
+    import subprocess, sys
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "msm_forms_worker.py"), "7"], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "MSM_FORMS_OK 11" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_tables_pack_and_unpack_residues_round_trip():
+    """sp_table_residue_split -> sp_tables_pack -> sp_tables_unpack_residues is the identity (the hand-over of the residue-sharded batched
+    cubic sum-checks): W sub-tables of each of several tables, packed per shard, concatenated in shard order, scattered back."""
+    from spartan_amd import capi
+    ctx = capi.Ctx(0)
+    rng = random.Random(3)
+    W, n, nt = 4, 1 << 12, 5
+    vals = [fast_scalars(rng, n) for _ in range(nt)]
+    tabs = [capi.Table.upload(ctx, mont_bulk(v), n) for v in vals]
+    sub = n // W
+    buf = (ctypes.c_uint64 * (4 * W * nt * sub))()
+    for g in range(W):
+        subs = []
+        for t in tabs:
+            o = ctypes.c_void_p()
+            assert capi.lib.sp_table_residue_split(ctx.h, t.h, sz(W), sz(g), ctypes.byref(o)) == 0
+            subs.append(o)
+        arr = (ctypes.c_void_p * nt)(*[x.value for x in subs])
+        dst = ctypes.cast(ctypes.addressof(buf) + 32 * g * nt * sub, ctypes.POINTER(ctypes.c_uint64))
+        assert capi.lib.sp_tables_pack(ctx.h, arr, sz(nt), sz(sub), dst) == 0
+        for x in subs:
+            capi.lib.sp_table_free(x)
+    fresh = [capi.Table.upload(ctx, mont_bulk([0] * n), n) for _ in range(nt)]
+    arr = (ctypes.c_void_p * nt)(*[t.h.value if hasattr(t.h, "value") else t.h for t in fresh])
+    assert capi.lib.sp_tables_unpack_residues(ctx.h, arr, sz(nt), sz(W), sz(sub), buf) == 0
+    for t, v in zip(fresh, vals):
+        assert from_mont_bulk(t.download(), n) == v
+    bad = (ctypes.c_void_p * 2)(arr[0], arr[0])
+    assert capi.lib.sp_tables_unpack_residues(ctx.h, bad, sz(2), sz(W), sz(sub), buf) != 0   # every table once
+    for t in tabs + fresh:
+        t.free()
+    ctx.close()
