@@ -288,6 +288,13 @@ void sp_ipa_free(sp_ipa* ipa);
 typedef struct sp_index sp_index; /* device-resident Vec<usize> (AddrTimestamps::ops_addr_usize, sparse_mlpoly.rs:213-219) */
 int32_t sp_index_upload(sp_ctx* ctx, const uint64_t* idx, size_t n, sp_index** out);
 void sp_index_free(sp_index* ix);
+/* SNARK::encode without a host pass over the matrices (lib.rs:325-336 -> sparse_mlpoly.rs:367-427): sp_sparse keeps its entries in the order
+ * they were given (SparseMatPolynomial.M);
+ *   sp_sparse_entry_index: their row (which = 0) or column (which = 1) addresses as a device index list of n >= nnz elements, zero-padded
+ *     (MultiSparseMatPolynomialAsDense pads every matrix to the batch's num_nz_entries) — free with sp_index_free;
+ *   sp_sparse_entry_values: their values written into dst[dst_off, dst_off + n), zero-padded. Device to device, queued on the context's stream. */
+int32_t sp_sparse_entry_index(sp_ctx* ctx, const sp_sparse* m, int which, size_t n, sp_index** out);
+int32_t sp_sparse_entry_values(sp_ctx* ctx, const sp_sparse* m, sp_table* dst, size_t dst_off, size_t n);
 /* AddrTimestamps::new (sparse_mlpoly.rs:221-254) for `nlists` address lists of equal length walked one after the other
  * over ONE array of `cells` counters: read_ts of list k goes to ts_dst[ts_off[k] ..] and the final counters (audit_ts)
  * to audit_dst[audit_off .. audit_off + cells), both as F_q tables. Addresses must be < cells. The sequential scan of

@@ -67,10 +67,9 @@ impl SparseMatPolynomial {
     let side = |is_row: bool, slot0: usize, mem_off: usize| -> AddrTimestamps {
       let (mut usize_lists, mut ops_addr, mut read_ts, mut handles, mut ts_off) = (Vec::new(), Vec::new(), Vec::new(), Vec::new(), [0usize; 3]);
       for (k, p) in sparse_polys.iter().enumerate() {
-        let mut addr = vec![0u64; N];
-        for (i, e) in p.M.iter().enumerate() { addr[i] = if is_row { e.row } else { e.col } as u64; }
+        // the entries' addresses from the entry-order copy sp_sparse keeps on the device (zero-padded to N): no host pass, no upload
         let mut ix = std::ptr::null_mut();
-        gpu::ok(unsafe { gpu::sp_index_upload(c, addr.as_ptr(), N, &mut ix) });
+        gpu::ok(unsafe { gpu::sp_sparse_entry_index(c, p.dev.as_ref().unwrap().0, if is_row { 0 } else { 1 }, N, &mut ix) });
         gpu::ok(unsafe { gpu::sp_table_from_index(c, ix, comb_ops.0, (slot0 + k) * N) }); // DensePolynomial::from_usize (:246-248)
         ops_addr.push(DensePolynomial::from_dev(comb_ops.view((slot0 + k) * N, N)));
         read_ts.push(DensePolynomial::from_dev(comb_ops.view((slot0 + 3 + k) * N, N)));
@@ -85,9 +84,7 @@ impl SparseMatPolynomial {
     let col = side(false, 6, cells);
     let mut val = Vec::new();
     for (k, p) in sparse_polys.iter().enumerate() {
-      let mut v = vec![Scalar::zero(); N];
-      for (i, e) in p.M.iter().enumerate() { v[i] = e.val; }
-      gpu::ok(unsafe { gpu::sp_table_write(c, comb_ops.0, (12 + k) * N, gpu::limbs(&v), N) });
+      gpu::ok(unsafe { gpu::sp_sparse_entry_values(c, p.dev.as_ref().unwrap().0, comb_ops.0, (12 + k) * N, N) });
       val.push(DensePolynomial::from_dev(comb_ops.view((12 + k) * N, N)));
     }
     MultiSparseMatPolynomialAsDense { batch_size: sparse_polys.len(), val, row, col, comb_ops: DensePolynomial::from_dev(comb_ops), comb_mem: DensePolynomial::from_dev(comb_mem) }

@@ -13,6 +13,8 @@ struct sp_sparse {
   Fq* csr_val;
   uint32_t *col_ptr, *csc_row;  // CSC
   Fq* csc_val;
+  uint32_t *ent_row, *ent_col;  // the entries in the order they were given (SparseMatPolynomial.M, sparse_mlpoly.rs:19-38): SNARK::encode's
+  Fq* ent_val;                  // address lists and value vectors are these, zero-padded (sparse_mlpoly.rs:367-427) — no host pass over them
 };
 
 // multiply_vec (sparse_mlpoly.rs:454-464)
@@ -122,14 +124,43 @@ int32_t sp_sparse_upload(sp_ctx* c, const uint64_t* rows, const uint64_t* cols, 
   if ((rc = dev_put(c, &m->row_ptr, ptr)) || (rc = dev_put(c, &m->csr_col, oth)) || (rc = dev_put(c, &m->csr_row, ks)) || (rc = dev_put(c, &m->csr_val, vv))) { sp_sparse_free(m); return rc; }
   build(cols, num_cols, rows, ptr, oth, ks, vv);
   if ((rc = dev_put(c, &m->col_ptr, ptr)) || (rc = dev_put(c, &m->csc_row, oth)) || (rc = dev_put(c, &m->csc_val, vv))) { sp_sparse_free(m); return rc; }
+  {
+    std::vector<uint32_t> er(nnz), ec(nnz);
+    for (size_t i = 0; i < nnz; i++) { er[i] = (uint32_t)rows[i]; ec[i] = (uint32_t)cols[i]; }
+    std::vector<Fq> ev(v, v + nnz);
+    if ((rc = dev_put(c, &m->ent_row, er)) || (rc = dev_put(c, &m->ent_col, ec)) || (rc = dev_put(c, &m->ent_val, ev))) { sp_sparse_free(m); return rc; }
+  }
   *out = m;
+  return SP_OK;
+}
+// SNARK::encode (lib.rs:325-336 -> sparse_mlpoly.rs:367-427): the row / column addresses of a matrix's entries as a device index list of
+// n >= nnz elements (zero-padded: MultiSparseMatPolynomialAsDense pads every matrix to the batch's num_nz_entries), and its values written
+// into dst[dst_off, dst_off + n) — both from the entry-order copies kept at upload, device to device.
+int32_t sp_sparse_entry_index(sp_ctx* c, const sp_sparse* m, int which, size_t n, sp_index** out) {
+  if (!c || !m || !out || (which != 0 && which != 1) || n == 0 || n < m->nnz) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  sp_index* ix = new (std::nothrow) sp_index();
+  if (!ix) return SP_ENOMEM;
+  ix->ctx = c; ix->n = n; ix->d = nullptr;
+  hipError_t e = hipMalloc((void**)&ix->d, 4 * n);
+  if (e == hipSuccess && n > m->nnz) e = hipMemsetAsync(ix->d + m->nnz, 0, 4 * (n - m->nnz), c->stream);
+  if (e == hipSuccess && m->nnz) e = hipMemcpyAsync(ix->d, which == 0 ? m->ent_row : m->ent_col, 4 * m->nnz, hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) { if (ix->d) (void)hipFree(ix->d); delete ix; return e == hipErrorOutOfMemory ? SP_ENOMEM : SP_EHIP; }
+  *out = ix;
+  return SP_OK;
+}
+int32_t sp_sparse_entry_values(sp_ctx* c, const sp_sparse* m, sp_table* dst, size_t dst_off, size_t n) {
+  if (!c || !m || !dst || n < m->nnz || dst_off + n > dst->cap) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  if (n > m->nnz) HIPCHK(hipMemsetAsync(dst->d + dst_off + m->nnz, 0, 32 * (n - m->nnz), c->stream));
+  if (m->nnz) HIPCHK(hipMemcpyAsync(dst->d + dst_off, m->ent_val, 32 * m->nnz, hipMemcpyDeviceToDevice, c->stream));
   return SP_OK;
 }
 void sp_sparse_free(sp_sparse* m) {
   if (!m) return;
   (void)hipSetDevice(m->ctx->dev);
   (void)hipStreamSynchronize(m->ctx->stream);
-  void* ps[] = {m->row_ptr, m->csr_col, m->csr_row, m->csr_val, m->col_ptr, m->csc_row, m->csc_val};
+  void* ps[] = {m->row_ptr, m->csr_col, m->csr_row, m->csr_val, m->col_ptr, m->csc_row, m->csc_val, m->ent_row, m->ent_col, m->ent_val};
   for (void* p : ps)
     if (p) (void)hipFree(p);
   delete m;
