@@ -984,16 +984,26 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
     // next chunk crosses PCIe); otherwise upload, then commit
     const bool upload_commit = async && !vars_resident && nvars_given == num_vars;
     if (!vars_resident && nvars_given && !upload_commit) SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
-    if (upload_commit) SPX(sp_commit_rows_upload_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, vars[0].l, Ls, Rs, U(blinds_vars), &job));
+    // A copy out of pageable memory keeps the calling thread busy until the bytes have left the caller's buffer (0.75 ms for 32 MB), and
+    // the transcript prefix (the computation commitment: 0.65 ms of Keccak at 2^20) needs no device: the upload + commit is issued by a
+    // helper thread while this one hashes; the context is not touched here before the join. SPARTAN_NO_UPLOAD_THREAD=1: one thread (A/B).
+    static const bool upload_thread = getenv("SPARTAN_NO_UPLOAD_THREAD") == nullptr;
+    std::thread uploader;
+    int32_t up_rc = SP_OK;
+    if (upload_commit && upload_thread && transcript_prefix)
+      uploader = std::thread([&] { up_rc = sp_commit_rows_upload_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, vars[0].l, Ls, Rs, U(blinds_vars), &job); });
+    else if (upload_commit) SPX(sp_commit_rows_upload_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, vars[0].l, Ls, Rs, U(blinds_vars), &job));
     else if (async) SPX(sp_commit_rows_dev_start(c, g.g, g.G[0], g.h, poly_vars.h, 0, Ls, Rs, U(blinds_vars), &job));
     try {
       if (transcript_prefix) (*transcript_prefix)();
       t.append_protocol_name("R1CS proof");
       t.append_scalars("input", input);
     } catch (...) {
+      if (uploader.joinable()) uploader.join();
       if (job) { std::vector<uint8_t> sink(32 * Ls); (void)sp_job_wait(job, sink.data()); }
       throw;
     }
+    if (uploader.joinable()) { uploader.join(); SPX(up_rc); }
     if (async) {
       std::vector<uint8_t> out(32 * Ls);
       SPX(sp_job_wait(job, out.data()));
