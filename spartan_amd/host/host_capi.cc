@@ -4,6 +4,7 @@
 #include <string>
 
 #include "libspartan.hpp"
+#include "fq_inv.hpp"
 
 using namespace spz;
 
@@ -142,6 +143,8 @@ int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint
     return -1;
   }
 }
+// test hook: the challenge inversion of the inner-product rounds (fq_inv.hpp), Montgomery limbs in and out
+void spz_fq_invert_vartime(const uint64_t in[4], uint64_t out[4]) { Fq a; memcpy(a.l, in, 32); Fq r = fq_invert_vartime(a); memcpy(out, r.l, 32); }
 void spz_seed_scalar(const char* domain, uint64_t seed, uint64_t out[4]) { Fq s = seed_scalar(domain, seed); memcpy(out, s.l, 32); }
 void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->set_digest(d, n); }
 // zlib header variant of the COMPUTED digest: 0 = 0x78 0x9C (miniz >= 2.2, miniz_oxide >= 0.4: FLEVEL from the level), 1 = 0x78 0x01 (older).

@@ -245,3 +245,19 @@ def test_round_grid_messages_and_contraction():
                 want.append(sum(x * y_ * z for x, y_, z in zip(a, b, c)) % Q)
             assert got[4 * j:4 * j + 4] == want, (k, j)
             cur = [ext(T, [ch[j]]) for T in cur]
+
+
+def test_challenge_inversion_by_division_steps():
+    """fq_inv.hpp: the inner-product rounds invert their (public) challenge with Bernstein-Yang division steps instead of the
+    reference's a^(q-2) chain (scalar/ristretto255.rs:541-595). Same value for every input: edge cases, powers of two (long runs of
+    zero bits exercise the skip-ahead), short and full-length scalars against Python's pow, and 0 -> 0 as the chain gives."""
+    import ctypes, random
+    from spartan_amd import prover
+    rng = random.Random(2024)
+    out = u64x4()
+    vals = [0, 1, 2, 3, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, 2**252, 2**252 - 1, 2**126, 2**62, 2**62 - 1, 2**124 + 1]
+    vals += [2**k for k in range(0, 252, 7)] + [Q - 2**k for k in range(1, 252, 11)]
+    vals += [rng.randrange(Q) for _ in range(3000)] + [rng.randrange(2**k) for k in (8, 31, 62, 63, 64, 65, 124, 130, 200) for _ in range(30)]
+    for a in vals:
+        prover.H.spz_fq_invert_vartime(to_mont_limbs(a), out)
+        assert from_mont_limbs(out) == pow(a, Q - 2, Q), hex(a)
