@@ -26,5 +26,9 @@ int main() {
   uint8_t enc[32];
   unsigned acc = 0;
   printf("pt_compress  %8.1f ns\n", ns_per(100000, [&] { pt_compress(q, enc); acc += enc[0]; q.X.v[0] ^= enc[1]; }));
+  Pt qq[4] = {q, p, pt_add(q, p), pt_add(p, p)};
+  uint8_t enc4[128];
+  for (size_t n = 2; n <= 4; n++)
+    printf("pt_compress_many(%zu) %8.1f ns\n", n, ns_per(100000, [&] { pt_compress_many(qq, n, enc4); acc += enc4[0]; qq[0].X.v[0] ^= enc4[1]; }));
   printf("(%llx %llx %u)\n", (unsigned long long)a.l[0], (unsigned long long)x.v[0], acc);
 }

@@ -1419,9 +1419,10 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
         }
         SPCHK(sig_wait(c, sig));
         if (hipGetLastError() != hipSuccess) return SP_EHIP;
-        const Pt* sums = (const Pt*)hres(c);
+        Pt sums[SP_HOST_ENCODE_ROWS];  // out of the host-mapped page first: the encodes read each coordinate several times
+        memcpy(sums, hres(c), sizeof(Pt) * rows);
         if (points_out) memcpy(points_out, sums, sizeof(Pt) * rows);
-        else for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
+        else pt_compress_many(sums, rows, out_host);
         return SP_OK;
       }
       {
@@ -1453,7 +1454,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
     SPCHK(fetch_small(c, sums, sizeof(Pt) * rows));
     if (hipGetLastError() != hipSuccess) return SP_EHIP;
     if (points_out) memcpy(points_out, sums, sizeof(Pt) * rows);
-    else for (size_t r = 0; r < rows; r++) pt_compress(sums[r], out_host + 32 * r);
+    else pt_compress_many(sums, rows, out_host);
     return SP_OK;
   }
   bool small_out = 32 * rows <= HMAP_SIZE - HMAP_IN;

@@ -611,7 +611,7 @@ int32_t sp_sumcheck_bind_eval_commit(sp_ctx* c, int kind, sp_table* const* tabs,
   if (kind != 0) memcpy(out_evals + 8, e + 8, 32);
   Pt sums[8];
   memcpy(sums, hres(c) + SUMS_OFF, sizeof(Pt) * rows);
-  for (size_t k = 0; k < rows; k++) pt_compress(sums[k], out_points + 32 * k);
+  pt_compress_many(sums, rows, out_points);
   return SP_OK;
 }
 int32_t sp_vecmat(sp_ctx* c, const uint64_t* L, size_t Lsz, const sp_table* Z, uint64_t* out) {

@@ -150,15 +150,20 @@ int32_t sp_host_commit_small(const sp_gens* g, const uint32_t* idx, size_t cols,
   if (!g || !idx || !S || !out || cols == 0 || cols > 16 || rows == 0) return SP_EINVAL;
   auto st = stream_of(g);
   const Niels* tabs[16] = {nullptr};
-  for (size_t r = 0; r < rows; r++) {
-    Pt acc;
-    SPCHK(row_point(g, *st, tabs, idx, cols, S + 4 * r * cols, &acc));
-    if (addend && addend[r]) {
-      Pt a;
-      memcpy(&a, addend[r], sizeof(Pt));
-      acc = pt_add(acc, a);
+  Pt accs[8];  // encoded together, up to four at a time (pt_compress_many: the inverse-square-root chains of a call's rows overlap)
+  for (size_t r0 = 0; r0 < rows; r0 += 8) {
+    const size_t nr = rows - r0 < 8 ? rows - r0 : 8;
+    for (size_t r = r0; r < r0 + nr; r++) {
+      Pt acc;
+      SPCHK(row_point(g, *st, tabs, idx, cols, S + 4 * r * cols, &acc));
+      if (addend && addend[r]) {
+        Pt a;
+        memcpy(&a, addend[r], sizeof(Pt));
+        acc = pt_add(acc, a);
+      }
+      accs[r - r0] = acc;
     }
-    pt_compress(acc, out + 32 * r);
+    pt_compress_many(accs, nr, out + 32 * r0);
   }
   return SP_OK;
 }
@@ -175,15 +180,20 @@ int32_t sp_host_commit_point(const sp_gens* g, const uint32_t* idx, size_t cols,
 // commitment (sp_commit_rows_partial: one set per shard, one more for the blind terms), all on the calling thread.
 int32_t sp_host_points_sum_encode(const sp_host_point* pts, size_t nsets, size_t rows, uint8_t* out) {
   if (!pts || !out || nsets == 0 || rows == 0) return SP_EINVAL;
-  for (size_t r = 0; r < rows; r++) {
-    Pt acc;
-    memcpy(&acc, &pts[r], sizeof(Pt));
-    for (size_t k = 1; k < nsets; k++) {
-      Pt p;
-      memcpy(&p, &pts[k * rows + r], sizeof(Pt));
-      acc = pt_add(acc, p);
+  Pt accs[8];
+  for (size_t r0 = 0; r0 < rows; r0 += 8) {
+    const size_t nr = rows - r0 < 8 ? rows - r0 : 8;
+    for (size_t r = r0; r < r0 + nr; r++) {
+      Pt acc;
+      memcpy(&acc, &pts[r], sizeof(Pt));
+      for (size_t k = 1; k < nsets; k++) {
+        Pt p;
+        memcpy(&p, &pts[k * rows + r], sizeof(Pt));
+        acc = pt_add(acc, p);
+      }
+      accs[r - r0] = acc;
     }
-    pt_compress(acc, out + 32 * r);
+    pt_compress_many(accs, nr, out + 32 * r0);
   }
   return SP_OK;
 }

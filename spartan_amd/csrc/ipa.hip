@@ -346,11 +346,15 @@ static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uin
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
   SPCHK(hrc);
   const Pt* sums = (const Pt*)hres(c);
+  Pt lr[2];
   for (int r = 0; r < 2; r++) {
     Pt tail;
     memcpy(&tail, &tails[r], sizeof(Pt));
-    pt_compress(pt_add(sums[r], tail), r == 0 ? L_out : R_out);
+    lr[r] = pt_add(sums[r], tail);
   }
+  uint8_t enc[64];
+  pt_compress_many(lr, 2, enc);  // L and R together: two interleaved inverse-square-root chains (curve.hpp)
+  memcpy(L_out, enc, 32); memcpy(R_out, enc + 32, 32);
   if (ipa->n_cur >= 4) {
     const Fq* dp = (const Fq*)(hres(c) + 1024);
     for (int k = 0; k < 8; k++) {

@@ -354,6 +354,8 @@ size_t spz_proof_bytes(void* p, uint8_t* out, size_t cap) {
 void spz_proof_free(void* p) { delete (ProofH*)p; }
 
 // host-side Fiat–Shamir pieces exposed for CPU tests (no GPU needed)
+const char* spz_keccak_variant() { return keccak_f1600_variant(); }
+int spz_keccak_run_variant(const char* name, uint64_t state[25]) { return keccak_f1600_run_variant(name, state); }
 void spz_shake256(const uint8_t* in, size_t n, uint8_t* out, size_t outlen) { Shake256 s; s.absorb(in, n); s.squeeze(out, outlen); }
 size_t spz_merlin_script(const char* tlabel, size_t nops, const int* kinds, const char* const* labels, const uint8_t* const* datas, const size_t* lens,
                          uint8_t* out) {

@@ -22,6 +22,8 @@ using sp::Fq;
 // clang's here, and it carries a BMI clone), the rest of the driver with clang++ (whose 4x64 Montgomery code is 1.5-2x
 // faster than g++'s). SPZ_HOSTPROF (diagnostic build) counts and times the calls.
 void keccak_f1600_impl(uint64_t A[25]);
+const char* keccak_f1600_variant();                            // "plain" | "bmi2" | "avx512": the form picked for this CPU (keccak.cc)
+int keccak_f1600_run_variant(const char* name, uint64_t A[25]);  // tests: 0 if this CPU cannot run it
 #ifdef SPZ_HOSTPROF
 struct KeccakProf { uint64_t n = 0; double t = 0; };
 inline KeccakProf& keccak_prof() { static KeccakProf p; return p; }

@@ -43,6 +43,15 @@ int hc_pt_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { Pt p, q; if (!
 // serial-chain (Fe10) forms: add two points and encode through Pt10
 int hc_pt10_add_compress(const uint8_t* a, const uint8_t* b, uint8_t* out) { Pt p, q; if (!pt_decompress(a, &p) || !pt_decompress(b, &q)) return 0; pt10_compress(pt10_add(pt10_load(p), pt10_load(q)), out); return 1; }
 int hc_pt10_sum_compress(const uint8_t* pts, size_t n, uint8_t* out) { Pt10 acc = pt10_identity(); for (size_t i = 0; i < n; i++) { Pt p; if (!pt_decompress(pts + 32 * i, &p)) return 0; acc = pt10_add(acc, pt10_load(p)); } pt10_compress(acc, out); return 1; }
+// running sums P_i = pts[0] + ... + pts[i] (Z != 1), encoded N at a time (pt_compress_many) into out and one by one into out_single
+int hc_pt_running_sums_compress_many(const uint8_t* pts, size_t n, uint8_t* out, uint8_t* out_single) {
+  if (n == 0 || n > 64) return 0;
+  Pt sums[64], acc = pt_identity();
+  for (size_t i = 0; i < n; i++) { Pt p; if (!pt_decompress(pts + 32 * i, &p)) return 0; acc = pt_add(acc, p); sums[i] = acc; }
+  pt_compress_many(sums, n, out);
+  for (size_t i = 0; i < n; i++) pt_compress(sums[i], out_single + 32 * i);
+  return 1;
+}
 int hc_pt_dbl(const uint8_t* a, uint8_t* out) { Pt p; if (!pt_decompress(a, &p)) return 0; pt_compress(pt_dbl(p), out); return 1; }
 
 // fixed-base table MSM exactly as the device does it: build tables like k_table_build, accumulate like k_msm_rows

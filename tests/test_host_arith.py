@@ -261,3 +261,28 @@ def test_challenge_inversion_by_division_steps():
     for a in vals:
         prover.H.spz_fq_invert_vartime(to_mont_limbs(a), out)
         assert from_mont_limbs(out) == pow(a, Q - 2, Q), hex(a)
+
+
+def test_several_encodes_at_once_equal_single_encodes(hc, orc):
+    """curve.hpp pt_compress_many: the proving thread encodes L and R of an inner-product round, the rows of a few-term commitment
+    call and the <= 8 row sums of a small commitment several at a time (interleaved inverse-square-root chains). Every group size
+    must give the bytes of pt_compress, which test_points_match_oracle ties to the oracle; the running sums have Z != 1 and include
+    the identity and points whose encoding takes the rotated branch."""
+    rng = random.Random(15)
+    o = u8x32()
+    pts = []
+    for _ in range(23):
+        hc.hc_pt_from_uniform(bytes(rng.randrange(256) for _ in range(64)), o)
+        pts.append(bytes(o))
+    pts.insert(3, bytes(32))  # identity as an addend: two equal running sums
+    for n in list(range(1, 12)) + [24]:
+        blob = b"".join(pts[:n])
+        many = (ctypes.c_uint8 * (32 * n))(); single = (ctypes.c_uint8 * (32 * n))()
+        assert hc.hc_pt_running_sums_compress_many(blob, sz(n), many, single) == 1
+        assert bytes(many) == bytes(single), n
+    acc = pts[0]
+    o2 = u8x32()
+    for i in range(1, 6):  # and the running sums themselves against the oracle's additions
+        assert orc.orc_pt_add(acc, pts[i], o2) == 1
+        acc = bytes(o2)
+        assert bytes(many)[32 * i:32 * i + 32] == acc

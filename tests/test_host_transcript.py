@@ -20,6 +20,29 @@ def test_shake256(H):
         assert bytes(out) == hashlib.shake_256(m).digest(500)
 
 
+def test_keccak_variants_agree(H):
+    """keccak.cc compiles the permutation three ways (plain, BMI2, AVX-512 planes) and picks one per CPU by timing them: every form this
+    CPU can run must give the same state as the plain one, and the FIPS 202 zero-state vector."""
+    H.spz_keccak_variant.restype = ctypes.c_char_p
+    assert H.spz_keccak_variant() in (b"plain", b"bmi2", b"avx512")
+    rng = random.Random(3)
+    St = ctypes.c_uint64 * 25
+    z = St()
+    assert H.spz_keccak_run_variant(b"plain", z) == 1
+    assert z[0] == 0xF1258F7940E1DDE7 and z[24] == 0xEAF1FF7B5CECA249  # Keccak-f[1600] of the all-zero state (KeccakF-1600-IntermediateValues)
+    ran = 0
+    for v in (b"bmi2", b"avx512"):
+        for _ in range(200):
+            words = [rng.randrange(2**64) for _ in range(25)]
+            a, b = St(*words), St(*words)
+            H.spz_keccak_run_variant(b"plain", a)
+            if H.spz_keccak_run_variant(v, b) == 0:
+                break  # this CPU cannot run the form
+            assert list(a) == list(b), v
+            ran += 1
+    print("variants checked:", ran)
+
+
 def _script(lib, fn, tlabel, ops):
     n = len(ops)
     kinds = (ctypes.c_int * n)(*[o[0] for o in ops])
