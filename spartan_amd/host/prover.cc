@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -781,6 +782,8 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
     // evaluations and claim = eval)
     UniPoly next_poly;
     std::vector<CP> cm2;
+    bool dpp_early = false;
+    Fq ch_early = fq_zero();
     if (on_host) {
       try {
         FqVec rows2(2 * W, fq_zero());
@@ -789,6 +792,17 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
         const sp_host_point* add2[2] = {nullptr, &ahead.wait(j).rb_h};
         cm2 = commit_rows(rows2, 2, add2);
       } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); rs.drain(); throw; }
+      // the rest of the DotProductProof's transcript work needs nothing from the device: absorbed (and `c` drawn) while the bind and the
+      // next evaluation are still in flight, before they are collected
+      Fq ch;
+      try {
+        t.append_point("Cy", cm2[0].data());
+        t.append_scalars("a", a);
+        t.append_point("delta", delta.data());
+        t.append_point("beta", cm2[1].data());
+        ch = t.challenge_scalar("c");
+      } catch (...) { if (pending && !rs.active) (void)sp_sumcheck_bind_eval_collect(c, ev); rs.drain(); throw; }
+      dpp_early = true; ch_early = ch;
       if (pending && rs.active) rs.bind_eval_collect(kind, ev);
       else if (pending) SPX(sp_sumcheck_bind_eval_collect(c, ev));
       if (resharded && more) { SPX(sp_sumcheck_eval(c, kind, tabs.data(), tabs.size(), ev)); pending = true; }
@@ -811,11 +825,15 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
       }
       cm2 = msm_rows(c, gn.g, idx_u, rows2, nrows2);
     }
-    t.append_point("Cy", cm2[0].data());
-    t.append_scalars("a", a);
-    t.append_point("delta", delta.data());
-    t.append_point("beta", cm2[1].data());
-    Fq ch = t.challenge_scalar("c");
+    Fq ch;
+    if (dpp_early) ch = ch_early;
+    else {
+      t.append_point("Cy", cm2[0].data());
+      t.append_scalars("a", a);
+      t.append_point("delta", delta.data());
+      t.append_point("beta", cm2[1].data());
+      ch = t.challenge_scalar("c");
+    }
     DotProductProof dpp;
     dpp.delta = delta; dpp.beta = cm2[1];
     dpp.z.resize(nn);
