@@ -563,6 +563,70 @@ __device__ __forceinline__ void pt10_tree_quad(Pt10* sm, Fe10* /*xch*/, size_t n
   __syncthreads();  // sm[0] is the sum for every thread of the block
 }
 #endif
+// Round 4, second form: a tree level TWO multiplications deep instead of three. The unified addition above spends its third level of
+// depth on the curve constant (C = T1 * (2d * T2)); the dedicated addition of Hisil-Wong-Carter-Dawson for a = -1 ("add-2008-hwcd-4")
+// has no constant at all:
+//   lane 0: A = (Y1-X1)(Y2+X2)   lane 1: B = (Y1+X1)(Y2-X2)   lane 2: C = (Z1+Z1) T2   lane 3: D = (T1+T1) Z2
+//   swap with the neighbour:      lane 0: F = B - A   lane 1: G = B + A   lane 2: E = D + C   lane 3: H = D - C
+//   fetch the second factor (quad_perm [1,3,0,2]):  lane 0: Z3 = F G   lane 1: Y3 = G H   lane 2: X3 = E F   lane 3: T3 = H E
+// Same group element as the unified formula (a different projective representative), hence the same canonical bytes. The price is
+// that the formula is not complete, and the tree pays it in two places:
+//   * the neutral element (zero digits, lanes past the end: exactly (0, 1, 1, 0)) is never fed to it — `idf[i]` marks the points that
+//     are the untouched neutral element; a sum with one is a copy, with two stays marked;
+//   * P = Q (possible only when a caller-supplied generator list repeats a point under equal scalars; sums over disjoint sets of
+//     independent generators cannot collide) gives F = H = 0 in identical limbs, i.e. the all-zero quadruple, which every later
+//     addition — either formula — maps to the all-zero quadruple again: the ROOT then has Z = 0, which no valid point has, and the
+//     host re-runs the launch with the unified tree (ipa.hip). P = -Q gives (0, Y, Z, 0) with Y = Z, a valid neutral element.
+__device__ __forceinline__ void pt10_tree_quad_ded(Pt10* sm, unsigned char* idf, size_t n) {
+  const int t = threadIdx.x, role = t & 3;
+  const Fe10 zero = Fe10{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  // field offsets inside Pt10, in units of Fe10: X 0, Y 1, Z 2, T 3
+  const int fP = role <= 1 ? 1 : role;                    // P: Y, Y, Z, T
+  const int gP = role <= 1 ? 0 : role;                    //    X (minus for lane 0), X, Z, T
+  const int fQ = role <= 1 ? 1 : (role == 2 ? 3 : 2);     // Q: Y, Y, T, Z
+  const int osel = role == 0 ? 2 : (role == 1 ? 1 : (role == 2 ? 0 : 3));  // coordinate this lane produces: Z, Y, X, T
+  int top = 128;
+  while (top > 1 && (size_t)top >= n) top >>= 1;
+  for (int s = top; s > 0; s >>= 1) {
+    for (int base = 0; base < s; base += 64) {
+      const int q = base + (t >> 2);
+      const bool act = q < s && (size_t)(q + s) < n;
+      if (act) {  // whole quads are active or not, and take the same branch below
+        Fe10* P = reinterpret_cast<Fe10*>(sm + q);
+        const Fe10* Q = reinterpret_cast<const Fe10*>(sm + q + s);
+        const bool idP = idf[q] != 0, idQ = idf[q + s] != 0;
+        if (!idQ) {
+          if (idP) {
+            P[role] = Q[role];
+            if (role == 0) idf[q] = 0;
+          } else {
+            Fe10 f1 = P[fP], g1 = P[gP], f2 = Q[fQ], g2 = Q[0];
+            g1 = fe10_pick(g1, fe10_neg(g1), role == 0);
+            g2 = fe10_pick(fe10_pick(g2, fe10_neg(g2), role == 1), zero, role >= 2);
+            Fe10 mine = fe10_mul(fe10_add(f1, g1), fe10_add(f2, g2));      // A | B | C | D
+            Fe10 other = fe10_quad_perm_1032(mine);                         // B | A | D | C
+            Fe10 minuend = fe10_pick(mine, other, role == 0), subtrahend = fe10_pick(other, mine, role == 0);
+            Fe10 val = (role == 1 || role == 2) ? fe10_add(mine, other) : fe10_sub(minuend, subtrahend);  // F | G | E | H
+            Fe10 fac = fe10_quad_perm_1302(val);                            // G | H | F | E
+            P[osel] = fe10_mul(val, fac);                                   // Z3 = F G | Y3 = G H | X3 = E F | T3 = H E
+          }
+        }
+      }
+    }
+    if (s > 16) __syncthreads();
+  }
+  __syncthreads();
+}
+// the untouched neutral element as the kernels build it: (0, 1, 1, 0) limb for limb (a computed neutral element has other limbs and is an
+// ordinary operand)
+__device__ __forceinline__ bool pt10_is_blank(const Pt10& p) {
+  int32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) acc |= p.X.v[i] | p.T.v[i];
+#pragma unroll
+  for (int i = 1; i < 10; i++) acc |= p.Y.v[i] | p.Z.v[i];
+  return acc == 0 && p.Y.v[0] == 1 && p.Z.v[0] == 1;
+}
 
 // Latency path, fused form (rows <= SP_HOST_ENCODE_ROWS): grid (nblk, rows). Thread p of a row looks up the table entry
 // of its (column, window) pair and the block sums its 256 entries in an LDS tree, so a Sigma-protocol commitment is ONE
@@ -703,10 +767,12 @@ __device__ __forceinline__ Fq ipa_fold_b(const Fq* __restrict__ b, size_t x, siz
   Fq v = ld_fq(b + x);
   return fold ? fq_add(fq_mul(v, u_inv), fq_mul(u, ld_fq(b + n_cur + x))) : v;  // b' = b_L u^-1 + u b_R
 }
+template <bool DED>  // DED: the two-multiplication tree level (pt10_tree_quad_ded); false: the unified formula (the fallback of an exceptional sum)
 __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* __restrict__ table, MsmGeom geom, DoneSig sig) {
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
   __shared__ unsigned ticket;
+  unsigned char* const idf = reinterpret_cast<unsigned char*>(xch);  // DED: one mark per point (the unified tree's exchange buffer is unused then)
   const int t = threadIdx.x;
   const size_t h = A.n_cur / 2;
   if (blockIdx.x >= 2 * A.nblk) {
@@ -782,9 +848,11 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
     }
   }
   sm[t] = acc;
+  if (DED) idf[t] = pt10_is_blank(acc) ? 1 : 0;
   SP_KT(kt0, 3);
   __syncthreads();
-  pt10_tree_quad(sm, xch, P - (size_t)blk * 256);
+  if (DED) pt10_tree_quad_ded(sm, idf, P - (size_t)blk * 256);
+  else pt10_tree_quad(sm, xch, P - (size_t)blk * 256);
   SP_KT(kt0, 4);
   if (t == 0) {
     A.part[(size_t)row * A.nblk + blk] = sm[0];
@@ -806,9 +874,11 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
     }
     __syncthreads();
     sm[t] = r;
+    if (DED) idf[t] = pt10_is_blank(r) ? 1 : 0;
     SP_KT(kt1, 9);
     __syncthreads();
-    pt10_tree_quad(sm, xch, A.nblk < 256 ? A.nblk : 256);
+    if (DED) pt10_tree_quad_ded(sm, idf, A.nblk < 256 ? A.nblk : 256);
+    else pt10_tree_quad(sm, xch, A.nblk < 256 ? A.nblk : 256);
     SP_KT(kt1, 10);
     if (t == 0) {
       Pt10 z = sm[0];
@@ -819,7 +889,9 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
   }
   signal_done(sig);
 }
-extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out) {
+// unified: the tree with the complete addition formula (the re-run of a round whose row sum came back with Z = 0; SPARTAN_IPA_UNIFIED_TREE=1 selects it
+// for every round: the A/B switch)
+extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out, int unified) {
   const size_t P = (A->n0 / 2) * (size_t)g->geom.nwin;
   A->nblk = (unsigned)((P + 255) / 256);
   const size_t qlen = A->n_cur >= 4 ? A->n_cur / 4 : 1;
@@ -832,7 +904,9 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
   DoneSig sig = sig_make(c, 2 * (size_t)A->nblk + A->nd);
   {
     ProfScope ps(c, PF_IPA, 32.0 * 3 * (double)A->n0 + 160.0 * 2 * (double)A->nblk, nullptr, (double)(2 * P));
-    hipLaunchKernelGGL(k_ipa_round, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
+    static const bool always_unified = getenv("SPARTAN_IPA_UNIFIED_TREE") != nullptr;
+    if (unified || always_unified) hipLaunchKernelGGL(k_ipa_round<false>, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
+    else hipLaunchKernelGGL(k_ipa_round<true>, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
   }
   *sig_out = sig;
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;

@@ -26,6 +26,7 @@ struct sp_ipa {
   DoneSig pre_sig;
   unsigned pre_nd = 0;
   Fq pre_cL, pre_cR;
+  struct IpaRoundArgs* last_args = nullptr;  // the arguments of the round in flight (owned): a row sum with Z = 0 re-runs them with the unified tree
 };
 // core.hip
 struct IpaRoundArgs {
@@ -40,7 +41,7 @@ struct IpaRoundArgs {
   Fq* dots_out;
   unsigned nblk, nd;
 };
-extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out);
+extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out, int unified);
 static unsigned ipa_c0_blocks(size_t n) { return (unsigned)((n / 2 + 511) / 512); }  // k_ipa_init: one workgroup per 512 index pairs
 static bool ipa_fused() {
   static const bool on = getenv("SPARTAN_IPA_UNFUSED") == nullptr;  // A/B switch: three launches + flag kernel per round (the round-2 path)
@@ -206,6 +207,7 @@ void sp_ipa_free(sp_ipa* ipa) {
   if (!ipa) return;
   if (ipa->pre) (void)sig_wait(ipa->ctx, ipa->pre_sig);  // a prelaunched round nobody collected still reads the buffers
   pool_release(ipa->ctx, ipa->base, ipa->bytes);  // one allocation backs a, b, a2, b2, s, s2, rows, idx
+  delete ipa->last_args;
   delete ipa;
 }
 // a: host vector, or (a_dev != nullptr) the first n entries of a device table. commit_a != nullptr: also returns
@@ -308,7 +310,10 @@ static int32_t ipa_round_start(sp_ipa* ipa, Fq* cL_out, Fq* cR_out, DoneSig* sig
   A.fold = ipa->fold_pending ? 1 : 0;
   A.u = ipa->fu; A.u_inv = ipa->fu_inv;
   A.counters = ipa->counters;
-  SPCHK(ipa_round_launch(c, ipa->g, &A, sig_out));
+  SPCHK(ipa_round_launch(c, ipa->g, &A, sig_out, 0));
+  if (!ipa->last_args) ipa->last_args = new (std::nothrow) IpaRoundArgs();
+  if (!ipa->last_args) return SP_ENOMEM;
+  *ipa->last_args = A;
   if (ipa->fold_pending) {  // the kernel leaves the folded vectors in the ping-pong buffers
     std::swap(ipa->a, ipa->a2); std::swap(ipa->b, ipa->b2); std::swap(ipa->s, ipa->s2);
     ipa->fold_pending = false;
@@ -346,6 +351,16 @@ static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uin
   if (hipGetLastError() != hipSuccess) return SP_EHIP;
   SPCHK(hrc);
   const Pt* sums = (const Pt*)hres(c);
+  if (fp_is_zero(sums[0].Z) || fp_is_zero(sums[1].Z)) {
+    // no valid point has Z = 0: an addition of the two-multiplication tree met one of its exceptional pairs (core.hip, pt10_tree_quad_ded:
+    // a generator list that repeats a point). The round is run again with the unified formula: same inputs, same outputs otherwise.
+    if (getenv("SPARTAN_IPA_NO_RERUN")) return SP_EHIP;  // test-only: shows that a test input reached this path
+    DoneSig sig2;
+    SPCHK(ipa_round_launch(c, ipa->g, ipa->last_args, &sig2, 1));
+    SPCHK(sig_wait(c, sig2));
+    if (hipGetLastError() != hipSuccess) return SP_EHIP;
+    if (fp_is_zero(sums[0].Z) || fp_is_zero(sums[1].Z)) return SP_EHIP;
+  }
   Pt lr[2];
   for (int r = 0; r < 2; r++) {
     Pt tail;

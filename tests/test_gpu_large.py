@@ -258,17 +258,15 @@ def test_vecmat_and_evaluate_large_match_oracle(ctx, orc):
     t.free()
 
 
-def test_inner_product_argument_n4096_matches_folded_generators(ctx, orc):
-    """BulletReductionProof::prove (nizk/bullet.rs:32-132) at n = 4096 as the reference computes it — G folded every round,
+def _ipa_against_folded_generators(ctx, orc, n, comp, a, b, rng):
+    """BulletReductionProof::prove (nizk/bullet.rs:32-132) as the reference computes it — G folded every round,
     L = <a_L, G_R> + c_L Q + blind_L H over the FOLDED generators — through the oracle's point arithmetic only
-    (orc_pt_msm), against sp_ipa_*, which never folds G (fixed-base rows over the original generators)."""
+    (orc_pt_msm), against sp_ipa_*, which never folds G (fixed-base rows over the original generators).
+    comp: n + 2 compressed points, G[0..n), Q = P[n], H = P[n+1]."""
     from spartan_amd import capi
-    n = 4096
-    rng = random.Random(4096)
-    comp = gens_bytes(orc, n + 1, b"gens_ipa_test")   # G[0..n), Q = P[n], H = P[n+1]
     g = capi.Gens(ctx, compressed=comp)
     P = [comp[32 * i:32 * i + 32] for i in range(n + 2)]
-    a, b = fast_scalars(rng, n), fast_scalars(rng, n)
+    a, b = list(a), list(b)
     qs = rng.getrandbits(250)
     ipa = vp()
     assert capi.lib.sp_ipa_begin(ctx.h, g.h, sz(0), sz(n), sz(n), sz(n + 1), fq1(qs), mont_bulk(a), mont_bulk(b), ctypes.byref(ipa)) == 0
@@ -305,6 +303,53 @@ def test_inner_product_argument_n4096_matches_folded_generators(ctx, orc):
     assert bytes(out) == msm([d, r], [G[0], P[n + 1]])             # nizk/mod.rs:496-501
     capi.lib.sp_ipa_free(ipa)
     g.free()
+
+
+def test_inner_product_argument_n4096_matches_folded_generators(ctx, orc):
+    """n = 4096: the opening size of a 2^20 proof (two trees of ~8 levels per row and round, core.hip k_ipa_round)."""
+    n = 4096
+    rng = random.Random(4096)
+    comp = gens_bytes(orc, n + 1, b"gens_ipa_test")   # G[0..n), Q = P[n], H = P[n+1]
+    _ipa_against_folded_generators(ctx, orc, n, comp, fast_scalars(rng, n), fast_scalars(rng, n), rng)
+
+
+@pytest.mark.parametrize("case", ["repeated_generators_equal_scalars", "repeated_generators_opposite_scalars", "zero_vector", "sparse_vector", "plain_small"])
+def test_inner_product_argument_exceptional_sums(ctx, orc, case):
+    """The tree of k_ipa_round adds with the dedicated (two-multiplication) formula, which is not complete (core.hip,
+    pt10_tree_quad_ded): the neutral element is kept away from it by marks, P = Q collapses to the all-zero quadruple and the host
+    re-runs the round with the unified formula. The cases that reach those paths, against the reference's folded-generator algorithm:
+    a generator list that repeats points under equal scalars (two sub-trees with limb-identical sums: the re-run), under opposite
+    scalars (a computed neutral element as an operand), an all-zero vector (every leaf is the marked neutral element), a vector with a
+    few non-zero entries (marked and unmarked operands mixed), and an ordinary small argument."""
+    n = 16
+    rng = random.Random(sum(map(ord, case)))
+    base = gens_bytes(orc, n + 1, b"gens_ipa_exc")
+    P = [base[32 * i:32 * i + 32] for i in range(n + 2)]
+    a, b = fast_scalars(rng, n), fast_scalars(rng, n)
+    if case.startswith("repeated_generators"):
+        for i in range(0, n, 2):
+            P[i + 1] = P[i]                      # G[2k+1] = G[2k]
+            a[i + 1] = a[i] if case.endswith("equal_scalars") else (Q - a[i]) % Q
+    elif case == "zero_vector":
+        a = [0] * n
+    elif case == "sparse_vector":
+        a = [a[i] if i in (3, 12) else 0 for i in range(n)]
+    _ipa_against_folded_generators(ctx, orc, n, b"".join(P), a, b, rng)
+    if case == "repeated_generators_equal_scalars":
+        # the re-run really happened: with it switched off (test-only switch) the same argument must fail in its first round
+        import os
+        from spartan_amd import capi
+        os.environ["SPARTAN_IPA_NO_RERUN"] = "1"
+        try:
+            g = capi.Gens(ctx, compressed=b"".join(P))
+            ipa = vp()
+            assert capi.lib.sp_ipa_begin(ctx.h, g.h, sz(0), sz(n), sz(n), sz(n + 1), fq1(5), mont_bulk(a), mont_bulk(b), ctypes.byref(ipa)) == 0
+            L = (ctypes.c_uint8 * 32)(); Rr = (ctypes.c_uint8 * 32)()
+            assert capi.lib.sp_ipa_round_lr(ipa, fq1(1), fq1(2), L, Rr) != 0
+            capi.lib.sp_ipa_free(ipa)
+            g.free()
+        finally:
+            del os.environ["SPARTAN_IPA_NO_RERUN"]
 
 
 def test_witness_sized_commit_every_row_matches_oracle(ctx, orc):
