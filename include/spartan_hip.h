@@ -326,6 +326,22 @@ int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* cons
  * once, out of place. Requires current length >= 4. */
 int32_t sp_sumcheck_bind_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst,
                                       const uint64_t r[4], uint64_t* out);
+/* The same two calls with the eq table as a FACTOR, for the throughput-sized rounds (current length >= 65536) of the batches
+ * ProductCircuitEvalProofBatched::prove builds (product_tree.rs:259-383): instances [0, neq) are product-circuit instances whose third
+ * table is the shared poly_C_par = EqPolynomial::new(rand).evals() (product_tree.rs:279), C[0] == ... == C[neq-1]; instances [neq, ninst)
+ * are generic (the dot-product circuits). After binds at r_1..r_{j-1} the bound eq table is a scalar the caller knows times eq(t, rand_j)
+ * times the LEADING entries of the original table, so the device never binds it and returns, per product-circuit instance,
+ *     q(t) = sum_x A(t,x) B(t,x) C_original[x]   at t = 0 and t = 2   (q is quadratic in t: q(1) follows from the round's claim, q(3) by
+ *     extrapolation; the caller multiplies by kappa_j(t) = [prod_{k<j} eq(r_k, rand_k) / (1 - rand_k)] * eq(t, rand_j) / (1 - rand_j)),
+ * 8 multiplications per index and instance instead of 12 (4 instead of 6 without a bind). Generic instances return e(t) at t = 0, 1, 2, 3.
+ * out[16 * ninst]: 4 scalars per instance, {q(0), q(2), 0, 0} or {e(0), e(1), e(2), e(3)}. The shared eq table is read, never written,
+ * and keeps its length; A, B (and the generic C tables) are bound in place as by sp_sumcheck_bind_eval_batched.
+ * sp_table_scale_prefix: table[i] *= k for i < n and n becomes its length — the hand-over to the generic rounds (k = the scalar above:
+ * the table is then the bound eq table the generic calls expect). Queued, not waited for. */
+int32_t sp_sumcheck_eval_batched_eq(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t neq, uint64_t* out);
+int32_t sp_sumcheck_bind_eval_batched_eq(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t neq,
+                                         const uint64_t r[4], uint64_t* out);
+int32_t sp_table_scale_prefix(sp_ctx* ctx, sp_table* table, size_t n, const uint64_t k[4]);
 /* TWO rounds per call, for the latency-bound rounds of prove_cubic_batched (a round trip to the device costs more than the
  * arithmetic of a short round). The evaluations of the round after a bind are a cubic in that bind's challenge r:
  *   E(t; r) = (1-r)^3 M0(t) + (1-r)^2 r M1(t) + (1-r) r^2 M2(t) + r^3 M3(t),   M1 = (T1 - T2)/2 - M3,  M2 = (T1 + T2)/2 - M0,

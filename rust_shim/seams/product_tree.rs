@@ -92,7 +92,8 @@ impl ProductCircuitEvalProofBatched {
         &claim, num_rounds_prod,
         (&mut poly_A_batched_par, &mut poly_B_batched_par, &mut poly_C_par),
         (&mut poly_A_batched_seq, &mut poly_B_batched_seq, &mut poly_C_batched_seq),
-        &coeff_vec, transcript);
+        &coeff_vec, transcript,
+        if rand.is_empty() { None } else { Some(&rand[..]) }); // poly_C_par is EqPolynomial::new(rand).evals() (:279): the factored rounds
       let (claims_prod_left, claims_prod_right, _claims_eq) = claims_prod;
       for i in 0..prod_circuit_vec.len() {
         transcript.append_scalar(b"claim_prod_left", &claims_prod_left[i]);

@@ -376,6 +376,53 @@ fn evals_from_coeffs(S: &[Scalar], r: &Scalar) -> [Scalar; 3] {
   }
   ev
 }
+/// The eq table as a FACTOR (spartan_hip.h, sp_sumcheck_eval_batched_eq; spark.inc EqFactor is the C++ twin): the throughput-sized rounds of a
+/// batch whose product-circuit instances share poly_C_par = EqPolynomial::new(rho).evals() (product_tree.rs:279). With the tables bound at
+/// r_0..r_{j-1}, round j's combined evaluations are E(t) = kappa_j(t) Q(t) + D(t) with Q(t) = sum_i coeff_i q_i(t) QUADRATIC (the device
+/// returns q_i(0), q_i(2) summed against the ORIGINAL eq table's leading entries, which it never binds), D(t) the generic instances' cubic
+/// (four evaluations each), kappa_j(t) = K_j eq(t, rho_j) / (1 - rho_j), K_j = prod_{k<j} eq(r_k, rho_k) / (1 - rho_k). Q(1) follows from
+/// the round's claim, Q(3) = Q(0) - 3 Q(1) + 3 Q(2). Exact identities in the field: the round polynomials are the reference's.
+/// THIS BODY CARRIES LOGIC (not a mechanical call sequence): review it against spark.inc and tests/test_host_arith.py.
+#[cfg(feature = "gpu")]
+struct EqFactor { on: bool, rho: Vec<Scalar>, inv1m: Vec<Scalar>, inv_rho: Vec<Scalar>, K: Scalar, Kinv: Scalar }
+#[cfg(feature = "gpu")]
+impl EqFactor {
+  const MIN_LEN: usize = 65536; // the factored kernels are the throughput forms only
+  fn off() -> Self { EqFactor { on: false, rho: vec![], inv1m: vec![], inv_rho: vec![], K: Scalar::one(), Kinv: Scalar::one() } }
+  /// usable when no coordinate of the point is 0 or 1 (1 / (1 - rho) and 1 / rho must exist)
+  fn begin(point: Option<&[Scalar]>, num_rounds: usize, len: usize, np: usize, ni: usize) -> Self {
+    let rho = match point { Some(p) if gpu::eq_factor_enabled() && p.len() == num_rounds && np > 0 && ni <= 24 && len >= Self::MIN_LEN => p.to_vec(), _ => return Self::off() };
+    let one = Scalar::one();
+    if rho.iter().any(|r| *r == Scalar::zero() || *r == one) { return Self::off(); }
+    let inv1m = rho.iter().map(|r| (one - r).invert().unwrap()).collect();
+    let inv_rho = rho.iter().map(|r| r.invert().unwrap()).collect();
+    EqFactor { on: true, rho, inv1m, inv_rho, K: one, Kinv: one }
+  }
+  /// E(0), E(2), E(3) of round j from the device's 4 scalars per instance, the coefficients and the round's claim e
+  fn combine(&self, j: usize, ev4: &[Scalar], coeffs: &[Scalar], np: usize, ni: usize, e: &Scalar) -> [Scalar; 3] {
+    let (mut q0, mut q2) = (Scalar::zero(), Scalar::zero());
+    let mut d = [Scalar::zero(); 4];
+    for i in 0..np { q0 += ev4[4 * i] * coeffs[i]; q2 += ev4[4 * i + 1] * coeffs[i]; }
+    for i in np..ni { for k in 0..4 { d[k] += ev4[4 * i + k] * coeffs[i]; } }
+    if self.K == Scalar::zero() { return [d[0], d[2], d[3]]; } // a challenge hit a root of eq(., rho_k): the eq table is zero from there on
+    let (one, two, three, five) = (Scalar::one(), (2_usize).to_scalar(), (3_usize).to_scalar(), (5_usize).to_scalar());
+    let r = self.rho[j];
+    let ks = self.K * self.inv1m[j];
+    let (k2, k3) = (ks * (three * r - one), ks * (five * r - two));
+    let e0 = self.K * q0 + d[0];
+    let e1 = e - e0;
+    let q1 = (e1 - d[1]) * self.Kinv * self.inv_rho[j] * (one - r); // / kappa(1), kappa(1) = K rho / (1 - rho)
+    let q3 = q0 - three * q1 + three * q2;
+    [e0, k2 * q2 + d[2], k3 * q3 + d[3]]
+  }
+  /// the tables have been bound at r (round j's challenge)
+  fn bound(&mut self, j: usize, r: &Scalar) {
+    let one = Scalar::one();
+    let f = (one - r) * (one - self.rho[j]) + r * self.rho[j]; // eq(r, rho_j)
+    self.K = self.K * f * self.inv1m[j];
+    self.Kinv = if f == Scalar::zero() { Scalar::zero() } else { self.Kinv * f.invert().unwrap() * (one - self.rho[j]) };
+  }
+}
 /// The last rounds on tables of m <= 8 entries, tab = [instance][A, B, C][m]: the reference's loop body (:290-393) verbatim in
 /// structure; `message` appends the round's polynomial and returns its challenge.
 #[cfg(feature = "gpu")]
@@ -413,6 +460,7 @@ impl SumcheckInstanceProof {
     poly_vec_seq: (&mut Vec<&mut DensePolynomial>, &mut Vec<&mut DensePolynomial>, &mut Vec<&mut DensePolynomial>),
     coeffs: &[Scalar],
     transcript: &mut Transcript,
+    eq_point: Option<&[Scalar]>, // Some(rand) when poly_C_par = EqPolynomial::new(rand).evals() (product_tree.rs:279): the factored rounds (EqFactor)
   ) -> (Self, Vec<Scalar>, (Vec<Scalar>, Vec<Scalar>, Scalar), (Vec<Scalar>, Vec<Scalar>, Vec<Scalar>)) {
     let (poly_A_vec_par, poly_B_vec_par, poly_C_par) = poly_vec_par;
     let (poly_A_vec_seq, poly_B_vec_seq, poly_C_vec_seq) = poly_vec_seq;
@@ -437,7 +485,9 @@ impl SumcheckInstanceProof {
     let mut e = *claim;
     let mut r: Vec<Scalar> = Vec::new();
     let mut cubic_polys: Vec<CompressedUniPoly> = Vec::new();
-    let mut ev = vec![Scalar::zero(); 3 * ni]; // per-instance evaluations (one round per launch)
+    let mut ev = vec![Scalar::zero(); 3 * ni];
+    let mut ev4 = vec![Scalar::zero(); 4 * ni]; // the factored form's 4 scalars per instance
+    let mut eqf = EqFactor::off(); // per-instance evaluations (one round per launch)
     let mut evc = [Scalar::zero(); 3];         // combined with coeffs (:359-369)
     let mut S = vec![Scalar::zero(); 12];      // the cubic that gives the next round's evaluations
     let mut heads = vec![Scalar::zero(); all.len()];
@@ -568,13 +618,32 @@ impl SumcheckInstanceProof {
           gpu::ok(unsafe { gpu::sp_sumcheck_eval_coeffs_batched(c, ap, bp, cp, ni, gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S)) });
           have_S = true;
         } else {
-          gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) });
-          evc = combine(&ev);
+          eqf = EqFactor::begin(eq_point, num_rounds, len0, np, ni);
+          if eqf.on {
+            gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched_eq(c, ap, bp, cp, ni, np, gpu::limbs_mut(&mut ev4)) });
+            evc = eqf.combine(0, &ev4, coeffs, np, ni, &e);
+          } else {
+            gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) });
+            evc = combine(&ev);
+          }
         }
       }
       while j < num_rounds {
         let len = len_of(A[0]);
         let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+        if eqf.on && len >= EqFactor::MIN_LEN {
+          // a throughput-sized round in the factored form: A and B are bound at r_j, the eq table is only read
+          gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched_eq(c, ap, bp, cp, ni, np, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev4)) });
+          eqf.bound(j, &r_j);
+          j += 1;
+          evc = eqf.combine(j, &ev4, coeffs, np, ni, &e);
+          continue;
+        }
+        if eqf.on {
+          // hand-over: K * C_original[0 .. len) is the eq table bound at r_0 .. r_{j-1}; the generic rounds continue with it
+          gpu::ok(unsafe { gpu::sp_table_scale_prefix(c, dev(poly_C_par), len, gpu::limbs1(&eqf.K)) });
+          eqf.on = false;
+        }
         if have_S && len >= 4 {
           // two rounds in one trip: the next round's evaluations are the device's cubic at r_j
           evc = evals_from_coeffs(&S, &r_j);

@@ -119,6 +119,104 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* _
     st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]);
   }
 }
+// ---- the eq table as a FACTOR (round 4): the throughput-sized rounds of the product-circuit instances -------------------------------
+// In prove_cubic_batched under ProductCircuitEvalProofBatched::prove (product_tree.rs:259-383) the third table of every product-circuit
+// instance is poly_C_par = EqPolynomial::new(rand).evals() (:279): C[x] = prod_k eq(x_k, rho_k). After the rounds' binds at r_1..r_{j-1} the
+// bound table is  C_j[t, x''] = [prod_{k<j} eq(r_k, rho_k)] * eq(t, rho_j) * eq(x''; rho_{j+1}..),  and the ORIGINAL table's leading
+// entries hold the last factor already:  C[x''] = [prod_{k<=j} (1 - rho_k)] * eq(x''; rho_{j+1}..)  (top j index bits zero). So
+//     sum_x'' A(t,x'') B(t,x'') C_j[t,x'']  =  kappa_j(t) * q(t),   q(t) = sum_x'' A(t,x'') B(t,x'') C[x''],
+// with a scalar kappa_j(t) the host knows (spark.inc): the device never binds the eq table, reads ONE entry of it per index instead of
+// four, and q is only QUADRATIC in t: q(0) and q(2) come from here, q(1) from the round's claim, q(3) by extrapolation — two evaluation
+// points instead of three. Per index and instance: 8 multiplications instead of 12 (4 instead of 6 in the first evaluation), 9 loads and
+// 4 stores instead of 12 and 6. Exact field identities: the round polynomials, hence the proof bytes, are those of the generic kernels
+// (tests/test_gpu_large.py). The generic instances (the dot-product circuits of the widest layer, whose third table is a real
+// table) take the generic arithmetic and return FOUR evaluations, t = 0, 1, 2, 3 (their e(1) is needed to split the claim).
+// partials[(inst * nblk + blk) * 4 + {0,1,2,3}]: factored {q(0), q(2), 0, 0}, generic {e(0), e(1), e(2), e(3)}.
+__device__ __forceinline__ void quad_point_eq(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c, Fq (&e)[4]) {
+  Fq a2 = fq_add(a1, fq_sub(a1, a0)), b2 = fq_add(b1, fq_sub(b1, b0));
+  e[0] = fq_add(e[0], fq_mul(fq_mul(a0, b0), c));
+  e[1] = fq_add(e[1], fq_mul(fq_mul(a2, b2), c));
+}
+__device__ __forceinline__ void cubic_point4(const Fq& a0, const Fq& a1, const Fq& b0, const Fq& b1, const Fq& c0, const Fq& c1, Fq (&e)[4]) {
+  Fq da = fq_sub(a1, a0), db = fq_sub(b1, b0), dc = fq_sub(c1, c0);
+  Fq a2 = fq_add(a1, da), b2 = fq_add(b1, db), c2 = fq_add(c1, dc);
+  Fq a3 = fq_add(a2, da), b3 = fq_add(b2, db), c3 = fq_add(c2, dc);
+  e[0] = fq_add(e[0], fq_mul(fq_mul(a0, b0), c0));
+  e[1] = fq_add(e[1], fq_mul(fq_mul(a1, b1), c1));
+  e[2] = fq_add(e[2], fq_mul(fq_mul(a2, b2), c2));
+  e[3] = fq_add(e[3], fq_mul(fq_mul(a3, b3), c3));
+}
+// GEN selects the arithmetic at compile time (one launch for the product-circuit instances, one for the generic ones when there are any):
+// a kernel holding both bodies is allocated for the larger one (205 registers, two waves per SIMD instead of three)
+template <bool GEN>
+__global__ void __launch_bounds__(256) k_cubic_eval_batched_eq(TripleInline IN, unsigned inst0, size_t half, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  const unsigned inst = inst0 + blockIdx.y;
+  Triple t = IN.t[inst];
+  Fq e[4] = {fq_zero(), fq_zero(), fq_zero(), fq_zero()};
+  if (!GEN) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+      quad_point_eq(ld_fq(t.a + i), ld_fq(t.a + half + i), ld_fq(t.b + i), ld_fq(t.b + half + i), ld_fq(t.c + i), e);
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+      cubic_point4(ld_fq(t.a + i), ld_fq(t.a + half + i), ld_fq(t.b + i), ld_fq(t.b + half + i), ld_fq(t.c + i), ld_fq(t.c + half + i), e);
+  }
+  if (GEN) block_sum_fq<4>(e, sm);
+  else {
+    Fq q[2] = {e[0], e[1]};
+    block_sum_fq<2>(q, sm);
+    e[0] = q[0]; e[1] = q[1];
+  }
+  if (threadIdx.x == 0) {
+    Fq* p = partials + ((size_t)inst * gridDim.x + blockIdx.x) * 4;
+    st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]); st_fq(p + 3, e[3]);
+  }
+}
+template <bool GEN>
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched_eq(TripleInline IN, unsigned inst0, size_t quarter, Fq r, Fq* __restrict__ partials) {
+  __shared__ Fq sm[256];
+  const unsigned inst = inst0 + blockIdx.y;
+  Triple t = IN.t[inst];
+  Fq e[4] = {fq_zero(), fq_zero(), fq_zero(), fq_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quarter; i += (size_t)gridDim.x * blockDim.x) {
+    Fq lo[3], hi[3];
+    Fq* ptr[3] = {t.a, t.b, t.c};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      Fq x0 = ld_fq(ptr[k] + i), x1 = ld_fq(ptr[k] + quarter + i), x2 = ld_fq(ptr[k] + 2 * quarter + i), x3 = ld_fq(ptr[k] + 3 * quarter + i);
+      lo[k] = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
+      hi[k] = fq_add(x1, fq_mul(r, fq_sub(x3, x1)));
+      st_fq(ptr[k] + i, lo[k]);
+      st_fq(ptr[k] + quarter + i, hi[k]);
+    }
+    if (!GEN) {
+      quad_point_eq(lo[0], hi[0], lo[1], hi[1], ld_fq(t.c + i), e);  // the eq table is read, never bound
+    } else {
+      Fq x0 = ld_fq(ptr[2] + i), x1 = ld_fq(ptr[2] + quarter + i), x2 = ld_fq(ptr[2] + 2 * quarter + i), x3 = ld_fq(ptr[2] + 3 * quarter + i);
+      lo[2] = fq_add(x0, fq_mul(r, fq_sub(x2, x0)));
+      hi[2] = fq_add(x1, fq_mul(r, fq_sub(x3, x1)));
+      if (t.c_out) {
+        st_fq(t.c_out + i, lo[2]);
+        st_fq(t.c_out + quarter + i, hi[2]);
+      }
+      cubic_point4(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], e);
+    }
+  }
+  if (GEN) block_sum_fq<4>(e, sm);
+  else {
+    Fq q[2] = {e[0], e[1]};
+    block_sum_fq<2>(q, sm);
+    e[0] = q[0]; e[1] = q[1];
+  }
+  if (threadIdx.x == 0) {
+    Fq* p = partials + ((size_t)inst * gridDim.x + blockIdx.x) * 4;
+    st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]); st_fq(p + 3, e[3]);
+  }
+}
+// t[i] *= k for i < n (the hand-over from the factored rounds: the bound eq table the generic kernels continue with)
+__global__ void __launch_bounds__(256) k_scale_prefix(Fq* __restrict__ t, size_t n, Fq k) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(t + i, fq_mul(ld_fq(t + i), k));
+}
 // Latency form of the fused round for short tables (quarter <= a few hundred): the ~12 dependent field
 // multiplications of one index are spread over 8 lanes (six do one bind each, then three do one evaluation point
 // each), so a round costs ~3 multiplications of latency instead of 12. Block = 32 indices x 8 roles; grid (nblk, ninst).
@@ -737,6 +835,105 @@ int32_t sp_sumcheck_bind_eval_batched(sp_ctx* c, sp_table* const* A, sp_table* c
   for (size_t k = 0; k < ninst; k++)
     if (C[k]->len == len) table_swap_to_alt(C[k], len / 2);
   return batched_finish(c, partials, nblk, ninst, out, sig);
+}
+
+// ---- the factored forms (kernels above): instances [0, neq) are product-circuit instances sharing the eq table C[0] (never bound, its
+// length stays what it was: the rounds read its leading entries), instances [neq, ninst) are generic. out[4 * ninst]: {q(0), q(2), 0, 0} for
+// the former, {e(0), e(1), e(2), e(3)} for the latter. Throughput-sized tables only (the latency forms have no factored twin): SP_EINVAL
+// below 65536 entries, the caller hands over to the generic rounds there (sp_table_scale_prefix).
+static int32_t batched_finish4(sp_ctx* c, Fq* partials, size_t nblk, size_t ninst, uint64_t* out, const DoneSig& sig) {
+  {
+    ProfScope ps(c, PF_REDUCE, 128.0 * (double)(nblk * ninst));
+    hipLaunchKernelGGL(k_reduce_partials_batched, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, 4, (Fq*)hres(c), sig);
+  }
+  SPCHK(sig_wait(c, sig));
+  memcpy(out, hres(c), 128 * ninst);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
+static int32_t eq_form_check(sp_table* const* C, size_t ninst, size_t neq, size_t len) {
+  if (neq == 0 || neq > ninst || ninst > 24 || 128 * ninst > HOST_SUM_BYTES) return SP_EINVAL;
+  for (size_t k = 0; k < neq; k++)
+    if (C[k] != C[0]) return SP_EINVAL;
+  if (!C[0] || C[0]->len < len) return SP_EINVAL;  // its leading `len` entries are read
+  for (size_t k = neq; k < ninst; k++)
+    if (!C[k] || C[k]->len != len || C[k] == C[0]) return SP_EINVAL;
+  return SP_OK;
+}
+// batched_setup wants every C at the tables' length: the shared eq table keeps its original length, so the triples are built here
+static int32_t eq_form_setup(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t neq, bool bind_c, size_t* len_out,
+                             TripleInline* IN) {
+  if (!c || !A || !B || !C || ninst == 0) return SP_EINVAL;
+  const size_t len = A[0] ? A[0]->len : 0;
+  if (len < 65536 || !is_pow2(len)) return SP_EINVAL;
+  SPCHK(eq_form_check(C, ninst, neq, len));
+  for (size_t k = 0; k < ninst; k++) {
+    if (!A[k] || !B[k] || A[k]->len != len || B[k]->len != len) return SP_EINVAL;
+    IN->t[k] = Triple{A[k]->d, B[k]->d, C[k]->d, nullptr};
+    if (bind_c && k >= neq) {
+      bool first = true;
+      for (size_t m = neq; m < k; m++) first = first && C[m] != C[k];
+      if (first) {
+        SPCHK(table_ensure_alt(C[k], len / 2));
+        IN->t[k].c_out = C[k]->alt;
+      }
+    }
+  }
+  *len_out = len;
+  return SP_OK;
+}
+int32_t sp_sumcheck_eval_batched_eq(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t neq, uint64_t* out) {
+  if (!c || !out) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t len;
+  TripleInline IN;
+  SPCHK(eq_form_setup(c, A, B, C, ninst, neq, false, &len, &IN));
+  const size_t half = len / 2, nblk = grid_for(half, 256);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 4 * (nblk + 1) * ninst));
+  Fq* partials = (Fq*)c->scratch;
+  DoneSig sig = sig_make(c, ninst);
+  {
+    ProfScope ps(c, PF_SC_EVAL, 32.0 * (double)len * (2.5 * (double)neq + 3.0 * (double)(ninst - neq)), nullptr,
+                 (double)half * (4.0 * (double)neq + 8.0 * (double)(ninst - neq)));
+    hipLaunchKernelGGL(k_cubic_eval_batched_eq<false>, dim3((unsigned)nblk, (unsigned)neq), dim3(256), 0, c->stream, IN, 0u, half, partials);
+    if (ninst > neq)
+      hipLaunchKernelGGL(k_cubic_eval_batched_eq<true>, dim3((unsigned)nblk, (unsigned)(ninst - neq)), dim3(256), 0, c->stream, IN, (unsigned)neq, half, partials);
+  }
+  return batched_finish4(c, partials, nblk, ninst, out, sig);
+}
+int32_t sp_sumcheck_bind_eval_batched_eq(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, size_t neq, const uint64_t r[4],
+                                         uint64_t* out) {
+  if (!c || !out || !r) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t len;
+  TripleInline IN;
+  SPCHK(eq_form_setup(c, A, B, C, ninst, neq, true, &len, &IN));
+  const size_t quarter = len / 4, nblk = grid_for(quarter, 256);
+  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 4 * (nblk + 1) * ninst));
+  Fq* partials = (Fq*)c->scratch;
+  DoneSig sig = sig_make(c, ninst);
+  {
+    ProfScope ps(c, PF_SC_BIND_EVAL, 32.0 * (double)len * (3.25 * (double)neq + 4.0 * (double)(ninst - neq)), nullptr,
+                 (double)quarter * (8.0 * (double)neq + 14.0 * (double)(ninst - neq)));
+    hipLaunchKernelGGL(k_cubic_bind_eval_batched_eq<false>, dim3((unsigned)nblk, (unsigned)neq), dim3(256), 0, c->stream, IN, 0u, quarter, limbs(r), partials);
+    if (ninst > neq)
+      hipLaunchKernelGGL(k_cubic_bind_eval_batched_eq<true>, dim3((unsigned)nblk, (unsigned)(ninst - neq)), dim3(256), 0, c->stream, IN, (unsigned)neq, quarter,
+                         limbs(r), partials);
+  }
+  for (size_t k = 0; k < ninst; k++) { A[k]->len = len / 2; B[k]->len = len / 2; }
+  for (size_t k = neq; k < ninst; k++)
+    if (C[k]->len == len) table_swap_to_alt(C[k], len / 2);
+  return batched_finish4(c, partials, nblk, ninst, out, sig);
+}
+// t[i] *= k for i < n, and n becomes the table's length: the hand-over from the factored rounds to the generic ones (queued, not waited for)
+int32_t sp_table_scale_prefix(sp_ctx* c, sp_table* t, size_t n, const uint64_t k[4]) {
+  if (!c || !t || !k || n == 0 || n > t->len) return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  {
+    ProfScope ps(c, PF_MISC, 64.0 * (double)n);
+    hipLaunchKernelGGL(k_scale_prefix, dim3((unsigned)grid_for(n)), dim3(256), 0, c->stream, t->d, n, limbs(k));
+  }
+  t->len = n;
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
 // partials[ninst][nblk][18] -> out[ninst][18], one block per instance: thread = (component k < 18 of 32, slice of blocks)

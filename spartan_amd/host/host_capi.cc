@@ -122,6 +122,15 @@ int spz_cubic_tail_probe(uint64_t* tab, size_t ni, size_t m, const uint64_t* coe
   return (int)rounds;
 }
 // grid with `axes` axes (4^axes scalars) and one challenge per axis -> the 4 values s(0..3) each round sends (spark.inc: RoundGrid)
+int spz_eq_factor_probe(const uint64_t* rho, size_t nvars, size_t np, size_t ni, const uint64_t* coeffs, size_t nrounds, const uint64_t* claims,
+                        const uint64_t* ev4, const uint64_t* challenges, uint64_t* evc_out, uint64_t* K_out) {
+  auto vec = [](const uint64_t* p, size_t n) { FqVec v(n); memcpy(v.data(), p, 32 * n); return v; };
+  FqVec evc, K;
+  if (!eq_factor_probe(vec(rho, nvars), np, ni, vec(coeffs, ni), vec(claims, nrounds), vec(ev4, 4 * ni * nrounds), vec(challenges, nrounds), &evc, &K)) return 0;
+  memcpy(evc_out, evc.data(), 32 * evc.size());
+  memcpy(K_out, K.data(), 32 * K.size());
+  return 1;
+}
 void spz_round_grid_probe(const uint64_t* F, int axes, const uint64_t* challenges, uint64_t* msgs) {
   FqVec f = limbs_vec(F, (size_t)1 << (2 * axes)), ch = limbs_vec(challenges, (size_t)axes), m;
   round_grid_probe(f, axes, ch, &m);

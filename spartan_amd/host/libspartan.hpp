@@ -51,6 +51,8 @@ struct Ctx {
 void unipoly_probe(const FqVec& evals, const Fq& r, FqVec* coeffs, FqVec* compressed, Fq* eval_at_r);  // test hook
 void cubic_coeffs_probe(const Fq S[12], const Fq& r, Fq ev[3]);                                                // test hook (spark.inc)
 void cubic_tail_probe(FqVec& tab, size_t ni, size_t m, const FqVec& coeffs, const FqVec& challenges, FqVec* evs);  // test hook (spark.inc)
+bool eq_factor_probe(const FqVec& rho, size_t np, size_t ni, const FqVec& coeffs, const FqVec& claims, const FqVec& ev4, const FqVec& challenges, FqVec* evc_out,
+                     FqVec* K_out);  // test hook (spark.inc)
 void round_grid_probe(const FqVec& F, int axes, const FqVec& challenges, FqVec* msgs);                                  // test hook (spark.inc)
 typedef int (*CommitGatherFn)(void* user, uint8_t* buf, size_t total, size_t off, size_t len);
 void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user);

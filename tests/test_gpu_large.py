@@ -131,6 +131,61 @@ def test_batched_cubic_sumcheck_large_matches_reference_arithmetic(ctx):
         t.free()
 
 
+def test_batched_cubic_sumcheck_with_the_eq_table_as_a_factor(ctx):
+    """k_cubic_eval_batched_eq / k_cubic_bind_eval_batched_eq (spartan_hip.h: sp_sumcheck_*_batched_eq) at 2^17: 3 product-circuit
+    instances that share an eq table and 2 generic instances. Per product-circuit instance the device must return
+    q(t) = sum_x A(t,x) B(t,x) C_original[x] at t = 0, 2 over the ORIGINAL eq table's leading entries (the table is never bound, and must
+    come back untouched), per generic instance the evaluations at t = 0, 1, 2, 3 of sumcheck.rs:290-357 (plus t = 1); A, B and the generic C
+    tables are bound as by the generic kernel. Then the hand-over: sp_table_scale_prefix. Python integers are the reference."""
+    from spartan_amd import capi
+    n = 1 << 17
+    rng = random.Random(777)
+    npar, nseq = 3, 2
+    ni = npar + nseq
+    A = [fast_scalars(rng, n) for _ in range(ni)]
+    B = [fast_scalars(rng, n) for _ in range(ni)]
+    Ceq = fast_scalars(rng, n)   # any table will do for the kernel's arithmetic: it only ever reads the leading entries
+    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
+    tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
+    tCeq, tCseq = up(ctx, Ceq), [up(ctx, c) for c in Cseq]
+    hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
+    hC = (vp * ni)(*([tCeq.h] * npar + [t.h for t in tCseq]))
+    line = lambda u, v, t: (u + t * (v - u)) % Q
+
+    def want(A, B, Cseq):
+        h = len(A[0]) // 2
+        w = []
+        for k in range(ni):
+            if k < npar:
+                w += [sum(line(A[k][z], A[k][h + z], t) * line(B[k][z], B[k][h + z], t) * Ceq[z] for z in range(h)) % Q for t in (0, 2)] + [0, 0]
+            else:
+                c = Cseq[k - npar]
+                w += [sum(line(A[k][z], A[k][h + z], t) * line(B[k][z], B[k][h + z], t) * line(c[z], c[h + z], t) for z in range(h)) % Q for t in range(4)]
+        return w
+    out = (ctypes.c_uint64 * (16 * ni))()
+    assert capi.lib.sp_sumcheck_eval_batched_eq(ctx.h, hA, hB, hC, sz(ni), sz(npar), out) == 0
+    assert from_mont_bulk(out, 4 * ni) == want(A, B, Cseq)
+    r = rng.getrandbits(251)
+    A = [bind(a, r) for a in A]; B = [bind(b, r) for b in B]; Cseq = [bind(c, r) for c in Cseq]
+    assert capi.lib.sp_sumcheck_bind_eval_batched_eq(ctx.h, hA, hB, hC, sz(ni), sz(npar), fq1(r), out) == 0   # 2^17 -> 2^16
+    assert from_mont_bulk(out, 4 * ni) == want(A, B, Cseq)
+    ln = n // 2
+    assert len(tA[0]) == ln and len(tCseq[0]) == ln and len(tCeq) == n
+    assert from_mont_bulk(tA[1].download(ln), ln) == A[1] and from_mont_bulk(tB[4].download(ln), ln) == B[4]
+    assert from_mont_bulk(tCseq[1].download(ln), ln) == Cseq[1]
+    assert from_mont_bulk(tCeq.download(n), n) == Ceq          # read, never written
+    r2 = rng.getrandbits(250)
+    A = [bind(a, r2) for a in A]; B = [bind(b, r2) for b in B]; Cseq = [bind(c, r2) for c in Cseq]
+    assert capi.lib.sp_sumcheck_bind_eval_batched_eq(ctx.h, hA, hB, hC, sz(ni), sz(npar), fq1(r2), out) == 0  # 2^16 -> 2^15: the last factored length
+    assert from_mont_bulk(out, 4 * ni) == want(A, B, Cseq)
+    assert capi.lib.sp_sumcheck_bind_eval_batched_eq(ctx.h, hA, hB, hC, sz(ni), sz(npar), fq1(r2), out) != 0  # below 65536 entries: no factored form
+    k = rng.getrandbits(249)
+    assert capi.lib.sp_table_scale_prefix(ctx.h, tCeq.h, sz(n // 4), fq1(k)) == 0
+    assert len(tCeq) == n // 4 and from_mont_bulk(tCeq.download(n // 4), n // 4) == [x * k % Q for x in Ceq[:n // 4]]
+    for t in tA + tB + tCseq + [tCeq]:
+        t.free()
+
+
 def test_dot_many_dot3_hash_layer_gather_large(ctx):
     """HashLayerProof::prove's shared-chi evaluations (sparse_mlpoly.rs:722-835 -> k_dot_many), DotProductCircuit::evaluate
     (product_tree.rs:84-88 -> k_dot3), Layers::build_hash_layer (sparse_mlpoly.rs:529-604 -> k_hash_layer) and

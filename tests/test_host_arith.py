@@ -286,3 +286,71 @@ def test_several_encodes_at_once_equal_single_encodes(hc, orc):
         assert orc.orc_pt_add(acc, pts[i], o2) == 1
         acc = bytes(o2)
         assert bytes(many)[32 * i:32 * i + 32] == acc
+
+
+def test_eq_table_as_a_factor_host_arithmetic():
+    """spark.inc EqFactor: in the throughput-sized rounds of prove_cubic_batched (sumcheck.rs:287-393) under
+    ProductCircuitEvalProofBatched::prove the device returns, per product-circuit instance, q(0) and q(2) of the QUADRATIC
+    q(t) = sum_x A(t,x) B(t,x) C_original[x] (the eq table never bound) and four evaluations of each generic instance; the host
+    rebuilds the round's E(0), E(2), E(3) from them, the round's claim and the eq point. Here the "device" is Python: every round of
+    a whole sum-check on random tables is computed both ways — the generic sums over tables actually bound, as the reference does,
+    and the factored sums pushed through the host arithmetic — and must agree; the hand-over scalar times the original table must
+    be the bound eq table."""
+    import ctypes, random
+    from spartan_amd import prover
+    rng = random.Random(99)
+    nv, np_, ns = 5, 3, 2
+    ni = np_ + ns
+    n = 1 << nv
+    rho = [rng.randrange(2, Q) for _ in range(nv)]
+    C = [1]
+    for r in rho:  # EqPolynomial::evals (dense_mlpoly.rs:68-84): r[0] is the most significant index bit
+        C = [x * y % Q for x in C for y in ((1 - r) % Q, r)]
+    A = [[rng.randrange(Q) for _ in range(n)] for _ in range(ni)]
+    B = [[rng.randrange(Q) for _ in range(n)] for _ in range(ni)]
+    Cg = [[rng.randrange(Q) for _ in range(n)] for _ in range(ns)]  # the generic instances' own third tables
+    coeffs = [rng.randrange(Q) for _ in range(ni)]
+    line = lambda u, v, t: (u + t * (v - u)) % Q
+    def generic_evals(a, b, c):  # sumcheck.rs:290-357 for one instance: t = 0, 1, 2, 3
+        h = len(a) // 2
+        return [sum(line(a[z], a[h + z], t) * line(b[z], b[h + z], t) * line(c[z], c[h + z], t) for z in range(h)) % Q for t in range(4)]
+    bind = lambda T, r: [(T[z] + r * (T[len(T) // 2 + z] - T[z])) % Q for z in range(len(T) // 2)]
+    Cb = list(C)
+    claim = sum(coeffs[i] * sum(A[i][x] * B[i][x] * (C[x] if i < np_ else Cg[i - np_][x]) for x in range(n)) for i in range(ni)) % Q
+    claims, ev4, chal, want = [], [], [], []
+    for j in range(nv):
+        h = len(A[0]) // 2
+        per = []
+        E = [0, 0, 0, 0]
+        for i in range(ni):
+            g = generic_evals(A[i], B[i], Cb if i < np_ else Cg[i - np_])
+            for t in range(4):
+                E[t] = (E[t] + coeffs[i] * g[t]) % Q
+            if i < np_:  # what the factored kernel returns: sums against the ORIGINAL eq table's leading entries
+                q = [sum(line(A[i][z], A[i][h + z], t) * line(B[i][z], B[i][h + z], t) * C[z] for z in range(h)) % Q for t in (0, 2)]
+                per += [q[0], q[1], 0, 0]
+            else:
+                per += g
+        assert (E[0] + E[1]) % Q == claim
+        claims.append(claim); ev4 += per; want += [E[0], E[2], E[3]]
+        r = rng.randrange(Q)
+        chal.append(r)
+        # the next claim: the round's cubic at r (UniPoly::evaluate): Lagrange over t = 0, 1, 2, 3
+        inv = lambda x: pow(x, Q - 2, Q)
+        L = [(-(r - 1) * (r - 2) * (r - 3) * inv(6)), (r * (r - 2) * (r - 3) * inv(2)), (-r * (r - 1) * (r - 3) * inv(2)), (r * (r - 1) * (r - 2) * inv(6))]
+        claim = sum(L[t] * E[t] for t in range(4)) % Q
+        A = [bind(T, r) for T in A]; B = [bind(T, r) for T in B]; Cg = [bind(T, r) for T in Cg]; Cb = bind(Cb, r)
+        want_K = None
+    evc = (ctypes.c_uint64 * (4 * 3 * nv))(); Ks = (ctypes.c_uint64 * (4 * nv))()
+    assert prover.H.spz_eq_factor_probe(mont_array(rho), sz(nv), sz(np_), sz(ni), mont_array(coeffs), sz(nv), mont_array(claims), mont_array(ev4),
+                                        mont_array(chal), evc, Ks) == 1
+    assert from_mont_array(evc, 3 * nv) == want
+    # hand-over: after j binds, K_j * C_original[x] = the eq table bound at the first j challenges, for every x below the bound length
+    K = from_mont_array(Ks, nv)
+    Cb = list(C)
+    for j in range(nv):
+        Cb = bind(Cb, chal[j])
+        assert all(K[j] * C[x] % Q == Cb[x] for x in range(len(Cb))), j
+    # a coordinate equal to 0 or 1 has no factored form: the driver must fall back to the generic kernels
+    assert prover.H.spz_eq_factor_probe(mont_array([1] + rho[1:]), sz(nv), sz(np_), sz(ni), mont_array(coeffs), sz(nv), mont_array(claims), mont_array(ev4),
+                                        mont_array(chal), evc, Ks) == 0
