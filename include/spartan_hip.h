@@ -313,11 +313,19 @@ int32_t sp_gather(sp_ctx* ctx, const sp_table* mem, const sp_index* addr, sp_tab
  * addr == NULL means the identity (addr[i] = i); ts == NULL means 0. */
 int32_t sp_hash_layer(sp_ctx* ctx, const sp_table* addr, const sp_table* val, const sp_table* ts, int ts_inc, size_t n,
                       const uint64_t r_hash[4], const uint64_t r_multiset[4], sp_table* dst, size_t dst_off);
+/* The same leaves AND the first multiplication layer of ProductCircuit::new (product_tree.rs:36-56: layer 1 [i] = leaf[i] * leaf[i + n/2], at
+ * offset n of a 2n-element circuit store) in one pass, n >= 4: the first layer does not re-read the leaves. dst_write != NULL (ts_inc must be
+ * 0): also the circuit of the WRITE set of the same matrix — its leaves are those of the read set with ts + 1 (sparse_mlpoly.rs:572-598), i.e.
+ * plus r_hash^2 — from the same pass over addr, val, ts. The remaining layers: sp_product_tree_many_from(.., layers_done = 1). */
+int32_t sp_hash_layer_first(sp_ctx* ctx, const sp_table* addr, const sp_table* val, const sp_table* ts, int ts_inc, size_t n,
+                            const uint64_t r_hash[4], const uint64_t r_multiset[4], sp_table* dst, sp_table* dst_write);
 /* ProductCircuit::new (product_tree.rs:36-56). `store` has 2n elements with the n leaves in [0,n); layer k
  * (n/2^k elements, left half then right half) is written at offset 2n - 2n/2^k for k = 1..log2(n)-1. */
 int32_t sp_product_tree(sp_ctx* ctx, sp_table* store, size_t n);
 /* The same for `count` circuits of equal size n, one launch per layer for all of them. */
 int32_t sp_product_tree_many(sp_ctx* ctx, sp_table* const* stores, size_t count, size_t n);
+/* The same, starting above the layers already present: layers_done = 0 (all of them) or 1 (layer 1 was written by sp_hash_layer_first). */
+int32_t sp_product_tree_many_from(sp_ctx* ctx, sp_table* const* stores, size_t count, size_t n, size_t layers_done);
 /* prove_cubic_batched evaluations (sumcheck.rs:287-357): for each instance k, the sums of A_k*B_k*C_k at
  * t = 0, 2, 3 over the current length -> out[4*(3k + {0,1,2})]. Tables may repeat across instances. */
 int32_t sp_sumcheck_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, uint64_t* out);

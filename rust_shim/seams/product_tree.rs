@@ -8,9 +8,10 @@ use super::gpu::{self, sp_table};
 impl ProductCircuit {
   /// ProductCircuit::new (:36-56) for every circuit of one size at once: one launch per layer for all of them, the short
   /// layers in a single launch (sp_product_tree_many). `stores[i]` holds circuit i's leaves in [0, n).
-  pub fn new_many(stores: Vec<gpu::Table>, n: usize) -> Vec<ProductCircuit> {
+  /// layers_done: 1 when layer 1 is already in the stores (sp_hash_layer_first), else 0.
+  pub fn new_many(stores: Vec<gpu::Table>, n: usize, layers_done: usize) -> Vec<ProductCircuit> {
     let hs: Vec<*mut sp_table> = stores.iter().map(|t| t.0).collect();
-    gpu::ok(unsafe { gpu::sp_product_tree_many(gpu::ctx(), hs.as_ptr(), hs.len(), n) });
+    gpu::ok(unsafe { gpu::sp_product_tree_many_from(gpu::ctx(), hs.as_ptr(), hs.len(), n, layers_done) });
     stores.into_iter().map(|store| {
       let num_layers = n.log_2();
       let (mut left_vec, mut right_vec) = (Vec::new(), Vec::new());

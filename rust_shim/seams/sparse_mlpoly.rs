@@ -109,17 +109,40 @@ impl Layers {
       store
     };
     let null = std::ptr::null::<sp_table>();
-    let init = leaves(null, eval_table.0, null, 0, cells);
     let n_ops = at.ops_addr[0].len();
+    // the hash layer writes the first multiplication layer too, and the read and write sets of a matrix (ts, ts + 1) come out of one pass
+    // (sp_hash_layer_first); SPARTAN_NO_HASH_FUSE=1: the separate launches. Mechanical call sequence (spark.inc layers_new is the twin).
+    let fuse = gpu::hash_fuse_enabled() && cells >= 4 && n_ops >= 4;
+    // leaves [0, n) and layer 1 [n, n + n/2) of `store` (and of `store_w`, the write set: ts + 1) in one pass
+    let first = |addr: *const sp_table, val: *const sp_table, ts: *const sp_table, n: usize, with_write: bool| -> (gpu::Table, Option<gpu::Table>) {
+      let store = gpu::Table::alloc_uninit(2 * n);
+      let store_w = if with_write { Some(gpu::Table::alloc_uninit(2 * n)) } else { None };
+      let pw = store_w.as_ref().map_or(std::ptr::null_mut(), |t| t.0);
+      gpu::ok(unsafe { gpu::sp_hash_layer_first(c, addr, val, ts, 0, n, gpu::limbs1(r_hash), gpu::limbs1(r_multiset), store.0, pw) });
+      (store, store_w)
+    };
     let (mut reads, mut writes) = (Vec::new(), Vec::new());
-    for k in 0..at.ops_addr.len() {
-      reads.push(leaves(dev(&at.ops_addr[k]), dev(&poly_ops_val[k]), dev(&at.read_ts[k]), 0, n_ops));
-      writes.push(leaves(dev(&at.ops_addr[k]), dev(&poly_ops_val[k]), dev(&at.read_ts[k]), 1, n_ops));
+    let (init, audit);
+    if fuse {
+      init = first(null, eval_table.0, null, cells, false).0;
+      for k in 0..at.ops_addr.len() {
+        let (rd, wr) = first(dev(&at.ops_addr[k]), dev(&poly_ops_val[k]), dev(&at.read_ts[k]), n_ops, true);
+        reads.push(rd);
+        writes.push(wr.unwrap());
+      }
+      audit = first(null, eval_table.0, dev(&at.audit_ts), cells, false).0;
+    } else {
+      init = leaves(null, eval_table.0, null, 0, cells);
+      for k in 0..at.ops_addr.len() {
+        reads.push(leaves(dev(&at.ops_addr[k]), dev(&poly_ops_val[k]), dev(&at.read_ts[k]), 0, n_ops));
+        writes.push(leaves(dev(&at.ops_addr[k]), dev(&poly_ops_val[k]), dev(&at.read_ts[k]), 1, n_ops));
+      }
+      audit = leaves(null, eval_table.0, dev(&at.audit_ts), 0, cells);
     }
-    let audit = leaves(null, eval_table.0, dev(&at.audit_ts), 0, cells);
-    let mut mem = ProductCircuit::new_many(vec![init, audit], cells); // sp_product_tree_many
+    let done = if fuse { 1 } else { 0 };
+    let mut mem = ProductCircuit::new_many(vec![init, audit], cells, done); // sp_product_tree_many_from
     let nr = reads.len();
-    let mut ops = ProductCircuit::new_many(reads.into_iter().chain(writes).collect(), n_ops);
+    let mut ops = ProductCircuit::new_many(reads.into_iter().chain(writes).collect(), n_ops, done);
     let write_vec = ops.split_off(nr);
     let audit = mem.pop().unwrap();
     Layers { prod_layer: ProductLayer { init: mem.pop().unwrap(), read_vec: ops, write_vec, audit } }

@@ -19,6 +19,34 @@ __global__ void __launch_bounds__(256) k_hash_layer(const Fq* __restrict__ addr,
     st_fq(dst + i, fq_sub(h, r_multiset));
   }
 }
+// The leaves AND the first multiplication layer of a product circuit in one pass (round 4): thread i hashes leaves i and i + n/2 and
+// multiplies them (ProductCircuit::new, product_tree.rs:36-56: layer 1 [i] = leaf[i] * leaf[i + n/2], stored at offset n of the circuit's
+// store) — the first layer no longer re-reads the 32 n bytes of leaves the hash layer has just written. PAIR: the read and the write set of
+// one matrix differ by ts + 1 only (sparse_mlpoly.rs:572-598), i.e. by r_hash^2 per leaf: both circuits from one pass over addr, val, ts.
+template <bool PAIR>
+__global__ void __launch_bounds__(256) k_hash_layer_first(const Fq* __restrict__ addr, const Fq* __restrict__ val, const Fq* __restrict__ ts, int ts_inc,
+                                                          size_t n, Fq r_hash, Fq r_hash_sqr, Fq r_multiset, Fq* __restrict__ dst_a, Fq* __restrict__ dst_b) {
+  const size_t half = n / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    Fq h[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const size_t j = i + (size_t)k * half;
+      Fq a = addr ? ld_fq(addr + j) : fq_from_u64((uint64_t)j);
+      Fq t = ts ? ld_fq(ts + j) : fq_zero();
+      if (ts_inc) t = fq_add(t, fq_one());
+      h[k] = fq_sub(fq_add(fq_add(fq_mul(t, r_hash_sqr), fq_mul(ld_fq(val + j), r_hash)), a), r_multiset);
+      st_fq(dst_a + j, h[k]);
+    }
+    st_fq(dst_a + n + i, fq_mul(h[0], h[1]));
+    if (PAIR) {
+      Fq w0 = fq_add(h[0], r_hash_sqr), w1 = fq_add(h[1], r_hash_sqr);  // (ts + 1) r^2 + val r + addr - gamma
+      st_fq(dst_b + i, w0);
+      st_fq(dst_b + half + i, w1);
+      st_fq(dst_b + n + i, fq_mul(w0, w1));
+    }
+  }
+}
 __global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, size_t half, Fq* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
     st_fq(out + i, fq_mul(ld_fq(in + i), ld_fq(in + half + i)));
@@ -682,6 +710,26 @@ int32_t sp_hash_layer(sp_ctx* c, const sp_table* addr, const sp_table* val, cons
                      (const Fq*)val->d, ts ? (const Fq*)ts->d : (const Fq*)nullptr, ts_inc, n, rh, rh2, rm, dst->d + dst_off);
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
+// leaves [0, n) and layer 1 [n, n + n/2) of dst (and, dst_write != NULL, of the write-set circuit of the same matrix: ts + 1) in one pass;
+// the rest of the tree: sp_product_tree_many_from(.., 1)
+int32_t sp_hash_layer_first(sp_ctx* c, const sp_table* addr, const sp_table* val, const sp_table* ts, int ts_inc, size_t n, const uint64_t r_hash[4],
+                            const uint64_t r_multiset[4], sp_table* dst, sp_table* dst_write) {
+  if (!c || !val || !dst || !r_hash || !r_multiset || n < 4 || !is_pow2(n) || val->cap < n || (addr && addr->cap < n) || (ts && ts->cap < n) ||
+      dst->cap < 2 * n || (dst_write && (dst_write->cap < 2 * n || dst_write == dst || ts_inc != 0)))
+    return SP_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  Fq rh = limbs(r_hash), rm = limbs(r_multiset);
+  Fq rh2 = fq_mul(rh, rh);
+  ProfScope ps(c, PF_SPARK, 32.0 * (double)n * ((dst_write ? 3.0 : 1.5) + (addr ? 1 : 0) + (ts ? 1 : 0) + 1));
+  const Fq* pa = addr ? (const Fq*)addr->d : (const Fq*)nullptr;
+  const Fq* pt = ts ? (const Fq*)ts->d : (const Fq*)nullptr;
+  if (dst_write)
+    hipLaunchKernelGGL(k_hash_layer_first<true>, dim3((unsigned)grid_for(n / 2)), dim3(256), 0, c->stream, pa, (const Fq*)val->d, pt, 0, n, rh, rh2, rm, dst->d, dst_write->d);
+  else
+    hipLaunchKernelGGL(k_hash_layer_first<false>, dim3((unsigned)grid_for(n / 2)), dim3(256), 0, c->stream, pa, (const Fq*)val->d, pt, ts_inc, n, rh, rh2, rm, dst->d,
+                       (Fq*)nullptr);
+  return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
+}
 int32_t sp_product_tree(sp_ctx* c, sp_table* store, size_t n) {
   if (!c || !store || !is_pow2(n) || n < 2 || store->cap < 2 * n) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
@@ -696,8 +744,10 @@ int32_t sp_product_tree(sp_ctx* c, sp_table* store, size_t n) {
   return hipGetLastError() == hipSuccess ? SP_OK : SP_EHIP;
 }
 
-int32_t sp_product_tree_many(sp_ctx* c, sp_table* const* stores, size_t count, size_t n) {
-  if (!c || !stores || count == 0 || !is_pow2(n) || n < 2) return SP_EINVAL;
+int32_t sp_product_tree_many(sp_ctx* c, sp_table* const* stores, size_t count, size_t n) { return sp_product_tree_many_from(c, stores, count, n, 0); }
+// layers_done: 0, or 1 when layer 1 is already in the stores (sp_hash_layer_first)
+int32_t sp_product_tree_many_from(sp_ctx* c, sp_table* const* stores, size_t count, size_t n, size_t layers_done) {
+  if (!c || !stores || count == 0 || !is_pow2(n) || n < 2 || layers_done > 1 || (layers_done == 1 && n < 4)) return SP_EINVAL;
   for (size_t k = 0; k < count; k++)
     if (!stores[k] || stores[k]->cap < 2 * n) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
@@ -706,6 +756,7 @@ int32_t sp_product_tree_many(sp_ctx* c, sp_table* const* stores, size_t count, s
     Stores16 st;
     for (size_t k = 0; k < 16; k++) st.p[k] = k < nk ? stores[k0 + k]->d : nullptr;
     size_t off = 0, len = n;
+    if (layers_done == 1) { off = n; len = n / 2; }
     while (len > 2) {
       size_t half = len / 2, noff = off + len;
       ProfScope ps(c, PF_SPARK, 48.0 * (double)len * (double)nk);

@@ -319,6 +319,34 @@ def test_bind_top_heads_product_tree_many_and_round_body(ctx, orc, gens40):
             assert got[off:off + half] == nxt
             layer = nxt
         t.free()
+    # --- hash layer + first multiplication layer in one pass, read and write set of a matrix together (sp_hash_layer_first), then the rest of
+    # the tree (sp_product_tree_many_from .. 1): Layers::build_hash_layer (sparse_mlpoly.rs:529-604) and ProductCircuit::new in Python
+    for n in (4, 64, 8192):   # 8192: above the one-launch tail (2048), so layer 2 comes from the per-layer kernel
+        addr, val, ts = [rng.randrange(n) for _ in range(n)], rand_scalars(rng, n), [rng.randrange(50) for _ in range(n)]
+        rh, rm = rng.randrange(Q), rng.randrange(Q)
+        hashed = lambda a, v, t: (t * rh * rh + v * rh + a - rm) % Q
+        want_r = [hashed(addr[i], val[i], ts[i]) for i in range(n)]
+        want_w = [hashed(addr[i], val[i], ts[i] + 1) for i in range(n)]
+        want_i = [hashed(i, val[i], 0) for i in range(n)]   # init: addr = identity, ts = 0 (:572-584)
+        ta, tv, tt = capi.Table.upload(ctx, mont_array(addr), n), capi.Table.upload(ctx, mont_array(val), n), capi.Table.upload(ctx, mont_array(ts), n)
+        st = [capi.Table.upload(ctx, mont_array([0] * (2 * n)), 2 * n) for _ in range(3)]
+        assert capi.lib.sp_hash_layer_first(ctx.h, ta.h, tv.h, tt.h, 0, sz(n), mont_array([rh]), mont_array([rm]), st[0].h, st[1].h) == 0
+        assert capi.lib.sp_hash_layer_first(ctx.h, None, tv.h, None, 0, sz(n), mont_array([rh]), mont_array([rm]), st[2].h, None) == 0
+        assert capi.lib.sp_hash_layer_first(ctx.h, ta.h, tv.h, tt.h, 1, sz(n), mont_array([rh]), mont_array([rm]), st[0].h, st[1].h) != 0   # a pair is ts and ts + 1
+        assert capi.lib.sp_product_tree_many_from(ctx.h, (vp * 3)(*[t.h for t in st]), sz(3), sz(n), sz(1)) == 0
+        for leaves_, t in zip((want_r, want_w, want_i), st):
+            got = from_mont_array(t.download(), 2 * n)
+            assert got[:n] == leaves_
+            layer, off = leaves_, 0
+            while len(layer) > 2:
+                half = len(layer) // 2
+                nxt = [layer[i] * layer[half + i] % Q for i in range(half)]
+                off += len(layer)
+                assert got[off:off + half] == nxt, (n, off)
+                layer = nxt
+            t.free()
+        for t in (ta, tv, tt):
+            t.free()
     # --- ZK round body: bind+evaluate and two small commitments in one call == the two calls made separately
     ell = 9
     A = [rand_scalars(rng, 1 << ell) for _ in range(4)]
