@@ -789,6 +789,9 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
       av = ipa_fold_a(A.a, x, A.n_cur, A.fold, A.u, A.u_inv);
       bv = ipa_fold_b(A.b, x, A.n_cur, A.fold, A.u, A.u_inv);
       if (A.fold) { st_fq(A.a_new + x, av); st_fq(A.b_new + x, bv); }
+      // the last round (two entries left): a', b' also go to the host page, behind the dot-product slots — with them, the round's two raw row
+      // sums and the last challenge the calling thread finishes the argument itself (ipa.hip, sp_ipa_finish_commit)
+      if (A.n_cur == 2) { st_fq(A.dots_out + 8 + x, av); st_fq(A.dots_out + 10 + x, bv); }
     }
     if (A.fold)
       for (size_t p = (size_t)db * 256 + t; p < A.n0 / A.n_cur; p += (size_t)A.nd * 256)
@@ -896,7 +899,7 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
   A->nblk = (unsigned)((P + 255) / 256);
   const size_t qlen = A->n_cur >= 4 ? A->n_cur / 4 : 1;
   A->nd = (unsigned)((qlen + 63) / 64);
-  if (1024 + (size_t)A->nd * 8 * 32 > HOST_SUM_BYTES) return SP_EINVAL;  // the dot-product partials share the host page with the two row sums (n_cur <= 16384)
+  if (1024 + ((size_t)A->nd * 8 + 4) * 32 > HOST_SUM_BYTES) return SP_EINVAL;  // the dot-product partials share the host page with the two row sums (n_cur <= 16384)
   SPCHK(ensure(&c->scratch, &c->scratch_cap, sizeof(Pt10) * 2 * (size_t)A->nblk + 256));
   A->part = (Pt10*)c->scratch;
   A->sums_out = (Pt*)hres(c);

@@ -27,6 +27,11 @@ struct sp_ipa {
   unsigned pre_nd = 0;
   Fq pre_cL, pre_cR;
   struct IpaRoundArgs* last_args = nullptr;  // the arguments of the round in flight (owned): a row sum with Z = 0 re-runs them with the unified tree
+  // what the LAST round (two entries) left on the host: its vectors a', b' and its two row sums without the c Q + blind H tails,
+  //   raw[0] = a'[0] * G'_R,  raw[1] = a'[1] * G'_L   (G'_L, G'_R: the two folded generators the reference holds at that point, bullet.rs:108)
+  bool have_fin = false;
+  Fq fin_a[2], fin_b[2];
+  Pt fin_raw[2];
 };
 // core.hip
 struct IpaRoundArgs {
@@ -370,6 +375,12 @@ static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uin
   uint8_t enc[64];
   pt_compress_many(lr, 2, enc);  // L and R together: two interleaved inverse-square-root chains (curve.hpp)
   memcpy(L_out, enc, 32); memcpy(R_out, enc + 32, 32);
+  if (ipa->n_cur == 2) {
+    const Fq* fin = (const Fq*)(hres(c) + 1024) + 8;
+    ipa->fin_a[0] = fin[0]; ipa->fin_a[1] = fin[1]; ipa->fin_b[0] = fin[2]; ipa->fin_b[1] = fin[3];
+    memcpy(ipa->fin_raw, sums, 2 * sizeof(Pt));
+    ipa->have_fin = true;
+  }
   if (ipa->n_cur >= 4) {
     const Fq* dp = (const Fq*)(hres(c) + 1024);
     for (int k = 0; k < 8; k++) {
@@ -455,8 +466,60 @@ int32_t sp_ipa_finish(sp_ipa* ipa, uint64_t a_hat[4], uint64_t b_hat[4], uint8_t
 }
 // sp_ipa_finish and sp_ipa_commit_ghat in one trip: delta = commit(d, r) under {g_hat, h} does not depend on a_hat, b_hat
 // (nizk/mod.rs:498-503 computes y_hat from them only afterwards), so its launches go out first and the two scalars ride along.
+// k1 * P1 + k2 * P2 for two points that are NOT fixed generators (host core; Straus with plain 4-bit windows: 252 doublings, <= 128
+// additions, ~35 us). The one place the prover multiplies a variable base: see sp_ipa_finish_commit.
+static Pt pt_var_msm2(const Pt& P1, const Fq& k1_mont, const Pt& P2, const Fq& k2_mont) {
+  const Fq k1 = fq_from_mont(k1_mont), k2 = fq_from_mont(k2_mont);
+  Pt T1[16], T2[16];
+  T1[0] = T2[0] = pt_identity();
+  T1[1] = P1; T2[1] = P2;
+  for (int i = 2; i < 16; i++) {
+    T1[i] = (i & 1) ? pt_add(T1[i - 1], P1) : pt_dbl(T1[i / 2]);
+    T2[i] = (i & 1) ? pt_add(T2[i - 1], P2) : pt_dbl(T2[i / 2]);
+  }
+  Pt acc = pt_identity();
+  bool started = false;
+  for (int w = 63; w >= 0; w--) {
+    if (started) { acc = pt_dbl(pt_dbl(pt_dbl(pt_dbl(acc)))); }
+    const unsigned n1 = (unsigned)(k1.l[w / 16] >> (4 * (w % 16))) & 15, n2 = (unsigned)(k2.l[w / 16] >> (4 * (w % 16))) & 15;
+    if (n1) { acc = pt_add(acc, T1[n1]); started = true; }
+    if (n2) { acc = pt_add(acc, T2[n2]); started = true; }
+  }
+  return acc;
+}
+// The end of the argument on the calling thread's core (round 4). After the last round the reference holds two folded generators G'_L, G'_R and
+// forms g_hat = u^-1 G'_L + u G'_R (bullet.rs:108), then commits delta = d g_hat + r_delta h (nizk/mod.rs:496-501). Here the folded generators
+// are never built — but the last round's row sums ARE multiples of them: raw[0] = a'[0] G'_R, raw[1] = a'[1] G'_L. So
+//     delta = (d u / a'[0]) raw[0] + (d u^-1 / a'[1]) raw[1] + r_delta h,     a_hat = a'[0] u + u^-1 a'[1],   b_hat = b'[0] u^-1 + u b'[1],
+// a two-point multi-scalar multiplication over points the host already holds: ~45 us of host arithmetic instead of a scalar-row kernel plus a
+// 78 000-lookup commitment kernel and their trip (~140 us), four times per SNARK proof. Same group element, same bytes
+// (tests/test_gpu_large.py compares with the device path). Falls back to the device when a'[0] or a'[1] is zero (no such multiple),
+// when the round ran unfused, or with SPARTAN_IPA_FINISH_DEVICE=1 (the A/B switch).
+static bool ipa_finish_on_host(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint64_t a_hat[4], uint64_t b_hat[4], uint8_t delta_out[32]) {
+  static const bool off = getenv("SPARTAN_IPA_FINISH_DEVICE") != nullptr;
+  if (off || !ipa->have_fin || !ipa->fold_pending || ipa->ctx->device_encode) return false;
+  const Fq &a0 = ipa->fin_a[0], &a1 = ipa->fin_a[1], &b0 = ipa->fin_b[0], &b1 = ipa->fin_b[1], &u = ipa->fu, &ui = ipa->fu_inv;
+  if (fq_is_zero(a0) || fq_is_zero(a1)) return false;
+  Fq dd, rr;
+  memcpy(dd.l, d, 32); memcpy(rr.l, r, 32);
+  const Fq inv01 = fq_invert(fq_mul(a0, a1));               // one inversion for both (the values derive from the witness: the constant chain)
+  const Fq inv0 = fq_mul(inv01, a1), inv1 = fq_mul(inv01, a0);
+  const Fq k0 = fq_mul(fq_mul(dd, u), inv0), k1 = fq_mul(fq_mul(dd, ui), inv1);
+  Pt acc = pt_var_msm2(ipa->fin_raw[0], k0, ipa->fin_raw[1], k1);
+  const uint32_t hidx[1] = {(uint32_t)ipa->h_idx};
+  sp_host_point tail;
+  if (sp_host_commit_point(ipa->g, hidx, 1, rr.l, &tail) != SP_OK) return false;
+  Pt th;
+  memcpy(&th, &tail, sizeof(Pt));
+  pt_compress(pt_add(acc, th), delta_out);
+  const Fq ah = fq_add(fq_mul(a0, u), fq_mul(ui, a1)), bh = fq_add(fq_mul(b0, ui), fq_mul(u, b1));
+  memcpy(a_hat, ah.l, 32);
+  memcpy(b_hat, bh.l, 32);
+  return true;
+}
 int32_t sp_ipa_finish_commit(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint64_t a_hat[4], uint64_t b_hat[4], uint8_t delta_out[32]) {
   if (!ipa || !d || !r || !a_hat || !b_hat || !delta_out || ipa->n_cur != 1) return SP_EINVAL;
+  if (ipa_finish_on_host(ipa, d, r, a_hat, b_hat, delta_out)) return SP_OK;
   sp_ctx* c = ipa->ctx;
   HIPCHK(hipSetDevice(c->dev));
   // between the partial sums (< HOST_SUM_BYTES) and the row sums (last KiB) of the result page: msm_launch leaves it alone

@@ -351,11 +351,16 @@ def _ipa_against_folded_generators(ctx, orc, n, comp, a, b, rng):
         G = [msm([ui, u], [G[i], G[h + i]]) for i in range(h)]     # :108
         cur = h
     ah = (ctypes.c_uint64 * 4)(); bh = (ctypes.c_uint64 * 4)(); gh = (ctypes.c_uint8 * 32)()
+    d, r = rng.getrandbits(250), rng.getrandbits(250)
+    want_delta = msm([d, r], [G[0], P[n + 1]])                     # nizk/mod.rs:496-501
+    # the end of the argument in one call: on the calling thread's core from the last round's row sums (ipa.hip, ipa_finish_on_host) ...
+    assert capi.lib.sp_ipa_finish_commit(ipa, fq1(d), fq1(r), ah, bh, out) == 0
+    assert from_mont_bulk(ah, 1) == a and from_mont_bulk(bh, 1) == b and bytes(out) == want_delta
+    # ... and on the device (the fold applied, g_hat as a fixed-base row over all n generators)
     assert capi.lib.sp_ipa_finish(ipa, ah, bh, gh) == 0
     assert from_mont_bulk(ah, 1) == a and from_mont_bulk(bh, 1) == b and bytes(gh) == G[0]
-    d, r = rng.getrandbits(250), rng.getrandbits(250)
     assert capi.lib.sp_ipa_commit_ghat(ipa, fq1(d), fq1(r), out) == 0
-    assert bytes(out) == msm([d, r], [G[0], P[n + 1]])             # nizk/mod.rs:496-501
+    assert bytes(out) == want_delta
     capi.lib.sp_ipa_free(ipa)
     g.free()
 
