@@ -160,9 +160,10 @@ def kernel_source_digest():
 
 def concurrent_throughput(P, device, s, K, steps):
     """K independent SNARK::prove streams on ONE GPU (own context + host thread each; generator tables are shared). A
-    single proof is a chain of latency-bound launches, so a second proof fills the gaps of the first. Measured at 2^20:
-    K = 1 / 2 / 4 / 8 -> 19.3 / 29.8 / 23.2 / 24.4 M constraints/s (beyond two, the proofs' throughput MSMs and
-    background commits collide). Serving-style throughput; reported next to, never instead of, the single-proof `value`."""
+    single proof is a chain of latency-bound launches, so a second and a third proof fill the gaps of the first. Measured at 2^20
+    (bench/concurrent_probe.py, profiles/r4_concurrent_probe.txt): K = 1 / 2 / 3 / 4 -> 42.5 / 60.9 / 68.9 / 64.0 M constraints/s;
+    admitting one proof at a time to the throughput-bound part (SPARTAN_PROOF_GATE=1) changes nothing, so the MSMs colliding is not
+    what limits it. Serving-style throughput; reported next to, never instead of, the single-proof `value`. Runs K' = 2 .. K."""
     import threading
     N = 1 << s
     workers = []
@@ -178,17 +179,22 @@ def concurrent_throughput(P, device, s, K, steps):
             P.SNARK.prove(w[0], w[1], w[3], w[1].vars, w[1].inputs, w[2], b"snark_example", w[4])
     for w in workers:
         run(w, 1)
-    ths = [threading.Thread(target=run, args=(w, steps)) for w in workers]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
+    res = {}
+    for kk in range(2, K + 1):
+        ths = [threading.Thread(target=run, args=(w, steps)) for w in workers[:kk]]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        res[kk] = {"value": kk * steps * N / dt, "ms_per_proof_slot": dt / steps * 1e3}
     for w in workers:
         w[3].free(); w[2].free(); w[1].free(); w[0].close()
-    return {"proofs_in_flight": K, "value": K * steps * N / dt, "unit": "constraints/s", "ms_per_proof_slot": dt / steps * 1e3,
-            "note": "K host threads, one sp_ctx each, same GPU; each proof byte-identical to its single-stream run"}
+    best = max(res, key=lambda kk: res[kk]["value"])
+    return {"proofs_in_flight": best, "value": res[best]["value"], "unit": "constraints/s", "ms_per_proof_slot": res[best]["ms_per_proof_slot"],
+            "by_proofs_in_flight": {str(kk): round(v["value"]) for kk, v in res.items()},
+            "note": "K host threads, one sp_ctx each, same GPU; each proof byte-identical to its single-stream run; the best K of 2 .. %d is reported" % K}
 
 
 def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
@@ -209,7 +215,7 @@ def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
     for _ in range(2):
         e = P.SNARK.encode(ctx, inst, gens); e.free()
     dt = (time.perf_counter() - t0) / 2
-    out["snark_encode"] = {"ms": dt * 1e3, "note": "SNARK::encode: address lists laid out on the host, AddrTimestamps::new + two multi_commits on the device"}
+    out["snark_encode"] = {"ms": dt * 1e3, "note": "SNARK::encode: dense representation from the entry-order copies on the device, AddrTimestamps::new + two multi_commits on the device"}
     return out
 
 
@@ -265,7 +271,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=64, help="OpenMP threads of the all-cores CPU baseline (capped by the logical cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-metrics", action="store_true", help="skip the NIZK::prove / SNARK::encode side measurements")
-    ap.add_argument("--concurrent", type=int, default=2, help="also measure K independent proofs in flight on the GPU (0 = skip); reported separately, never as `value`")
+    ap.add_argument("--concurrent", type=int, default=3, help="also measure K independent proofs in flight on the GPU (0 = skip); reported separately, never as `value`")
     ap.add_argument("--shard-commits", action="store_true", help="N>1: one proof, row commitments sharded over the ranks + all-gather (strong scaling)")
     ap.add_argument("--strong-timeout", type=int, default=120, help="seconds the strong-scaling leg may take before the job prints what it has and exits")
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling leg (one sharded proof) that follows the replica measurement")
@@ -499,7 +505,8 @@ def main():
                        "fs_trips_per_proof": fs_trips,
                        "table_GB": {"gens_r1cs_sat": round(gens.table_bytes(0) / 1e9, 2), "gens_r1cs_eval": round(gens.table_bytes(1) / 1e9, 2),
                                     "window_bits": [gens.window_bits(0), gens.window_bits(1)]},
-                       "host_cores_busy": world, "host_note": "each proving thread spins on its completion flag and runs Merlin, the 2..5-term Sigma-protocol commitments and ~150 point encodes: one host core per GPU, flat out; a helper thread computes the tape-only halves of the ZK sum-checks' commitments ahead of the rounds (~0.5 ms of a second core per proof)"},
+                       "host_cores_busy": world, "host_note": "each proving thread spins on its completion flag and runs Merlin, the 2..5-term Sigma-protocol commitments, ~150 point encodes (in pairs), the challenge inversions and the end of every inner-product argument: one host core per GPU, flat out; a helper thread computes the tape-only halves of the ZK sum-checks' commitments ahead of the rounds (~0.5 ms of a second core per proof), another issues the witness upload",
+                       "host_keccak": P.keccak_variant()},
             "roofline": roofline,
             "kernel_ms_per_step": {n: round(v["ms"], 4) for n, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])},
             "gpu_busy_ms_per_step": round(gpu_ms_total, 3),

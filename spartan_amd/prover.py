@@ -151,6 +151,12 @@ def rccl_unique_id():
     return bytes(out)
 
 
+def keccak_variant():
+    """which form of Keccak-f[1600] the host driver picked for this CPU (keccak.cc): plain | bmi2 | avx512"""
+    H.spz_keccak_variant.restype = ctypes.c_char_p
+    return H.spz_keccak_variant().decode()
+
+
 def seed_scalar(domain, seed):
     """TEST/BENCH ONLY: the reproducible 64-bit-seed -> scalar map behind the RandomTape seeds of tests/ and bench.py. A real
     proof passes tape_seed=None (the tape is then seeded from OS entropy, like RandomTape::new, random.rs:13-15): a known or
