@@ -474,3 +474,35 @@ def test_small_commitments_on_host_core_or_device_and_resident_assignment_give_t
     onp = vp(orc.orc_nizk_prove(oi, ong, b"digest-10", sz(9), b"nizk_example", tape, None))
     assert all(p == oracle_bytes(orc, onp) for p in nizk)
     va.free(); ngens.free(); enc.free(); gens.free(); inst.free()
+
+
+def test_every_ab_switch_gives_the_same_proof(orc):
+    """Every optimisation of round 4's second half has an A/B switch that restores the form it replaced. All of them must give the oracle's
+    bytes: the eq table as a factor vs bound like any table (SPARTAN_NO_EQ_FACTOR), hash layers fused with the first multiplication layer
+    vs separate (SPARTAN_NO_HASH_FUSE), dedicated vs unified addition in the inner-product trees (SPARTAN_IPA_UNIFIED_TREE), the end of the
+    inner-product arguments on the proving core vs on the device (SPARTAN_IPA_FINISH_DEVICE), challenge inversion by division steps vs the
+    a^(q-2) chain (SPARTAN_INVERT_CHAIN), each Keccak-f form, the proof gate. One process per setting (tests/switch_worker.py) at 2^17 —
+    the smallest size with throughput-sized batched rounds — against the oracle's proof of the same instance and tape."""
+    import hashlib, os, subprocess, sys
+    s_, seed = 17, 5
+    N = 1 << s_
+    from spartan_amd import prover as P
+    tape = P.seed_scalar(b"tape", seed)
+    oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
+    og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
+    oe = vp(orc.orc_snark_encode(oi, og))
+    op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
+    want = hashlib.sha256(oracle_bytes(orc, op)).hexdigest()
+    settings = [{}, {"SPARTAN_NO_EQ_FACTOR": "1"}, {"SPARTAN_NO_HASH_FUSE": "1"}, {"SPARTAN_IPA_UNIFIED_TREE": "1"}, {"SPARTAN_IPA_FINISH_DEVICE": "1"},
+                {"SPARTAN_INVERT_CHAIN": "1"}, {"SPARTAN_KECCAK": "plain"}, {"SPARTAN_KECCAK": "bmi2"}, {"SPARTAN_KECCAK": "avx512"}, {"SPARTAN_PROOF_GATE": "1"},
+                {"SPARTAN_NO_EQ_FACTOR": "1", "SPARTAN_NO_HASH_FUSE": "1", "SPARTAN_IPA_UNIFIED_TREE": "1", "SPARTAN_IPA_FINISH_DEVICE": "1", "SPARTAN_INVERT_CHAIN": "1"}]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for st in settings:
+        e = dict(os.environ)
+        for k in ("SPARTAN_NO_EQ_FACTOR", "SPARTAN_NO_HASH_FUSE", "SPARTAN_IPA_UNIFIED_TREE", "SPARTAN_IPA_FINISH_DEVICE", "SPARTAN_INVERT_CHAIN", "SPARTAN_KECCAK", "SPARTAN_PROOF_GATE"):
+            e.pop(k, None)
+        e.update(st)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "switch_worker.py"), str(s_), str(seed)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (st, r.stdout[-2000:], r.stderr[-2000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("PROOF_SHA256")]
+        assert line and line[0].split()[1] == want, (st, line)
