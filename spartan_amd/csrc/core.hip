@@ -753,6 +753,7 @@ struct IpaRoundArgs {
   size_t n_cur, n0, g_off;
   int fold;
   Fq u, u_inv;
+  Fq u2, u2_inv;               // u^2, u^-2: the lookups' scalar a'[i] s'[p] in two multiplications (k_ipa_round)
   Pt10* part;                  // [2][nblk]
   uint32_t* counters;          // [2], zero between launches
   Pt* sums_out;                // host page: the two row sums
@@ -834,9 +835,17 @@ __global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* 
     const int w = (int)(p / cols);
     const size_t pb = q / h, i = q % h;
     const size_t gen = A.g_off + pb * A.n_cur + (row == 0 ? h + i : i);
-    Fq av = ipa_fold_a(A.a, row == 0 ? i : h + i, A.n_cur, A.fold, A.u, A.u_inv);
-    Fq sv = A.fold ? fq_mul(ld_fq(A.s + pb / 2), (pb & 1) ? A.u : A.u_inv) : ld_fq(A.s + pb);
-    Fq sc = fq_mul(av, sv);
+    // a'[x] s'[p] with the pending fold applied: (a_L u + a_R u^-1) * s[p/2] u^(+-1) = s[p/2] (a_L u^2 + a_R) for odd p, s[p/2] (a_L + a_R u^-2) for
+    // even p — two multiplications per lookup instead of four (the same field element)
+    const size_t x = row == 0 ? i : h + i;
+    Fq sc;
+    if (A.fold) {
+      const Fq aL = ld_fq(A.a + x), aR = ld_fq(A.a + A.n_cur + x);
+      const Fq t = (pb & 1) ? fq_add(fq_mul(aL, A.u2), aR) : fq_add(aL, fq_mul(aR, A.u2_inv));
+      sc = fq_mul(ld_fq(A.s + pb / 2), t);
+    } else {
+      sc = fq_mul(ld_fq(A.a + x), ld_fq(A.s + pb));
+    }
     SP_KT(kt0, 1);
     if (!fq_is_zero(sc)) {
       int d = msm_digit(fq_from_mont(sc), w, geom);

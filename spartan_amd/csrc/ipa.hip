@@ -40,6 +40,7 @@ struct IpaRoundArgs {
   size_t n_cur, n0, g_off;
   int fold;
   Fq u, u_inv;
+  Fq u2, u2_inv;               // u^2, u^-2: the lookups' scalar a'[i] s'[p] in two multiplications (k_ipa_round)
   Pt10* part;
   uint32_t* counters;
   Pt* sums_out;
@@ -314,6 +315,7 @@ static int32_t ipa_round_start(sp_ipa* ipa, Fq* cL_out, Fq* cR_out, DoneSig* sig
   A.n_cur = ipa->n_cur; A.n0 = ipa->n0; A.g_off = ipa->g_off;
   A.fold = ipa->fold_pending ? 1 : 0;
   A.u = ipa->fu; A.u_inv = ipa->fu_inv;
+  A.u2 = fq_mul(ipa->fu, ipa->fu); A.u2_inv = fq_mul(ipa->fu_inv, ipa->fu_inv);
   A.counters = ipa->counters;
   SPCHK(ipa_round_launch(c, ipa->g, &A, sig_out, 0));
   if (!ipa->last_args) ipa->last_args = new (std::nothrow) IpaRoundArgs();
