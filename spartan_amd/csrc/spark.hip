@@ -64,6 +64,20 @@ __global__ void __launch_bounds__(256) k_prod_layer_many(Stores16 st, size_t off
     st_fq(out + i, fq_mul(ld_fq(in + i), ld_fq(in + half + i)));
 }
 
+// TWO layers per launch for the middle of the tree (round 4): the layers between the streaming ones and the one-launch tail are a few
+// microseconds of work behind a launch each. Thread i reads the four entries i, i + q, i + 2q, i + 3q (q = len / 4) of layer k, writes
+// layer k+1 [i] = x0 x2 and [i + q] = x1 x3 (its pairs are (i, i + len/2)), and layer k+2 [i] = their product.
+__global__ void __launch_bounds__(256) k_prod_layer2_many(Stores16 st, size_t off, size_t len) {
+  const size_t q = len / 4, off1 = off + len, off2 = off1 + len / 2;
+  Fq* base = st.p[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+    const Fq x0 = ld_fq(base + off + i), x1 = ld_fq(base + off + q + i), x2 = ld_fq(base + off + 2 * q + i), x3 = ld_fq(base + off + 3 * q + i);
+    const Fq lo = fq_mul(x0, x2), hi = fq_mul(x1, x3);
+    st_fq(base + off1 + i, lo);
+    st_fq(base + off1 + q + i, hi);
+    st_fq(base + off2 + i, fq_mul(lo, hi));
+  }
+}
 // The short layers of the same circuits in ONE launch: from a layer of `len` <= 2048 elements down to the two roots, one
 // workgroup per circuit, each layer kept in LDS for the next (a 2^20-leaf tree has 10 such layers: ten launches of a few
 // microseconds each on the path to the first product_circuits_evaluate).
@@ -763,6 +777,14 @@ int32_t sp_product_tree_many_from(sp_ctx* c, sp_table* const* stores, size_t cou
       if (len <= 2048) {  // the remaining layers in one launch
         hipLaunchKernelGGL(k_prod_layer_tail, dim3((unsigned)nk), dim3(256), 0, c->stream, st, off, len);
         break;
+      }
+      static const bool two_layers = getenv("SPARTAN_NO_PROD_LAYER2") == nullptr;  // A/B switch
+      static const size_t l2max = [] { const char* e = getenv("SPARTAN_PROD_LAYER2_MAX_LOG2"); int v = e ? atoi(e) : 18; return (size_t)1 << (v < 13 ? 13 : (v > 40 ? 40 : v)); }();
+      if (two_layers && len <= l2max && len >= 8192) {  // launch-sized layers: two per launch (len / 4 >= 2048: the tail takes over below)
+        hipLaunchKernelGGL(k_prod_layer2_many, dim3((unsigned)grid_for(len / 4, 1024), (unsigned)nk), dim3(256), 0, c->stream, st, off, len);
+        off = off + len + len / 2;
+        len = len / 4;
+        continue;
       }
       hipLaunchKernelGGL(k_prod_layer_many, dim3((unsigned)grid_for(half, 1024), (unsigned)nk), dim3(256), 0, c->stream, st, off, half, noff);
       off = noff;

@@ -321,7 +321,7 @@ def test_bind_top_heads_product_tree_many_and_round_body(ctx, orc, gens40):
         t.free()
     # --- hash layer + first multiplication layer in one pass, read and write set of a matrix together (sp_hash_layer_first), then the rest of
     # the tree (sp_product_tree_many_from .. 1): Layers::build_hash_layer (sparse_mlpoly.rs:529-604) and ProductCircuit::new in Python
-    for n in (4, 64, 8192):   # 8192: above the one-launch tail (2048), so layer 2 comes from the per-layer kernel
+    for n in (4, 64, 8192, 65536):   # 8192: above the one-launch tail (2048), so layer 2 comes from the per-layer kernel; 65536: two layers per launch (k_prod_layer2_many)
         addr, val, ts = [rng.randrange(n) for _ in range(n)], rand_scalars(rng, n), [rng.randrange(50) for _ in range(n)]
         rh, rm = rng.randrange(Q), rng.randrange(Q)
         hashed = lambda a, v, t: (t * rh * rh + v * rh + a - rm) % Q
