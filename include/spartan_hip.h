@@ -143,6 +143,10 @@ int32_t sp_commit_rows_partial(sp_ctx* ctx, const sp_gens* g, size_t g_off, cons
 int32_t sp_host_points_sum_encode(const sp_host_point* pts, size_t nsets, size_t rows, uint8_t* out /*32*rows*/);
 /* The same arithmetic without a device or an sp_gens (CPU tests): npts encoded points, rows x npts scalars. */
 int32_t sp_host_commit_probe(const uint8_t* compressed /*32*npts*/, size_t npts, const uint64_t* S, size_t rows, uint8_t* out);
+/* Device-free form, for tests, of the one variable-base multiplication of the prover: k1 P1 + k2 P2 over two compressed points, encoded — the
+ * arithmetic with which sp_ipa_finish_commit ends an inner-product argument on the calling thread's core (delta = d g_hat + r_delta h of
+ * nizk/mod.rs:496-501 from the last round's two row sums, bullet.rs:108). SP_EPOINT for an invalid encoding. */
+int32_t sp_host_msm2_probe(const uint8_t p1[32], const uint64_t k1[4], const uint8_t p2[32], const uint64_t k2[4], uint8_t out[32]);
 /* Look-ahead for the zero-knowledge sum-checks. Inside their round loop nothing but DotProductProof::prove draws from the
  * random tape (d_vec, r_delta, r_beta: nizk/mod.rs:330-334), so a caller can take the draws of all rounds up front, in the
  * reference's order, and have a helper thread compute everything that depends on the tape alone while the rounds run:

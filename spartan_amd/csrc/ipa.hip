@@ -519,6 +519,16 @@ static bool ipa_finish_on_host(sp_ipa* ipa, const uint64_t d[4], const uint64_t 
   memcpy(b_hat, bh.l, 32);
   return true;
 }
+// Device-free form of the two-point variable-base multiplication for tests (the arithmetic behind ipa_finish_on_host): k1 P1 + k2 P2, encoded.
+int32_t sp_host_msm2_probe(const uint8_t p1[32], const uint64_t k1[4], const uint8_t p2[32], const uint64_t k2[4], uint8_t out[32]) {
+  if (!p1 || !k1 || !p2 || !k2 || !out) return SP_EINVAL;
+  Pt P1, P2;
+  if (!pt_decompress(p1, &P1) || !pt_decompress(p2, &P2)) return SP_EPOINT;
+  Fq a, b;
+  memcpy(a.l, k1, 32); memcpy(b.l, k2, 32);
+  pt_compress(pt_var_msm2(P1, a, P2, b), out);
+  return SP_OK;
+}
 int32_t sp_ipa_finish_commit(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint64_t a_hat[4], uint64_t b_hat[4], uint8_t delta_out[32]) {
   if (!ipa || !d || !r || !a_hat || !b_hat || !delta_out || ipa->n_cur != 1) return SP_EINVAL;
   if (ipa_finish_on_host(ipa, d, r, a_hat, b_hat, delta_out)) return SP_OK;

@@ -354,3 +354,25 @@ def test_eq_table_as_a_factor_host_arithmetic():
     # a coordinate equal to 0 or 1 has no factored form: the driver must fall back to the generic kernels
     assert prover.H.spz_eq_factor_probe(mont_array([1] + rho[1:]), sz(nv), sz(np_), sz(ni), mont_array(coeffs), sz(nv), mont_array(claims), mont_array(ev4),
                                         mont_array(chal), evc, Ks) == 0
+
+
+def test_two_point_variable_base_multiplication_on_the_host(orc):
+    """ipa.hip pt_var_msm2 (through its device-free entry point): the end of every inner-product argument is k1 P1 + k2 P2 over the last
+    round's two row sums, computed by the proving thread with 4-bit windows (sp_ipa_finish_commit). Against the oracle's multi-scalar
+    multiplication for random, small, zero and maximal scalars and for equal and opposite points."""
+    import ctypes, random
+    from spartan_amd import capi
+    rng = random.Random(808)
+    g = gens_bytes(orc, 5)
+    P = [g[32 * i:32 * i + 32] for i in range(6)]
+    neg = (ctypes.c_uint8 * 32)()
+    assert orc.orc_pt_msm(mont_array([Q - 1]), P[0], sz(1), neg) == 1   # -P0
+    got = (ctypes.c_uint8 * 32)(); want = (ctypes.c_uint8 * 32)()
+    cases = [(P[0], rng.randrange(Q), P[1], rng.randrange(Q)) for _ in range(20)]
+    cases += [(P[2], 0, P[3], rng.randrange(Q)), (P[2], rng.randrange(Q), P[3], 0), (P[2], 0, P[3], 0), (P[4], 1, P[5], Q - 1), (P[4], Q - 1, P[5], Q - 1),
+              (P[0], 7, P[0], 9), (P[0], 5, bytes(neg), 5), (P[1], 2**252, P[2], 15), (P[1], 16, P[2], 2**248 + 1), (bytes(32), rng.randrange(Q), P[3], 3)]
+    for p1, k1, p2, k2 in cases:
+        assert capi.lib.sp_host_msm2_probe(p1, mont_array([k1]), p2, mont_array([k2]), got) == 0
+        assert orc.orc_pt_msm(mont_array([k1, k2]), p1 + p2, sz(2), want) == 1
+        assert bytes(got) == bytes(want), (k1, k2)
+    assert capi.lib.sp_host_msm2_probe(bytes([1] + [0] * 31), mont_array([1]), P[0], mont_array([1]), got) != 0   # not a valid encoding
