@@ -54,13 +54,17 @@ impl ProductCircuitEvalProofBatched {
     prod_circuit_vec: &mut [&mut ProductCircuit],
     dotp_circuit_vec: &mut [&mut DotProductCircuit],
     dotp_evals: Option<&[Scalar]>,
+    roots: Option<&[Scalar]>, // ProductCircuit::evaluate of each circuit when the caller already has them (ProductLayerProof::prove has just absorbed them)
     transcript: &mut Transcript,
   ) -> (Self, Vec<Scalar>) {
     assert!(!prod_circuit_vec.is_empty());
     let mut claims_dotp_final = (Vec::new(), Vec::new(), Vec::new());
     let mut proof_layers: Vec<LayerProofBatched> = Vec::new();
     let num_layers = prod_circuit_vec[0].left_vec.len();
-    let mut claims_to_verify = product_circuits_evaluate(&prod_circuit_vec.iter().map(|p| &**p).collect::<Vec<_>>());
+    let mut claims_to_verify = match roots {
+      Some(v) => { assert_eq!(v.len(), prod_circuit_vec.len()); v.to_vec() }
+      None => product_circuits_evaluate(&prod_circuit_vec.iter().map(|p| &**p).collect::<Vec<_>>()),
+    };
     let mut rand: Vec<Scalar> = Vec::new();
     for layer_id in (0..num_layers).rev() {
       let len = prod_circuit_vec[0].left_vec[layer_id].len() + prod_circuit_vec[0].right_vec[layer_id].len();

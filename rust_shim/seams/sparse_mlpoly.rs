@@ -216,9 +216,12 @@ impl ProductLayerProof {
     let mut dps: Vec<&mut DotProductCircuit> = Vec::new();
     for (l, r) in dl.iter_mut().zip(dr.iter_mut()) { dps.push(l); dps.push(r); }
     let dps_evals: Vec<Scalar> = (0..nb).flat_map(|i| [eval_dotp_left_vec[i], eval_dotp_right_vec[i]]).collect();
-    let (proof_ops, rand_ops) = ProductCircuitEvalProofBatched::prove_gpu(&mut [r0, r1, r2, w0, w1, w2, c0, c1, c2, x0, x1, x2], &mut dps, Some(&dps_evals), transcript);
+    // the circuits' roots were evaluated and absorbed above (the claims of :1043-1100): handed on, a device trip less per batch
+    let ops_roots: Vec<Scalar> = row_eval_read.iter().chain(row_eval_write.iter()).chain(col_eval_read.iter()).chain(col_eval_write.iter()).cloned().collect();
+    let (proof_ops, rand_ops) = ProductCircuitEvalProofBatched::prove_gpu(&mut [r0, r1, r2, w0, w1, w2, c0, c1, c2, x0, x1, x2], &mut dps, Some(&dps_evals), Some(&ops_roots), transcript);
     // The second batch: the memory-related product circuits
-    let (proof_mem, rand_mem) = ProductCircuitEvalProofBatched::prove_gpu(&mut [&mut row.init, &mut row.audit, &mut col.init, &mut col.audit], &mut [], None, transcript);
+    let mem_roots = [row_eval_init, row_eval_audit, col_eval_init, col_eval_audit];
+    let (proof_mem, rand_mem) = ProductCircuitEvalProofBatched::prove_gpu(&mut [&mut row.init, &mut row.audit, &mut col.init, &mut col.audit], &mut [], None, Some(&mem_roots), transcript);
     drop(keep);
     (
       ProductLayerProof {
