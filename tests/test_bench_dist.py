@@ -82,3 +82,31 @@ def test_two_rank_gloo_commit_shard_gather():
         o, e = p.communicate(timeout=300)
         assert p.returncode == 0, e[-2000:]
         assert '"ok": true' in o
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (no RANK / WORLD_SIZE in the environment — how the driver starts the N=1 run)
+    must start two ranks itself (torch.distributed.run on 127.0.0.1) and print a line for a 2-rank job (missing #3). The
+    --plumbing-only hook stops before any GPU work: launch, rendezvous, rank count, MAX over ranks."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"], env=_clean_env(BENCH_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["self_launched"] is True
+    assert d["max_over_ranks"] == 2.0           # rank 1 is the slow one: MAX over ranks
+
+
+def test_bench_refuses_a_world_of_another_size():
+    """a launcher that started 1 rank for --gpus 2 (or the reverse) gets an error, never a line"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                       env=_clean_env(WORLD_SIZE="1", RANK="0", BENCH_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())

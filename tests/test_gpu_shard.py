@@ -35,29 +35,29 @@ def test_sharded_commit_proof_is_byte_identical(s):
 
 
 def test_default_multi_rank_run_reports_replicas_and_strong_leg():
-    """`bench.py --gpus 2` as the driver launches it (no --shard-commits): the headline is the replica throughput
-    ("weak": one independent proof per rank, no data-path collective) and the same command adds the strong-scaling leg
-    (one proof, row commitments sharded, byte-identical to the unsharded proof). Two gloo ranks on the one GPU of the box."""
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_NO_PROF="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-cons", "14", "--steps", "2", "--warmup", "1"],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=600)
-        assert p.returncode == 0, e[-3000:]
-        outs.append(o)
-    line = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][-1])
+    """`python bench.py --gpus 2` with NO launcher and no RANK / WORLD_SIZE in the environment, as the driver starts its N=1 run:
+    bench.py launches its own two ranks (torch.distributed.run on 127.0.0.1; two gloo ranks on the one GPU of the box). The headline
+    is the replica throughput ("weak": one independent proof per rank, no data-path collective) and the same command adds the
+    strong-scaling leg at every size of --strong-log2 (one proof, row commitments sharded, byte-identical to the unsharded proof),
+    each with its exchange counts and the Amdahl ceiling of its own unsharded run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_NO_PROF="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-cons", "14", "--steps", "2", "--warmup", "1",
+                        "--strong-log2", "12,14"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                                              # rank 0 alone prints
+    line = json.loads(lines[0])
     assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["n_ranks_seen"] == 2
     assert line["value"] == pytest.approx(2 * (1 << 14) / (line["ms_per_step"] * 1e-3), rel=1e-6)  # two proofs per step
-    st = line["strong"]
-    assert "error" not in st, st
-    assert st["scaling"] == "strong" and st["byte_identical_to_unsharded"] and st["all_gathers_per_proof"] == 2
-    assert st["value"] == pytest.approx((1 << 14) / (st["ms_per_step"] * 1e-3), rel=1e-6)             # one proof per step
-    assert not [l for l in outs[1].splitlines() if l.startswith("{")]                                   # rank 0 alone prints
+    assert [st.get("log2_cons") for st in line["strong"]] == [12, 14]
+    for st in line["strong"]:
+        s = st["log2_cons"]
+        assert "error" not in st, st
+        assert st["scaling"] == "strong" and st["byte_identical_to_unsharded"] and st["all_gathers_per_proof"] == 2
+        assert st["all_gather_bytes_per_proof"] == 32 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))
+        assert st["value"] == pytest.approx((1 << s) / (st["ms_per_step"] * 1e-3), rel=1e-6)         # one proof per step
+        assert st["amdahl"]["ceiling_commits_only"] >= 1.0 and st["ms_per_step_unsharded"] > 0
 
 
 @pytest.mark.parametrize("s,nshards", [(14, 8), (16, 4)])
