@@ -179,7 +179,7 @@ def concurrent_throughput(P, device, s, K, steps):
     """K independent SNARK::prove streams on ONE GPU (own context + host thread each; generator tables are shared). A
     single proof is a chain of latency-bound launches, so a second and a third proof fill the gaps of the first. Measured at 2^20
     (bench/concurrent_probe.py, profiles/r4_concurrent_probe.txt): K = 1 / 2 / 3 / 4 -> 42.5 / 60.9 / 68.9 / 64.0 M constraints/s;
-    admitting one proof at a time to the throughput-bound part (SPARTAN_PROOF_GATE=1) changes nothing, so the MSMs colliding is not
+    admitting one proof at a time to the throughput-bound part (option host.proof_gate = 1) changes nothing, so the MSMs colliding is not
     what limits it. Serving-style throughput; reported next to, never instead of, the single-proof `value`. Runs K' = 2 .. K."""
     import threading
     N = 1 << s
@@ -287,7 +287,7 @@ def strong_scaling_leg(P, ctx, dist, rank, world, s, steps, dev, partial=None):
     ctx.set_commit_shard_virtual(1)  # clears the sharding (and leaves the RCCL communicator)
     enc.free(); gens.free(); inst.free()
     # Amdahl (multi-GPU): what shards at this size, from the unsharded run's own spans. The row commitments always
-    # (polycommit + commit_nondet_witness); from 2^22-entry tables (SPARTAN_RESIDUE_MIN_LOG2) the throughput-sized rounds too — those are
+    # (polycommit + commit_nondet_witness); from 2^22-entry tables (option shard.residue_min_log2) the throughput-sized rounds too — those are
     # not separable from the latency-sized rounds in the span times, so the second figure is an upper bound (all of the sum-check spans).
     commits = ph.get("polycommit", 0.0) + ph.get("commit_nondet_witness", 0.0)
     rounds = ph.get("prove_sc_phase_one", 0.0) + ph.get("prove_sc_phase_two", 0.0) + ph.get("evalproof_layered_network", 0.0)
@@ -491,7 +491,7 @@ def main():
             named[(1 << (s // 2), 1 << (s - s // 2), False)] = ("witness commit (poly_vars, + one blind per row)", N + (1 << (s // 2)), False)
             if (1 << (s // 2)) % 1024 == 0:  # host assignment: four row chunks, each launched behind its PCIe copy (sp_commit_rows_upload_start)
                 named[((1 << (s // 2)) // 4, 1 << (s - s // 2), False)] = ("witness commit, one of four row chunks (each launched behind its PCIe copy)", (N + (1 << (s // 2))) // 4, False)
-            named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, SPARTAN_BG_EIGHTHS/8 of the CUs)", 3 * N, True)
+            named[(rows_row_half, R, True)] = ("derefs commit, row half (background stream, bg.eighths/8 of the CUs)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, True)] = ("derefs commit, column half (+ zero padding rows; background stream behind the row half)", 3 * N, True)
             named[((8 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (+ zero padding rows)", 3 * N, True)
             named[((6 * N) // R - rows_row_half, R, False)] = ("derefs commit, column half (the zero padding rows of the merged polynomial are not launched)", 3 * N, True)
@@ -505,8 +505,9 @@ def main():
             madds = nm[1] * nwin
             e = {"shape": f'{sh["rows"]} x {sh["cols"]}', "what": nm[0], "launch_ms": round(lms, 4), "window_bits": wb_eval if nm[2] else wb_sat, "mixed_additions": madds,
                  "achieved_G_per_s": round(madds / lms / 1e6, 2)}
-            if sh["background"]:   # k_msm_rows_bg holds SPARTAN_BG_EIGHTHS/8 of the CUs (one persistent 1024-thread workgroup each)
-                e["cu_share"] = int(os.environ.get("SPARTAN_BG_EIGHTHS", "5")) / 8  # core.hip ctx_init: share of the CUs the persistent background MSM is launched on
+            if sh["background"]:   # the persistent background MSM holds bg.eighths/8 of the CUs (one workgroup each; option of the context)
+                bg8 = ctypes.c_int64(5); capi.lib.sp_ctx_get_option(raw, b"bg.eighths", ctypes.byref(bg8))
+                e["cu_share"] = bg8.value / 8
             if ceil:
                 e["frac"] = round(madds / lms / 1e6 / ceil["pt_madd_G_per_s"], 3)
                 if sh["background"] and e["cu_share"] > 0:

@@ -49,6 +49,21 @@ int sp_ctx_device(const sp_ctx* ctx); /* the device_id the context was created o
 /* Completed device round trips of the context so far (every wait for a result counts one): the difference around a proof is its
  * number of Fiat-Shamir steps that went to the GPU (bench.py reports it as fs_trips_per_proof). */
 uint64_t sp_ctx_trips(const sp_ctx* ctx);
+/* ---- options ---------------------------------------------------------------------------------------
+ * Every tunable of the library is a named option with a compiled-in default (spartan_amd/csrc/options.hpp holds the table: key,
+ * default, range, tier, one line of documentation; sp_option_describe enumerates it). The reference has three cargo features and no
+ * environment variables (Cargo.toml:64-78); this library has an option table and ONE environment hook, SPARTAN_OPTIONS="key=value,...",
+ * applied to the process-wide defaults (how A/B scripts reach the table without a recompile; an unknown or out-of-range entry aborts).
+ *   sp_ctx_set_option(ctx, key, value): value is a decimal integer; SP_EINVAL for an unknown key, a value outside the option's range, or
+ *     a tier-1 option (an A/B / test switch: same bytes, another placement or launch form) before "testing.unlock" = 1 was set.
+ *     ctx == NULL sets the process-wide default that contexts created AFTERWARDS start from (and the options marked PROC in the table).
+ *     Options that shape a generator set's tables (msm.wbits, msm.table_gb, msm.wide_gb, msm.lds_bits) are read when the set is built.
+ *   sp_ctx_copy_options: a sub-context (a virtual shard) takes over its parent's settings. */
+int32_t sp_ctx_set_option(sp_ctx* ctx, const char* key, const char* value);
+int32_t sp_ctx_get_option(const sp_ctx* ctx, const char* key, int64_t* value);
+int32_t sp_ctx_copy_options(sp_ctx* dst, const sp_ctx* src);
+/* entry `index` of the table (0 .. until SP_EINVAL); any out pointer may be NULL */
+int32_t sp_option_describe(int index, const char** key, int64_t* default_value, int64_t* min_value, int64_t* max_value, int* tier, const char** doc);
 /* HIP-event timing of every kernel family on the context's stream (bench.py's roofline numbers). */
 int32_t sp_prof_enable(sp_ctx* ctx, int on);
 int32_t sp_prof_reset(sp_ctx* ctx);
@@ -72,12 +87,17 @@ int sp_msm_window_bits(void);
  * A sp_gens is a list of n points P[0..n). A MultiCommitGens{G[0..m), h} made by
  * MultiCommitGens::new(m, label) is the list of its m+1 stream points with h = P[m]; gens that are prefixes
  * of one SHAKE stream (gens_3/gens_4/gens_pc of R1CSGens, src/r1csproof.rs:48-73) share one sp_gens.
- * Upload builds signed c-bit fixed-base window tables (ceil(254/c) windows x 2^(c-1) affine entries of 96 B per point):
- * generators are public parameters reused across proofs, so this is setup cost. c is chosen per set by PROOF time, not launch
- * time: 15 bits (17 additions per committed scalar, 26 MiB per point) while the set's tables stay under SPARTAN_MSM_WIDE_GB
- * (default 32), otherwise the widest of 14/13/12/10/8 that fits SPARTAN_MSM_TABLE_GB (default 128); SPARTAN_MSM_WBITS forces a
- * width. 2^20: 15 bits for the 1025-point stream (27 GB), 14 for the 4098-point one (61 GB). SP_ENOMEM (with a message on
- * stderr) if not even 8-bit tables fit in free device memory. */
+ * Upload builds signed c-bit fixed-base window tables (ceil(254/c) windows x 2^(c-1) affine entries, 96 B of values in a
+ * 128-byte line, per point): generators are public parameters reused across proofs, so this is setup cost. c is chosen per set
+ * by PROOF time, not launch time: 15 bits (17 additions per committed scalar, 35.7 MB per point) while the set's tables stay
+ * under option msm.wide_gb (default 80), otherwise the widest of 14/13/12/10/8 that fits msm.table_gb (default 170 per set);
+ * msm.wbits forces a width. 2^20: 15 bits for the 1025-point stream (36.6 GB), 14 for the 4098-point one (81.6 GB). With
+ * msm.lds_bits = 10 the set also gets the packed 10-bit tables of the LDS-staged row MSM (1.25 MB per point: 1.3 + 5.2 GB at
+ * 2^20; msm.form = 1 selects that form for commits of >= 512 rows). SP_ENOMEM (with a message on stderr) if not even 8-bit
+ * tables fit in free device memory.
+ * FIXED PUBLIC BASES ONLY: every multi-scalar multiplication of this library (sp_commit_rows*, sp_msm_indexed, the inner-product
+ * argument) runs over the points of a sp_gens through its precomputed tables. There is no variable-base device MSM — the prover
+ * never needs one (every base on the path is a public generator). */
 int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n, sp_gens** out);
 /* MultiCommitGens::new body (commitments.rs:21-30): n blocks of 64 uniform bytes from the caller's
  * SHAKE256 stream -> from_uniform_bytes on the device. compressed_out (32*n) may be NULL. */
@@ -96,7 +116,7 @@ int32_t sp_commit_rows(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx
 int32_t sp_commit_rows_dev(sp_ctx* ctx, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t z_off, size_t rows,
                            size_t cols, const uint64_t* blinds, uint8_t* out);
 /* Background variant (no blinds): the commit is queued on a lower-priority HIP stream behind everything issued so far and
- * runs concurrently with later calls on the context (persistent workgroups on half the CUs, so the latency-bound kernels
+ * runs concurrently with later calls on the context (persistent workgroups on bg.eighths/8 of the CUs, 5/8 by default, so the latency-bound kernels
  * of those calls keep idle CUs to run on); sp_job_wait blocks, copies the 32*rows bytes out and frees the job.
  * Z and g must stay alive and Z[z_off, z_off + rows*cols) unmodified until sp_job_wait returns.
  * Used to overlap the row half of the SPARK `derefs` commitment (sparse_mlpoly.rs:1473-1478), which only depends on rx,
@@ -381,18 +401,6 @@ int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table
 int32_t sp_sumcheck_bind2_eval_tables_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r0,
                                               const uint64_t* r1, const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs,
                                               uint64_t* out_heads, uint64_t* out_tables /* 4*ninst*3*8 */);
-/* Up to THREE rounds per call (generalises the two calls above). The call first binds every table at r[0..nbind) (nbind <= 3; a
- * shared C table is bound once, out of place), then returns, for the tables so bound (length n2 = len / 2^nbind >= 2^kd), the
- * weighted sums over the instances of
- *   F(y_0, .., y_{kd-1}) = sum_z A~(y, z) B~(y, z) C~(y, z)          on the grid y in {0, 1, 2, 3}^kd,  out_grid[y_0 4^(kd-1) + .. + y_{kd-1}],
- * A~ etc. being multilinear in the top kd index bits. F has degree 3 in each y, so the grid determines it and the caller runs the
- * next kd rounds of prove_cubic_batched without the device: round j sends s_j(t) = sum_{b in {0,1}^(kd-1)} F(t, b); its challenge r_j
- * contracts the first axis with the Lagrange basis of {0, 1, 2, 3}; round j+1 sends sum_b F(r_j, t, b); and so on (the values at
- * t = 0, 2, 3 are the reference's evaluations, sumcheck.rs:290-357; the value at t = 1 is e - s(0)). kd = 0: only bind.
- * out_tables (may be NULL): as sp_sumcheck_bind2_eval_tables_batched — the bound tables, [ninst][3][n2], when n2 <= 8 and ninst <= 21
- * (n2 = 1: the final claims), else out_tables[0] is set to all ones. weights (4*ninst limbs) are mandatory. */
-int32_t sp_sumcheck_grid_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* r, size_t nbind,
-                                 const uint64_t* weights, size_t kd, uint64_t* out_grid /* 4*4^kd */, uint64_t* out_tables /* 4*ninst*3*8 */);
 /* out[k] = <chi, T_k> for k < nt (the ~23 DensePolynomial::evaluate calls of HashLayerProof::prove share chi). */
 int32_t sp_dot_many(sp_ctx* ctx, const sp_table* chi, sp_table* const* tabs, size_t nt, uint64_t* out /*4*nt*/);
 /* DotProductCircuit::evaluate (product_tree.rs:84-88): sum l[i]*r[i]*w[i] over n elements from the given offsets. */

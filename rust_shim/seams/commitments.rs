@@ -47,7 +47,7 @@ impl MultiCommitGens {
 /// rows of scalars over an explicit list of stream indices -> one CompressedGroup per row. On the calling thread's core through
 /// the library's host-side engine (sp_host_commit_small: a 2..5-term commitment is a chain of ~100 dependent point additions
 /// the transcript waits for — ~15 us there, ~60 us + a round trip on a lone wavefront), or on the device with
-/// SPARTAN_SMALL_MSM=device (sp_msm_indexed). Same bytes either way. `addend[r]`: a point computed ahead (sp_host_zk_ahead_*).
+/// option commit.small_device = 1 (sp_msm_indexed). Same bytes either way. `addend[r]`: a point computed ahead (sp_host_zk_ahead_*).
 #[cfg(feature = "gpu")]
 pub fn commit_small(
   g: *const gpu::sp_gens,

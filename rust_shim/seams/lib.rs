@@ -48,7 +48,7 @@ impl SNARK {
       comm.comm.append_to_transcript(b"comm", t);
     };
     // the row half of the derefs commitment starts as soon as rx is known (seams/sparse_mlpoly.rs: DerefsEarly)
-    let overlap = std::env::var_os("SPARTAN_NO_OVERLAP").is_none();
+    let overlap = gpu::opt("overlap.derefs") != 0;
     let ry_len = inst.inst.get_num_vars().log_2() + 1;
     let mut early: Option<DerefsEarly> = None;
     let mut rx_seen: Vec<Scalar> = Vec::new();
@@ -58,7 +58,7 @@ impl SNARK {
     };
     // R1CSInstance::evaluate (r1cs.rs:300-303) needs rx, ry only: queued on a low-priority stream when the second sum-check ends
     // (sp_sparse_evaluate_begin), it runs in the idle time of the witness opening; collected below with sp_job_wait
-    let eval_ahead = overlap && std::env::var_os("SPARTAN_NO_EVAL_AHEAD").is_none();
+    let eval_ahead = overlap && gpu::opt("overlap.eval_ahead") != 0;
     let mut ahead: Option<(gpu::Table, gpu::Table, gpu::CommitJob)> = None;
     let mut on_ry = |ry: &[Scalar]| {
       let (tx, ty) = (gpu::Table::eq(&rx_seen), gpu::Table::eq(ry));

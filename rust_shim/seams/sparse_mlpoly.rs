@@ -111,7 +111,7 @@ impl Layers {
     let null = std::ptr::null::<sp_table>();
     let n_ops = at.ops_addr[0].len();
     // the hash layer writes the first multiplication layer too, and the read and write sets of a matrix (ts, ts + 1) come out of one pass
-    // (sp_hash_layer_first); SPARTAN_NO_HASH_FUSE=1: the separate launches. Mechanical call sequence (spark.inc layers_new is the twin).
+    // (sp_hash_layer_first); option spark.hash_fuse = 0: the separate launches. Mechanical call sequence (spark.inc layers_new is the twin).
     let fuse = gpu::hash_fuse_enabled() && cells >= 4 && n_ops >= 4;
     // leaves [0, n) and layer 1 [n, n + n/2) of `store` (and of `store_w`, the write set: ts + 1) in one pass
     let first = |addr: *const sp_table, val: *const sp_table, ts: *const sp_table, n: usize, with_write: bool| -> (gpu::Table, Option<gpu::Table>) {

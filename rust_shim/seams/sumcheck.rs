@@ -493,8 +493,8 @@ impl SumcheckInstanceProof {
     let mut heads = vec![Scalar::zero(); all.len()];
     let mut tail = vec![Scalar::zero(); 3 * 8 * ni];
     let (mut have_heads, mut have_S) = (false, false);
-    let tail_ok = std::env::var_os("SPARTAN_NO_HOST_TAIL").is_none() && np >= 1 && ni <= 21;
-    let dmax = gpu::double_round_max_len(); // 4096 (SPARTAN_DOUBLE_ROUND_MAX_LEN)
+    let tail_ok = gpu::opt("sumcheck.host_tail") != 0 && np >= 1 && ni <= 21;
+    let dmax = gpu::double_round_max_len(); // 4096 (option sumcheck.double_round_max_len)
     let len_of = |t: *mut sp_table| unsafe { gpu::sp_table_len(t) };
     // :370-381 and :395-396: the round's cubic, its transcript message, the challenge
     let mut round_message = |evc: &[Scalar; 3], e: &mut Scalar, r: &mut Vec<Scalar>, polys: &mut Vec<CompressedUniPoly>, transcript: &mut Transcript| {
@@ -525,172 +525,107 @@ impl SumcheckInstanceProof {
       have_heads = true;
     }} }
 
-    if gpu::trip_rounds() == 3 {
-      // ---- up to THREE rounds per trip: the grid form (A/B option; spark.inc prove_cubic_batched, default off) -------------
-      // sp_sumcheck_grid_batched returns F on {0,1,2,3}^kd; round: s(t) = sum of F(t, b) over b in {0,1}^(axes-1); then the first
-      // axis is contracted at the challenge with the Lagrange basis of {0, 1, 2, 3}.
-      let gmax = gpu::grid_max_len();
-      let mut pend: Vec<Scalar> = Vec::new();
-      let (mut F, mut axes): (Vec<Scalar>, usize) = (Vec::new(), 0);
-      while j < num_rounds {
-        if axes == 0 {
-          let eff = len_of(A[0]) >> pend.len();
-          if tail_ok && eff <= 8 {
-            mark(&mut tail);
-            gpu::ok(unsafe { gpu::sp_sumcheck_grid_batched(c, ap, bp, cp, ni, gpu::limbs(&pend), pend.len(), gpu::limbs(coeffs), 0, null, gpu::limbs_mut(&mut tail)) });
-            assert!(tail_given(&tail));
-            pend.clear();
-            finish_on_host!(eff);
-            break;
-          }
-          if eff <= gmax {
-            let left = eff.log_2() - if tail_ok { 3 } else { 0 };
-            let kd = left.min(3).min(num_rounds - j);
-            F = vec![Scalar::zero(); 1 << (2 * kd)];
-            gpu::ok(unsafe { gpu::sp_sumcheck_grid_batched(c, ap, bp, cp, ni, gpu::limbs(&pend), pend.len(), gpu::limbs(coeffs), kd, gpu::limbs_mut(&mut F), null) });
-            axes = kd;
-            pend.clear();
-          } else {
-            if pend.is_empty() { gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) }); }
-            else { gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&pend[0]), gpu::limbs_mut(&mut ev)) }); pend.clear(); }
-            evc = combine(&ev);
-            pend.push(round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript));
-            j += 1;
-            continue;
-          }
-        }
-        let S4 = 1usize << (2 * (axes - 1));
-        let mut s = [Scalar::zero(); 4];
-        for t in 0..4 { for m in 0..(1usize << (axes - 1)) {
-          let idx: usize = (0..axes - 1).map(|i| ((m >> i) & 1) << (2 * i)).sum();
-          s[t] += F[t * S4 + idx];
-        } }
-        evc = [s[0], s[2], s[3]]; // s[1] = e - s[0] by the sum-check invariant
+    // ---- TWO rounds per trip on short tables (the default) ---------------------------------------------------------------
+    // the throughput-sized rounds on W residue classes of every table (CubicShards above), until the hand-over length
+    let mut cs = if num_rounds > 0 { CubicShards::split(&all, &A, &B, &C) } else { CubicShards::split(&all[..0], &A[..0], &B[..0], &C[..0]) };
+    if cs.active {
+      cs.eval(&mut ev);
+      evc = combine(&ev);
+      while cs.active {
         let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
-        let (inv2, inv6) = ((2_usize).to_scalar().invert().unwrap(), (6_usize).to_scalar().invert().unwrap());
-        let (r1, r2, r3) = (r_j - Scalar::one(), r_j - Scalar::one() - Scalar::one(), r_j - Scalar::one() - Scalar::one() - Scalar::one());
-        let (L0, L1, L2, L3) = (-(r1 * r2 * r3 * inv6), r_j * r2 * r3 * inv2, -(r_j * r1 * r3 * inv2), r_j * r1 * r2 * inv6);
-        F = (0..S4).map(|i| L0 * F[i] + L1 * F[S4 + i] + L2 * F[2 * S4 + i] + L3 * F[3 * S4 + i]).collect();
-        axes -= 1;
-        pend.push(r_j);
         j += 1;
+        let last = !cs.keep_going();
+        cs.bind_eval(&r_j, &mut ev);
+        evc = combine(&ev);
+        if last { cs.hand_back(); }
       }
-      if !have_heads {
-        if !pend.is_empty() && ni <= 21 {
-          mark(&mut tail);
-          gpu::ok(unsafe { gpu::sp_sumcheck_grid_batched(c, ap, bp, cp, ni, gpu::limbs(&pend), pend.len(), gpu::limbs(coeffs), 0, null, gpu::limbs_mut(&mut tail)) });
-          for i in 0..ni { heads[2 * i] = tail[i * 3]; heads[2 * i + 1] = tail[i * 3 + 1]; }
-          heads[2 * ni] = tail[2];
-          for k in 0..ns { heads[2 * ni + 1 + k] = tail[(np + k) * 3 + 2]; }
+    } else if num_rounds > 0 {
+      let len0 = len_of(A[0]);
+      if tail_ok && len0 >= 2 && len0 <= 8 {
+        mark(&mut tail);
+        gpu::ok(unsafe {
+          gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, std::ptr::null(), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc),
+                                                     if len0 >= 4 { gpu::limbs_mut(&mut S) } else { null }, null, gpu::limbs_mut(&mut tail))
+        });
+        assert!(tail_given(&tail));
+        finish_on_host!(len0);
+      } else if len0 >= 4 && len0 <= dmax {
+        gpu::ok(unsafe { gpu::sp_sumcheck_eval_coeffs_batched(c, ap, bp, cp, ni, gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S)) });
+        have_S = true;
+      } else {
+        eqf = EqFactor::begin(eq_point, num_rounds, len0, np, ni);
+        if eqf.on {
+          gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched_eq(c, ap, bp, cp, ni, np, gpu::limbs_mut(&mut ev4)) });
+          evc = eqf.combine(0, &ev4, coeffs, np, ni, &e);
         } else {
-          for k in 0..pend.len().saturating_sub(1) { gpu::ok(unsafe { gpu::sp_table_bind_top(c, all.as_ptr(), all.len(), gpu::limbs1(&pend[k])) }); }
-          if let Some(last) = pend.last() { gpu::ok(unsafe { gpu::sp_table_bind_top_heads(c, all.as_ptr(), all.len(), gpu::limbs1(last), gpu::limbs_mut(&mut heads)) }); }
-          else { gpu::ok(unsafe { gpu::sp_table_heads(c, all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) }); }
+          gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) });
+          evc = combine(&ev);
         }
+      }
+    }
+    while j < num_rounds {
+      let len = len_of(A[0]);
+      let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+      if eqf.on && len >= EqFactor::MIN_LEN {
+        // a throughput-sized round in the factored form: A and B are bound at r_j, the eq table is only read
+        gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched_eq(c, ap, bp, cp, ni, np, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev4)) });
+        eqf.bound(j, &r_j);
+        j += 1;
+        evc = eqf.combine(j, &ev4, coeffs, np, ni, &e);
+        continue;
+      }
+      if eqf.on {
+        // hand-over: K * C_original[0 .. len) is the eq table bound at r_0 .. r_{j-1}; the generic rounds continue with it
+        gpu::ok(unsafe { gpu::sp_table_scale_prefix(c, dev(poly_C_par), len, gpu::limbs1(&eqf.K)) });
+        eqf.on = false;
+      }
+      if have_S && len >= 4 {
+        // two rounds in one trip: the next round's evaluations are the device's cubic at r_j
+        evc = evals_from_coeffs(&S, &r_j);
+        let r_j1 = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
+        let n2 = len / 4;
+        let want_tail = tail_ok && n2 >= 2 && n2 <= 8;
+        let (pe, ps) = (if n2 >= 2 { gpu::limbs_mut(&mut evc) } else { null }, if n2 >= 4 { gpu::limbs_mut(&mut S) } else { null });
+        if want_tail {
+          mark(&mut tail);
+          gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs1(&r_j1), gpu::limbs(coeffs), pe, ps, null, gpu::limbs_mut(&mut tail)) });
+        } else {
+          gpu::ok(unsafe {
+            gpu::sp_sumcheck_bind2_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs1(&r_j1), gpu::limbs(coeffs), pe, ps,
+                                                if n2 == 1 { gpu::limbs_mut(&mut heads) } else { null })
+          });
+        }
+        have_S = n2 >= 4;
+        have_heads = n2 == 1;
+        j += 2;
+        if want_tail && tail_given(&tail) { finish_on_host!(n2); }
+        continue;
+      }
+      if len >= 8 && len / 2 <= dmax {
+        // the tables become short with this bind: it also returns the cubic, then two rounds per trip
+        let n2 = len / 2;
+        let want_tail = tail_ok && n2 <= 8;
+        if want_tail {
+          mark(&mut tail);
+          gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S), null, gpu::limbs_mut(&mut tail)) });
+        } else {
+          gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S), null) });
+        }
+        have_S = true;
+        j += 1;
+        if want_tail && tail_given(&tail) { finish_on_host!(n2); }
+        continue;
+      } else if len >= 4 {
+        gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev)) });
+        evc = combine(&ev);
+      } else {
+        gpu::ok(unsafe { gpu::sp_table_bind_top_heads(c, all.as_ptr(), all.len(), gpu::limbs1(&r_j), gpu::limbs_mut(&mut heads)) });
         have_heads = true;
       }
-    } else {
-      // ---- TWO rounds per trip on short tables (the default) ---------------------------------------------------------------
-      // the throughput-sized rounds on W residue classes of every table (CubicShards above), until the hand-over length
-      let mut cs = if num_rounds > 0 { CubicShards::split(&all, &A, &B, &C) } else { CubicShards::split(&all[..0], &A[..0], &B[..0], &C[..0]) };
-      if cs.active {
-        cs.eval(&mut ev);
-        evc = combine(&ev);
-        while cs.active {
-          let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
-          j += 1;
-          let last = !cs.keep_going();
-          cs.bind_eval(&r_j, &mut ev);
-          evc = combine(&ev);
-          if last { cs.hand_back(); }
-        }
-      } else if num_rounds > 0 {
-        let len0 = len_of(A[0]);
-        if tail_ok && len0 >= 2 && len0 <= 8 {
-          mark(&mut tail);
-          gpu::ok(unsafe {
-            gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, std::ptr::null(), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc),
-                                                       if len0 >= 4 { gpu::limbs_mut(&mut S) } else { null }, null, gpu::limbs_mut(&mut tail))
-          });
-          assert!(tail_given(&tail));
-          finish_on_host!(len0);
-        } else if len0 >= 4 && len0 <= dmax {
-          gpu::ok(unsafe { gpu::sp_sumcheck_eval_coeffs_batched(c, ap, bp, cp, ni, gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S)) });
-          have_S = true;
-        } else {
-          eqf = EqFactor::begin(eq_point, num_rounds, len0, np, ni);
-          if eqf.on {
-            gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched_eq(c, ap, bp, cp, ni, np, gpu::limbs_mut(&mut ev4)) });
-            evc = eqf.combine(0, &ev4, coeffs, np, ni, &e);
-          } else {
-            gpu::ok(unsafe { gpu::sp_sumcheck_eval_batched(c, ap, bp, cp, ni, gpu::limbs_mut(&mut ev)) });
-            evc = combine(&ev);
-          }
-        }
-      }
-      while j < num_rounds {
-        let len = len_of(A[0]);
-        let r_j = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
-        if eqf.on && len >= EqFactor::MIN_LEN {
-          // a throughput-sized round in the factored form: A and B are bound at r_j, the eq table is only read
-          gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched_eq(c, ap, bp, cp, ni, np, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev4)) });
-          eqf.bound(j, &r_j);
-          j += 1;
-          evc = eqf.combine(j, &ev4, coeffs, np, ni, &e);
-          continue;
-        }
-        if eqf.on {
-          // hand-over: K * C_original[0 .. len) is the eq table bound at r_0 .. r_{j-1}; the generic rounds continue with it
-          gpu::ok(unsafe { gpu::sp_table_scale_prefix(c, dev(poly_C_par), len, gpu::limbs1(&eqf.K)) });
-          eqf.on = false;
-        }
-        if have_S && len >= 4 {
-          // two rounds in one trip: the next round's evaluations are the device's cubic at r_j
-          evc = evals_from_coeffs(&S, &r_j);
-          let r_j1 = round_message(&evc, &mut e, &mut r, &mut cubic_polys, transcript);
-          let n2 = len / 4;
-          let want_tail = tail_ok && n2 >= 2 && n2 <= 8;
-          let (pe, ps) = (if n2 >= 2 { gpu::limbs_mut(&mut evc) } else { null }, if n2 >= 4 { gpu::limbs_mut(&mut S) } else { null });
-          if want_tail {
-            mark(&mut tail);
-            gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs1(&r_j1), gpu::limbs(coeffs), pe, ps, null, gpu::limbs_mut(&mut tail)) });
-          } else {
-            gpu::ok(unsafe {
-              gpu::sp_sumcheck_bind2_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs1(&r_j1), gpu::limbs(coeffs), pe, ps,
-                                                  if n2 == 1 { gpu::limbs_mut(&mut heads) } else { null })
-            });
-          }
-          have_S = n2 >= 4;
-          have_heads = n2 == 1;
-          j += 2;
-          if want_tail && tail_given(&tail) { finish_on_host!(n2); }
-          continue;
-        }
-        if len >= 8 && len / 2 <= dmax {
-          // the tables become short with this bind: it also returns the cubic, then two rounds per trip
-          let n2 = len / 2;
-          let want_tail = tail_ok && n2 <= 8;
-          if want_tail {
-            mark(&mut tail);
-            gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_tables_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S), null, gpu::limbs_mut(&mut tail)) });
-          } else {
-            gpu::ok(unsafe { gpu::sp_sumcheck_bind2_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), std::ptr::null(), gpu::limbs(coeffs), gpu::limbs_mut(&mut evc), gpu::limbs_mut(&mut S), null) });
-          }
-          have_S = true;
-          j += 1;
-          if want_tail && tail_given(&tail) { finish_on_host!(n2); }
-          continue;
-        } else if len >= 4 {
-          gpu::ok(unsafe { gpu::sp_sumcheck_bind_eval_batched(c, ap, bp, cp, ni, gpu::limbs1(&r_j), gpu::limbs_mut(&mut ev)) });
-          evc = combine(&ev);
-        } else {
-          gpu::ok(unsafe { gpu::sp_table_bind_top_heads(c, all.as_ptr(), all.len(), gpu::limbs1(&r_j), gpu::limbs_mut(&mut heads)) });
-          have_heads = true;
-        }
-        j += 1;
-      }
-      if !have_heads { gpu::ok(unsafe { gpu::sp_table_heads(c, all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) }); }
+      j += 1;
     }
+    if !have_heads { gpu::ok(unsafe { gpu::sp_table_heads(c, all.as_ptr(), all.len(), gpu::limbs_mut(&mut heads)) }); }
+
     // host-side bookkeeping of the bound polynomials (their tables were halved num_rounds times on the device)
     for p in poly_A_vec_par.iter_mut().chain(poly_B_vec_par.iter_mut()).chain(poly_A_vec_seq.iter_mut())
       .chain(poly_B_vec_seq.iter_mut()).chain(poly_C_vec_seq.iter_mut()) {

@@ -134,8 +134,7 @@ int32_t sync_wait(sp_ctx* c, uint32_t seq) {
 }
 int32_t sync_spin(sp_ctx* c) { return sync_wait(c, sync_post(c)); }
 DoneSig sig_make(sp_ctx* c, size_t total_workgroups) {
-  static const bool off = getenv("SPARTAN_NO_KERNEL_SIGNAL") != nullptr;  // A/B switch: completion by a flag kernel behind the last kernel
-  if (off || !c->done_counter) return sig_none();
+  if (!c->opt.v[OPT_SYNC_KERNEL_SIGNAL] || !c->done_counter) return sig_none();  // A/B switch: completion by a flag kernel behind the last kernel
   return DoneSig{c->done_flag, c->done_counter, ++c->done_seq, (uint32_t)total_workgroups, c->ktime};
 }
 // wait for a trip whose last kernel was launched with `sig` (falls back to the flag kernel when the signal is off)
@@ -186,7 +185,8 @@ __global__ void k_points_load(const uint8_t* __restrict__ in, int mode, size_t n
   pts[i] = p;
 }
 // stage 2: one thread per (point, window, chunk of up to 128 magnitudes): entries k * 2^(c w) * P in affine Niels form.
-__global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __restrict__ table, MsmGeom geom) {
+template <class E>  // E = Niels (one entry per 128-byte line: the gathered wide-window tables) or NielsP (packed: the streamed LDS-form tables)
+__global__ void k_table_build(const Pt* __restrict__ pts, size_t n, E* __restrict__ table, MsmGeom geom) {
   const int chunk = geom.tent < 128 ? geom.tent : 128, nchunk = geom.tent / chunk;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * geom.nwin * nchunk) return;
@@ -205,7 +205,9 @@ __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, Niels* __res
   }
   for (int m = m0; m < m0 + chunk; m++) {
     Fp zinv = fp_invert(acc.Z);
-    table[msm_tidx(geom, pt, w, m)] = pt_to_niels(acc, zinv);
+    Niels e = pt_to_niels(acc, zinv);
+    E& dst = table[msm_tidx(geom, pt, w, m)];
+    dst.yp = e.yp; dst.ym = e.ym; dst.t2d = e.t2d;
     if (m + 1 < m0 + chunk) acc = pt_add(acc, base);
   }
 }
@@ -916,7 +918,7 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
   DoneSig sig = sig_make(c, 2 * (size_t)A->nblk + A->nd);
   {
     ProfScope ps(c, PF_IPA, 32.0 * 3 * (double)A->n0 + 160.0 * 2 * (double)A->nblk, nullptr, (double)(2 * P));
-    static const bool always_unified = getenv("SPARTAN_IPA_UNIFIED_TREE") != nullptr;
+    const bool always_unified = c->opt.v[OPT_IPA_UNIFIED_TREE] != 0;
     if (unified || always_unified) hipLaunchKernelGGL(k_ipa_round<false>, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
     else hipLaunchKernelGGL(k_ipa_round<true>, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
   }
@@ -1041,7 +1043,8 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->sync_epoch = 0;
   c->eq_next = 0;
   for (int k = 0; k < 8; k++) c->eq_slot_epoch[k] = 0;
-  c->device_encode = getenv("SPARTAN_DEVICE_ENCODE") != nullptr;  // diagnostic: keep every RFC 9496 encode on the GPU
+  c->opt = sp_default_options();
+  c->device_encode = c->opt.v[OPT_ENCODE_DEVICE] != 0;  // diagnostic: keep every RFC 9496 encode on the GPU
   c->prof_on = 0;
   c->prof_mask = ~0ULL;
   c->pool_bytes = 0;
@@ -1067,10 +1070,9 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
     // rounds), share 3 / 4 / 5 / 6 -> 29.2 / 28.3 / 27.5 / 27.8 ms per proof (29.98 without the overlap): 5.
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
-    int share = 5;
-    if (const char* e = getenv("SPARTAN_BG_EIGHTHS")) { int v = atoi(e); if (v >= 0 && v <= 8) share = v; }
+    c->n_cus = prop.multiProcessorCount;
     c->bg_lds = 0;
-    c->bg_blocks = prop.multiProcessorCount * share / 8;
+    c->bg_blocks = c->n_cus * (int)c->opt.v[OPT_BG_EIGHTHS] / 8;
   }
   HIPCHK(hipHostMalloc((void**)&c->hmap, HMAP_SIZE, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&c->done_flag, 64, hipHostMallocDefault));
@@ -1079,11 +1081,23 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   HIPCHK(hipMalloc((void**)&c->done_counter, 64));
   HIPCHK(hipMemset(c->done_counter, 0, 64));
 #ifdef SP_KTIME
-  if (getenv("SPARTAN_KTIME")) { HIPCHK(hipMalloc((void**)&c->ktime, 64 * 8)); HIPCHK(hipMemset(c->ktime, 0, 64 * 8)); }
+  if (c->opt.v[OPT_DEBUG_KTIME]) { HIPCHK(hipMalloc((void**)&c->ktime, 64 * 8)); HIPCHK(hipMemset(c->ktime, 0, 64 * 8)); }
 #endif
   HIPCHK(hipEventCreateWithFlags(&c->sync_ev, hipEventDisableTiming));
   return SP_OK;
 }
+}  // extern "C"
+// state derived from options (sp_ctx_set_option / sp_ctx_copy_options, options.hip); which < 0: all of it
+void ctx_options_changed(sp_ctx* c, int which) {
+  if (which < 0 || which == OPT_ENCODE_DEVICE) c->device_encode = c->opt.v[OPT_ENCODE_DEVICE] != 0;
+  if (which < 0 || which == OPT_BG_EIGHTHS) c->bg_blocks = c->n_cus * (int)c->opt.v[OPT_BG_EIGHTHS] / 8;
+#ifdef SP_KTIME
+  if ((which < 0 || which == OPT_DEBUG_KTIME) && c->opt.v[OPT_DEBUG_KTIME] && !c->ktime && hipSetDevice(c->dev) == hipSuccess &&
+      hipMalloc((void**)&c->ktime, 64 * 8) == hipSuccess)
+    (void)hipMemset(c->ktime, 0, 64 * 8);
+#endif
+}
+extern "C" {
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
@@ -1098,7 +1112,6 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
-  if (c->grid_tickets) (void)hipFree(c->grid_tickets);
   if (c->ktime) (void)hipFree(c->ktime);
   if (c->vm_pinned) (void)hipHostFree(c->vm_pinned);
   if (c->vm_dstage) (void)hipFree(c->vm_dstage);
@@ -1203,6 +1216,8 @@ struct GensCacheEntry {
   size_t n, refs;
   std::vector<uint8_t> in, comp;
   Niels* table;
+  NielsP* table_lds = nullptr;  // LDS-form tables (msm_lds.hip), built with the set when SPARTAN_MSM_LDS asks for them
+  int wbits_lds = 0;
 };
 static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
@@ -1221,14 +1236,9 @@ static std::list<GensCacheEntry> g_gens_cache;
 // 2^20: 15 / 14 bits (36.5 + 81.6 GB); 2^22: 15 / 14 (73 + 163 GB of the 288); 2^24: 14 / 12. SPARTAN_MSM_WBITS forces a width (the tests
 // use it to cover several). A width below the first choice is reported on stderr (once per set): a silent narrowing would be a
 // performance cliff nobody sees. Returns 0 when not even 8-bit tables fit in free memory.
-static int choose_wbits(size_t n) {
-  if (const char* e = getenv("SPARTAN_MSM_WBITS")) {
-    int v = atoi(e);
-    if (v >= 4 && v <= 15) return v;
-  }
-  double budget = 170.0, wide = 80.0;
-  if (const char* e = getenv("SPARTAN_MSM_TABLE_GB")) { double v = atof(e); if (v > 0) budget = v; }
-  if (const char* e = getenv("SPARTAN_MSM_WIDE_GB")) { double v = atof(e); if (v > 0) wide = v; }
+static int choose_wbits(const sp_ctx* c, size_t n) {
+  if (c->opt.v[OPT_MSM_WBITS] >= 4) return (int)c->opt.v[OPT_MSM_WBITS];
+  const double budget = (double)c->opt.v[OPT_MSM_TABLE_GB], wide = (double)c->opt.v[OPT_MSM_WIDE_GB];
   size_t free_b = 0, total_b = 0;
   double free_gb = 1e9;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) free_gb = (double)free_b / 1e9;
@@ -1263,7 +1273,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   for (auto& e : g_gens_cache)  // a resident table set serves every later handle on the same points, whatever width it was built with
     if (e.dev == c->dev && e.mode == mode && e.n == n && memcmp(e.in.data(), in, in_bytes) == 0) { hit = &e; break; }
   if (!hit) {
-    int wbits = choose_wbits(n);
+    int wbits = choose_wbits(c, n);
     if (wbits == 0) {
       fprintf(stderr, "spartan_hip: no window-table width fits: %zu generators need at least %.2f GB of free device memory (8-bit windows)\n", n,
               (double)n * (double)msm_geom(8).pt_entries * sizeof(Niels) / 1e9);
@@ -1281,12 +1291,23 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     HIPCHK(hipMemsetAsync(base + off_bad, 0, 4, c->stream));
     Niels* table = nullptr;
     HIPCHK(hipMalloc((void**)&table, n * geom.pt_entries * sizeof(Niels)));
+    NielsP* table_lds = nullptr;
+    const int lds_bits = c->opt.v[OPT_MSM_LDS_BITS] >= 5 ? (int)c->opt.v[OPT_MSM_LDS_BITS] : 0;  // 10 bits: 512 x 96 B = 48 KB per sub-table, double-buffered in 96 of a CU's 160 KB of LDS
+    if (lds_bits && hipMalloc((void**)&table_lds, n * msm_geom(lds_bits).pt_entries * sizeof(NielsP)) != hipSuccess) {
+      (void)hipFree(table);
+      return SP_ENOMEM;
+    }
     {
       ProfScope ps(c, PF_GENS_TABLE, (double)n * geom.pt_entries * sizeof(Niels));
       hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
                          mode == 1 ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
       size_t nt = n * geom.nwin * (size_t)(geom.tent < 128 ? 1 : geom.tent / 128);
-      hipLaunchKernelGGL(k_table_build, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table, geom);
+      hipLaunchKernelGGL(k_table_build<Niels>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table, geom);
+      if (lds_bits) {
+        MsmGeom gl = msm_geom(lds_bits);
+        size_t ntl = n * gl.nwin * (size_t)(gl.tent < 128 ? 1 : gl.tent / 128);
+        hipLaunchKernelGGL(k_table_build<NielsP>, dim3((unsigned)((ntl + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table_lds, gl);
+      }
     }
     int bad = 0;
     std::vector<uint8_t> comp(mode == 1 ? 32 * n : 0);
@@ -1295,15 +1316,17 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     if (rc == SP_OK && hipGetLastError() != hipSuccess) rc = SP_EHIP;
     if (rc != SP_OK || bad) {
       (void)hipFree(table);
+      if (table_lds) (void)hipFree(table_lds);
       return rc != SP_OK ? rc : SP_EPOINT;
     }
-    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table});
+    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table, table_lds, lds_bits});
     hit = &g_gens_cache.back();
   }
   sp_gens* g = new (std::nothrow) sp_gens();
   if (!g) {
     if (hit->refs == 0) {  // just built for this call
       (void)hipFree(hit->table);
+      if (hit->table_lds) (void)hipFree(hit->table_lds);
       g_gens_cache.pop_back();
     }
     return SP_ENOMEM;
@@ -1314,6 +1337,8 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   g->n = n;
   g->table = hit->table;
   g->geom = msm_geom(hit->wbits);
+  g->table_lds = hit->table_lds;
+  g->geom_lds = msm_geom(hit->wbits_lds ? hit->wbits_lds : 10);
   g->cache_entry = hit;
   *out = g;
   return SP_OK;
@@ -1335,6 +1360,7 @@ void sp_gens_free(sp_gens* g) {
     if (--e->refs == 0) {
       host_commit_forget(e);
       (void)hipFree(e->table);
+      if (e->table_lds) (void)hipFree(e->table_lds);
       for (auto it = g_gens_cache.begin(); it != g_gens_cache.end(); ++it)
         if (&*it == e) { g_gens_cache.erase(it); break; }
     }
@@ -1346,21 +1372,25 @@ constexpr size_t SP_HOST_ENCODE_ROWS = 8;  // commitments of up to this many row
 // MSM launch plan: kernel shapes and scratch sizes for a (rows x cols) fixed-base commit
 struct MsmPlan {
   bool windowed, two_pass;
+  bool lds = false;  // the LDS-staged small-window form (msm_lds.hip), P = runs per row-block
   int flat;  // 0: strip form; 1 / 2: balanced form (k_msm_flat<0> / <1>), P = runs per row
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
 // workgroups of 256 threads the chip holds at once for the balanced row MSM (occupancy of the kernel x CUs), per device
 static size_t msm_flat_slots(int pipe) {
-  static size_t slots[2] = {0, 0};
-  if (!slots[pipe]) {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 768;
-    hipError_t e = pipe ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<1>, 256, 0);
-    if (e != hipSuccess || per_cu < 1) per_cu = 3;
-    slots[pipe] = (size_t)per_cu * (size_t)prop.multiProcessorCount;
-  }
-  return slots[pipe];
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, size_t> slots;  // (device, pipe) -> resident workgroups
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 768;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = slots.find({dev, pipe});
+  if (it != slots.end()) return it->second;
+  int per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 768;
+  hipError_t e = pipe ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<1>, 256, 0);
+  if (e != hipSuccess || per_cu < 1) per_cu = 3;
+  return slots[{dev, pipe}] = (size_t)per_cu * (size_t)prop.multiProcessorCount;
 }
 static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t bg_subblocks = 0 /* background launch: 256-thread tiles it runs at once */,
                         size_t launch_rows = 0 /* rows per launch when the commit is issued in row chunks (sp_commit_rows_upload_start) */,
@@ -1374,19 +1404,20 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
   if (m.windowed) {
     m.P = ncol * NWIN;
   } else {
-    static const size_t target_threads = [] { const char* e = getenv("SPARTAN_MSM_THREADS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 65536 ? v : (size_t)524288; }();
+    const SpOptions& opt = g->ctx->opt;
+    const size_t target_threads = (size_t)opt.v[OPT_MSM_STRIP_THREADS];
     m.strip = total / target_threads;  // enough threads for >= 4 waves per SIMD on 256 CUs
     if (m.strip < 1) m.strip = 1;
     if (m.strip > cols) m.strip = cols;
     m.nstrips = (cols + m.strip - 1) / m.strip;
     m.P = m.nstrips;
     // balanced form (A/B switch SPARTAN_MSM_FLAT: 0 = strip form, 1 = one entry in flight, 2 = two, the default)
-    static const int flat_mode = [] { const char* e = getenv("SPARTAN_MSM_FLAT"); int v = e ? atoi(e) : 2; return v >= 0 && v <= 2 ? v : 2; }();
+    const int flat_mode = (int)opt.v[OPT_MSM_FLAT];
     if (launch_rows == 0) launch_rows = rows;
     // the background launch keeps the strip form by default: its balanced form finishes a 768 x 4096 commit in 4.7 instead of 5.8 ms on 5/8 of
     // the chip, and the latency-bound kernels next to it (second sum-check, witness opening) then run 2x slower instead of 1.3x — the
     // proof loses more than the commit gains (profiles/r4_ab_msm_forms.txt); SPARTAN_MSM_FLAT_BG=1 selects it
-    static const bool flat_bg = [] { const char* e = getenv("SPARTAN_MSM_FLAT_BG"); return e && atoi(e) != 0; }();
+    const bool flat_bg = opt.v[OPT_MSM_FLAT_BG] != 0;
     // a foreground commit that shares the chip with a background one also keeps the strip form: the balanced form is exactly as many
     // workgroups as an EMPTY chip holds, each as long as the launch — with 5/8 of the CUs taken it would run in three uneven waves of
     // them (commit_nondet_witness 4.1 -> 4.55 ms), where the strip form's two thousand short workgroups fill whatever is free
@@ -1397,10 +1428,19 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
     if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && launch_rows / 256 <= 4 && (bg_subblocks ? flat_bg : !shares_chip)) {
       const size_t rb = launch_rows / 256, units = ncol * NWIN;
       size_t slots = bg_subblocks ? bg_subblocks : msm_flat_slots(flat_mode == 2 ? 1 : 0);
-      static const size_t rounds = [] { const char* e = getenv("SPARTAN_MSM_FLAT_ROUNDS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)1; }();
+      const size_t rounds = (size_t)opt.v[OPT_MSM_FLAT_ROUNDS];
       size_t nb = slots * rounds / rb;          // runs per row: the launch is `rounds` full sets of resident workgroups
       if (nb > units / 4) nb = units / 4;       // at least four additions per thread
       if (nb >= 1) { m.flat = bg_subblocks ? 1 : flat_mode; m.P = nb; }
+    }
+    // LDS-staged small-window form: a workgroup is up to 1024 rows, so it needs rows to fill a CU with (>= 768 for 3 waves per SIMD)
+    if (g->table_lds && opt.v[OPT_MSM_FORM] == 1 && launch_rows >= 512) {
+      const size_t cus = (size_t)g->ctx->n_cus;
+      // one workgroup per CU (96 KB of LDS each); next to a background commit the launch is cut three times finer, so that the CUs
+      // the background job leaves free are handed runs as they come
+      size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
+      m.lds = true; m.flat = 0;
+      m.P = msm_lds_runs(g, launch_rows, cols, has_blinds, slots);
     }
   }
   m.chunk = 1024; m.nchunks = (m.P + m.chunk - 1) / m.chunk;
@@ -1438,7 +1478,9 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * g->geom.nwin, shape);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
-    if (m.flat) {
+    if (m.lds) {
+      msm_lds_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
+    } else if (m.flat) {
       MsmFlatArgs A{dZ, z_stride, rows, cols, (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, (unsigned)m.P, (unsigned)(rows / 256), g->geom};
       const unsigned ntiles = A.nb * A.rb_count;
       if (st != c->stream && c->bg_blocks > 0)
@@ -1451,7 +1493,7 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
       hipLaunchKernelGGL(k_msm_rows_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
                          (const Niels*)g->table, g_off, partial, xcd_map, nblocks, g->geom);
     } else {
-      static const bool pf2 = getenv("SPARTAN_MSM_PREFETCH1") == nullptr;  // A/B switch: one table entry in flight instead of two
+      const bool pf2 = c->opt.v[OPT_MSM_PREFETCH] == 2;  // A/B switch: one table entry in flight instead of two
       if (pf2)
         hipLaunchKernelGGL(k_msm_rows<true>, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
                            (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
@@ -1495,7 +1537,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
     if (m.windowed) {
       size_t nblk = (m.P + 255) / 256;
       Pt10* part = (Pt10*)c->scratch;  // nblk * rows * 160 B <= part_bytes
-      static const bool fused = getenv("SPARTAN_MSM_UNFUSED") == nullptr;  // A/B switch: lookups + tree, reduction and flag as three launches
+      const bool fused = c->opt.v[OPT_MSM_FUSED_TREE] != 0;  // A/B switch: lookups + tree, reduction and flag as three launches
       if (fused && nblk > 1 && !c->device_encode && c->done_counter) {
         DoneSig sig = sig_make(c, nblk * rows);
         {
@@ -1626,8 +1668,8 @@ int32_t sp_commit_rows_upload_start(sp_ctx* c, const sp_gens* g, size_t g_off, s
       z_off + rows * cols > Z->cap)
     return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  static const size_t nch = [] { const char* e = getenv("SPARTAN_UPLOAD_CHUNKS"); size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0; return v >= 1 && v <= 16 ? v : (size_t)4; }();
-  static const bool chunked_on = getenv("SPARTAN_NO_UPLOAD_OVERLAP") == nullptr;  // A/B switch
+  const size_t nch = (size_t)c->opt.v[OPT_UPLOAD_CHUNKS];
+  const bool chunked_on = c->opt.v[OPT_UPLOAD_OVERLAP] != 0;  // A/B switch
   MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, chunked_on && rows % (256 * nch) == 0 ? rows / nch : 0, c->bg_inflight > 0);
   if (!chunked_on || m.windowed || rows % (256 * nch) != 0) {
     HIPCHK(hipMemcpyAsync(Z->d + z_off, src, 32 * rows * cols, hipMemcpyHostToDevice, c->stream));

@@ -39,6 +39,12 @@ struct alignas(SP_NIELS_ALIGN) Niels {
   Fp yp, ym, t2d;  // y+x, y-x, 2*d*x*y
 };
 
+// the same three values packed at 96 bytes: the entry format of the LDS-staged small-window MSM (msm_lds.hip), whose sub-tables are streamed
+// into LDS whole (coalesced, no per-lane gather from HBM: no line to align to)
+struct NielsP {
+  Fp yp, ym, t2d;
+};
+
 SP_HD Pt pt_identity() { return Pt{fp_zero(), fp_one(), fp_one(), fp_zero()}; }
 
 // RFC 9496 §4.2 SQRT_RATIO_M1

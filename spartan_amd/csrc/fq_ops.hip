@@ -352,7 +352,7 @@ extern "C" {
 // r_host: the same ell scalars on the host (ell <= 13: they go into the kernel arguments); dr: their copy in the host-mapped page (the fallback)
 static void launch_eq_small(sp_ctx* c, const Fq* dr, const uint64_t* r_host, size_t ell, Fq* out) {
   size_t len = (size_t)1 << ell;
-  static const bool inline_args = getenv("SPARTAN_NO_INLINE_ARGS") == nullptr;  // A/B switch
+  const bool inline_args = c->opt.v[OPT_SUMCHECK_INLINE_ARGS] != 0;  // A/B switch
   EqR in;
   const bool inl = inline_args && r_host && ell <= 13;
   if (inl) memcpy(in.r, r_host, 32 * ell);

@@ -13,6 +13,7 @@
 #include "curve.hpp"
 #include "field.hpp"
 #include "msm.hpp"
+#include "options.hpp"
 
 using namespace sp;
 
@@ -60,6 +61,8 @@ struct sp_job {
 
 struct sp_ctx {
   int dev;
+  SpOptions opt;  // options.hpp: a copy of the process-wide defaults at creation, changed by sp_ctx_set_option
+  int n_cus = 256;
   hipStream_t stream;
   hipStream_t stream_side;  // same priority as `stream`: small commitments that run NEXT TO a sum-check kernel of the same round
   hipEvent_t side_ev;
@@ -88,7 +91,6 @@ struct sp_ctx {
   uint32_t done_seq;
   uint32_t* done_counter = nullptr;  // DoneSig::counter
   long long* ktime = nullptr;        // DoneSig::kt (SP_KTIME builds with SPARTAN_KTIME set)
-  uint32_t* grid_tickets = nullptr;  // k_cubic_grid: per-instance and global tickets, zero between launches
   uint8_t *vm_pinned = nullptr, *vm_dstage = nullptr;  // sp_vecmat_dev's own staging pair for L: the call does not wait (core.hip: vm_stage)
   size_t vm_cap = 0;
   hipEvent_t vm_ev = nullptr;
@@ -115,6 +117,8 @@ struct sp_gens {
   size_t n;
   Niels* table;  // [n][nwin][tent]; owned by the process-wide table cache (core.hip), shared between contexts
   MsmGeom geom;  // window geometry these tables were built with
+  NielsP* table_lds = nullptr;  // [n][nwin][tent] packed entries of the LDS-staged form (msm_lds.hip), or null when the set was built without it
+  MsmGeom geom_lds;
   void* cache_entry;
 };
 struct sp_index {  // a usize vector kept as u32 on the device (addresses of the SPARK memory checks)
@@ -255,6 +259,12 @@ extern "C" int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t 
                               const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride = 0,
                               Pt* points_out = nullptr /* rows <= 8: the row sums as extended points instead of encodings */);
 // idx_row_stride: 0 = every row uses idx[0..cols); otherwise row r uses idx[r*idx_row_stride ..] (latency path only)
+
+// LDS-staged small-window row MSM (msm_lds.hip): runs per row-block for `wg_slots` resident workgroups; enqueue of the lookups
+// (partial[row][nb] extended points; the reduction is the caller's, as for the other forms). grid_limit != 0: persistent form on that many workgroups
+size_t msm_lds_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t wg_slots);
+void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
+                     const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit);
 
 static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {
   size_t b = (work + 255) / 256;

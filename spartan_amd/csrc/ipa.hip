@@ -49,10 +49,7 @@ struct IpaRoundArgs {
 };
 extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A, DoneSig* sig_out, int unified);
 static unsigned ipa_c0_blocks(size_t n) { return (unsigned)((n / 2 + 511) / 512); }  // k_ipa_init: one workgroup per 512 index pairs
-static bool ipa_fused() {
-  static const bool on = getenv("SPARTAN_IPA_UNFUSED") == nullptr;  // A/B switch: three launches + flag kernel per round (the round-2 path)
-  return on;
-}
+static bool ipa_fused(const sp_ctx* c) { return c->opt.v[OPT_IPA_FUSED] != 0; }  // A/B switch (0): three launches + flag kernel per round (the round-2 path)
 
 // L = <a_L, G_R> + c_L Q + blind_L H and R = <a_R, G_L> + c_R Q + blind_R H (bullet.rs:83-97) over the ORIGINAL generators:
 // generator j = p*n_cur + i belongs to L when i >= h (scalar a[i-h]*s[p]) and to R when i < h (scalar a[h+i]*s[p]), so
@@ -255,7 +252,7 @@ static int32_t ipa_begin(sp_ctx* c, const sp_gens* g, size_t g_off, size_t n, si
   // c_L, c_R of the first round ride along with whatever this call waits for: into the result page, clear of the row sums
   Fq* c0_dst = (Fq*)(hres(c) + HOST_SUM_BYTES);  // [30720, 31744): between the partial sums and the row sums of the last KiB
   const unsigned nblk0 = ipa_c0_blocks(n) ? ipa_c0_blocks(n) : 1;
-  const bool want_c0 = ipa_fused() && n >= 2 && !c->device_encode && nblk0 <= 16;  // 16 partial pairs = 1 KiB of the page
+  const bool want_c0 = ipa_fused(c) && n >= 2 && !c->device_encode && nblk0 <= 16;  // 16 partial pairs = 1 KiB of the page
   {
     ProfScope ps(c, PF_IPA, 128.0 * (double)n);
     hipLaunchKernelGGL(k_ipa_init, dim3(nblk0), dim3(256), 0, c->stream, a_src, (const Fq*)pb, n, g_off, (uint32_t)q_idx, (uint32_t)h_idx, ipa->a, ipa->b, ipa->s,
@@ -330,7 +327,7 @@ static int32_t ipa_round_start(sp_ipa* ipa, Fq* cL_out, Fq* cR_out, DoneSig* sig
 }
 static bool ipa_round_fusable(const sp_ipa* ipa) {
   const sp_ctx* c = ipa->ctx;
-  return ipa_fused() && !c->device_encode && ipa->n_cur <= 16384 && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0));
+  return ipa_fused(c) && !c->device_encode && ipa->n_cur <= 16384 && ((ipa->fold_pending && ipa->have_dots) || (!ipa->fold_pending && ipa->have_c0));
 }
 static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uint64_t blind_R[4], uint8_t L_out[32], uint8_t R_out[32]) {
   sp_ctx* c = ipa->ctx;
@@ -361,7 +358,7 @@ static int32_t ipa_round_fused(sp_ipa* ipa, const uint64_t blind_L[4], const uin
   if (fp_is_zero(sums[0].Z) || fp_is_zero(sums[1].Z)) {
     // no valid point has Z = 0: an addition of the two-multiplication tree met one of its exceptional pairs (core.hip, pt10_tree_quad_ded:
     // a generator list that repeats a point). The round is run again with the unified formula: same inputs, same outputs otherwise.
-    if (getenv("SPARTAN_IPA_NO_RERUN")) return SP_EHIP;  // test-only: shows that a test input reached this path
+    if (!c->opt.v[OPT_IPA_RERUN_EXCEPTIONAL]) return SP_EHIP;  // test-only: shows that a test input reached this path
     DoneSig sig2;
     SPCHK(ipa_round_launch(c, ipa->g, ipa->last_args, &sig2, 1));
     SPCHK(sig_wait(c, sig2));
@@ -498,7 +495,7 @@ static Pt pt_var_msm2(const Pt& P1, const Fq& k1_mont, const Pt& P2, const Fq& k
 // (tests/test_gpu_large.py compares with the device path). Falls back to the device when a'[0] or a'[1] is zero (no such multiple),
 // when the round ran unfused, or with SPARTAN_IPA_FINISH_DEVICE=1 (the A/B switch).
 static bool ipa_finish_on_host(sp_ipa* ipa, const uint64_t d[4], const uint64_t r[4], uint64_t a_hat[4], uint64_t b_hat[4], uint8_t delta_out[32]) {
-  static const bool off = getenv("SPARTAN_IPA_FINISH_DEVICE") != nullptr;
+  const bool off = ipa->ctx->opt.v[OPT_IPA_FINISH_DEVICE] != 0;
   if (off || !ipa->have_fin || !ipa->fold_pending || ipa->ctx->device_encode) return false;
   const Fq &a0 = ipa->fin_a[0], &a1 = ipa->fin_a[1], &b0 = ipa->fin_b[0], &b1 = ipa->fin_b[1], &u = ipa->fu, &ui = ipa->fu_inv;
   if (fq_is_zero(a0) || fq_is_zero(a1)) return false;

@@ -81,28 +81,13 @@ SP_HD int msm_digit(const Fq& s, int w) { return msm_digit(s, w, msm_geom(MSM_WB
 // acc += s * P[pt] using P's window table. `s` is the reference's Montgomery-form Scalar. The table entry of the
 // next window is requested before the current mixed addition so the gather latency overlaps the 7 multiplications.
 // PF2: two table entries in flight instead of one (26 more registers: the foreground row MSM has them, the 1024-thread background form has not)
-#ifdef SP_EXP_E64
-// TIMING EXPERIMENT ONLY (wrong results): entries read as 64 bytes (y+x, y-x) at a 64-byte stride, 2dxy recomputed with two
-// multiplications when the entry is consumed
-struct MsmEntry { Fp yp, ym; };
-SP_HD Niels msm_entry_niels(const MsmEntry& e) {
-  Niels n; n.yp = e.yp; n.ym = e.ym;
-  n.t2d = fp_mul(fp_mul(fp_sub(e.yp, e.ym), fp_add(e.yp, e.ym)), fp_D2());
-  return n;
-}
-#else
 typedef Niels MsmEntry;
 SP_HD const Niels& msm_entry_niels(const MsmEntry& e) { return e; }
-#endif
 // the 96 bytes of an entry, field by field (with SP_NIELS_ALIGN=128 a struct copy would also move the 32 bytes of padding)
 SP_HD MsmEntry msm_load(const MsmEntry* p) {
-#ifdef SP_EXP_E64
-  return *p;
-#else
   MsmEntry e;
   e.yp = p->yp; e.ym = p->ym; e.t2d = p->t2d;
   return e;
-#endif
 }
 template <bool PF2>
 SP_HD void msm_accumulate_t(Pt& acc, const Fq& s_mont, const Niels* __restrict__ table, size_t pt, const MsmGeom& g) {

@@ -1,0 +1,72 @@
+// spartan_amd: the library's options. Every tunable is a NAMED OPTION of a context with a compiled-in default — set with
+// sp_ctx_set_option(ctx, "key", "value") (include/spartan_hip.h), never by an environment variable read somewhere inside a kernel
+// launcher. (The reference has three cargo features and no environment variables: Cargo.toml:64-78.)
+//
+//   tier 0  deployment tuning: memory budgets, the background share of the CUs, sharding thresholds, the MSM form.
+//   tier 1  A/B and test switches: alternative placements and launch forms that produce the SAME BYTES (every one is exercised by
+//           tests/test_gpu_proofs.py::test_every_ab_switch_gives_the_same_proof). Refused (SP_EINVAL) until the caller has set
+//           "testing.unlock" = 1 on the same context (or process-wide): a production caller cannot trip into them.
+//
+// sp_ctx_set_option(NULL, ...) changes the process-wide defaults that contexts created afterwards start from (and the few options that
+// are process-wide by nature, marked PROC). The ONE environment hook is SPARTAN_OPTIONS="key=value,key=value", applied to the
+// process-wide defaults when the library first needs them: it is how A/B scripts reach the same table without a recompile.
+#pragma once
+#include <cstdint>
+
+// X(id, key, default, min, max, tier, doc)
+#define SP_OPTION_TABLE(X)                                                                                                                  \
+  X(TESTING_UNLOCK, "testing.unlock", 0, 0, 1, 0, "1: accept tier-1 (A/B / test) options on this context")                                   \
+  X(MSM_FORM, "msm.form", 0, 0, 1, 0, "row MSM of >= 512 rows: 0 = wide-window tables gathered from HBM, 1 = LDS-staged small windows (needs msm.lds_bits at set creation)") \
+  X(MSM_LDS_BITS, "msm.lds_bits", 0, 0, 10, 0, "window width of the LDS-staged form's tables built with a generator set (0 = not built; 10 = 48 KB sub-tables, double-buffered)") \
+  X(MSM_WBITS, "msm.wbits", 0, 0, 15, 0, "force the wide tables' window width (4..15); 0 = chosen by the policy below")                       \
+  X(MSM_TABLE_GB, "msm.table_gb", 170, 1, 100000, 0, "HBM budget of one generator set's wide tables, GB")                                    \
+  X(MSM_WIDE_GB, "msm.wide_gb", 80, 1, 100000, 0, "15-bit windows only while the set's tables stay under this many GB")                      \
+  X(BG_EIGHTHS, "bg.eighths", 5, 0, 8, 0, "share of the CUs (in eighths) the background half of the derefs commitment runs on; 0 = plain low-priority launches") \
+  X(UPLOAD_CHUNKS, "upload.chunks", 4, 1, 16, 0, "row chunks the witness upload + commit is issued in (each chunk's additions behind its PCIe copy)") \
+  X(SHARD_COLS, "shard.cols", 1, 0, 1, 0, "column-sharded commitments for commits with fewer rows than shards")                              \
+  X(SHARD_RESIDUES, "shard.residues", 1, 0, 1, 0, "index-residue sharding of sum-check tables, bound and evaluate")                          \
+  X(SHARD_RESIDUE_MIN_LOG2, "shard.residue_min_log2", 22, 0, 64, 0, "over multi-process transports: shard a sum-check when its tables have >= 2^this entries (0 = always, 64 = never)") \
+  X(HOST_KECCAK, "host.keccak", 0, 0, 3, 0, "PROC. Keccak-f[1600] form of the host transcript: 0 = fastest by calibration, 1 = plain, 2 = BMI2, 3 = AVX-512") \
+  X(HOST_PROOF_GATE, "host.proof_gate", 0, 0, 1, 0, "PROC. several proofs in flight on one device: admit one at a time to the throughput-bound part") \
+  X(SYNC_KERNEL_SIGNAL, "sync.kernel_signal", 1, 0, 1, 1, "completion raised by the last kernel of a trip (0: a flag kernel behind it)")     \
+  X(IPA_UNIFIED_TREE, "ipa.unified_tree", 0, 0, 1, 1, "inner-product rounds always with the unified (complete) addition tree")               \
+  X(IPA_FUSED, "ipa.fused", 1, 0, 1, 1, "one launch per inner-product round (0: prepare + lookups + reduce)")                                \
+  X(IPA_RERUN_EXCEPTIONAL, "ipa.rerun_exceptional", 1, 0, 1, 1, "re-run a round with the unified tree when the dedicated tree met an exceptional sum") \
+  X(IPA_FINISH_DEVICE, "ipa.finish_device", 0, 0, 1, 1, "the end of an inner-product argument on the device instead of the proving core")     \
+  X(ENCODE_DEVICE, "encode.device", 0, 0, 1, 1, "every RFC 9496 encode on the device (few-row commitments are encoded by the proving core by default)") \
+  X(COMMIT_SMALL_DEVICE, "commit.small_device", 0, 0, 1, 1, "the 2..5-term Sigma-protocol commitments on the device instead of the proving core") \
+  X(MSM_STRIP_THREADS, "msm.strip_threads", 524288, 65536, 16777216, 1, "threads a strip-form row MSM launch aims for")                      \
+  X(MSM_FLAT, "msm.flat", 2, 0, 2, 1, "balanced (column, window) form of the wide row MSM: 0 = strip form only, 1 = one entry in flight, 2 = two") \
+  X(MSM_FLAT_BG, "msm.flat_bg", 0, 0, 1, 1, "balanced form for the background launch too")                                                   \
+  X(MSM_FLAT_ROUNDS, "msm.flat_rounds", 1, 1, 16, 1, "sets of resident workgroups a balanced launch is cut into")                            \
+  X(MSM_PREFETCH, "msm.prefetch", 2, 1, 2, 1, "table entries in flight in the strip form")                                                   \
+  X(MSM_FUSED_TREE, "msm.fused_tree", 1, 0, 1, 1, "single-row commitments in one launch (0: lookups + tree, reduction, flag)")               \
+  X(UPLOAD_OVERLAP, "upload.overlap", 1, 0, 1, 1, "witness commit issued in row chunks behind the upload")                                   \
+  X(UPLOAD_THREAD, "upload.thread", 1, 0, 1, 1, "witness upload + commit issued by a helper thread while the proving thread hashes the transcript prefix") \
+  X(SUMCHECK_INLINE_ARGS, "sumcheck.inline_args", 1, 0, 1, 1, "table pointers of the batched sum-check kernels in the kernel arguments")      \
+  X(SUMCHECK_DOUBLE_ROUND_MAX_LEN, "sumcheck.double_round_max_len", 4096, 0, 1073741824, 1, "two rounds per trip while the tables have at most this many entries") \
+  X(SUMCHECK_HOST_TAIL, "sumcheck.host_tail", 1, 0, 1, 1, "last <= 3 rounds of a batched sum-check on the proving core")                     \
+  X(SPARK_PROD_LAYER2, "spark.prod_layer2", 1, 0, 1, 1, "two product-circuit layers per launch in the launch-sized middle of the tree")       \
+  X(SPARK_PROD_LAYER2_MAX_LOG2, "spark.prod_layer2_max_log2", 18, 0, 40, 1, "... for layers of at most 2^this entries")                      \
+  X(SPARK_EQ_FACTOR, "spark.eq_factor", 1, 0, 1, 1, "the eq table as a factor in the throughput-sized batched rounds")                       \
+  X(SPARK_HASH_FUSE, "spark.hash_fuse", 1, 0, 1, 1, "hash layer + first product layer in one pass")                                          \
+  X(OVERLAP_DEREFS, "overlap.derefs", 1, 0, 1, 1, "row half of the derefs commitment on the background stream under the second sum-check")    \
+  X(OVERLAP_EVAL_AHEAD, "overlap.eval_ahead", 1, 0, 1, 1, "R1CSInstance::evaluate queued on a low-priority stream as soon as ry is known")    \
+  X(OVERLAP_COL_HALF, "overlap.col_half", 0, 0, 1, 1, "column half of derefs queued behind the row half on the background stream")           \
+  X(SHARD_RESIDUE_TRANSPORT, "shard.residue_transport", 0, 0, 1, 1, "residue-shard every sum-check over multi-process transports (= shard.residue_min_log2 0)") \
+  X(SHARD_CUBIC_MIN_LEN, "shard.cubic_min_len", 0, 0, 1073741824, 1, "batched cubic sum-checks stay sharded while a bind leaves at least this many entries (a power of two >= 32; 0 = twice sumcheck.double_round_max_len)") \
+  X(HOST_INVERT_CHAIN, "host.invert_chain", 0, 0, 1, 1, "challenge inversion by the addition chain instead of division steps")               \
+  X(HOST_CALLSTATS, "host.callstats", 0, 0, 1, 1, "PROC. per-entry-point wall time on stderr at exit")                                        \
+  X(DEBUG_KTIME, "debug.ktime", 0, 0, 1, 1, "SP_KTIME builds: in-kernel time stamps")
+
+enum SpOpt {
+#define X(id, key, def, lo, hi, tier, doc) OPT_##id,
+  SP_OPTION_TABLE(X)
+#undef X
+  OPT_COUNT
+};
+struct SpOptDesc { const char* key; long long def, lo, hi; int tier; const char* doc; };
+extern const SpOptDesc kOptDesc[OPT_COUNT];
+struct SpOptions { long long v[OPT_COUNT]; };
+// process-wide defaults (compiled-in defaults overlaid by SPARTAN_OPTIONS once, then by sp_ctx_set_option(NULL, ...))
+const SpOptions& sp_default_options();

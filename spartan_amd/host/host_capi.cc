@@ -121,7 +121,6 @@ int spz_cubic_tail_probe(uint64_t* tab, size_t ni, size_t m, const uint64_t* coe
   memcpy(evs, e.data(), 32 * e.size());
   return (int)rounds;
 }
-// grid with `axes` axes (4^axes scalars) and one challenge per axis -> the 4 values s(0..3) each round sends (spark.inc: RoundGrid)
 int spz_eq_factor_probe(const uint64_t* rho, size_t nvars, size_t np, size_t ni, const uint64_t* coeffs, size_t nrounds, const uint64_t* claims,
                         const uint64_t* ev4, const uint64_t* challenges, uint64_t* evc_out, uint64_t* K_out) {
   auto vec = [](const uint64_t* p, size_t n) { FqVec v(n); memcpy(v.data(), p, 32 * n); return v; };
@@ -130,11 +129,6 @@ int spz_eq_factor_probe(const uint64_t* rho, size_t nvars, size_t np, size_t ni,
   memcpy(evc_out, evc.data(), 32 * evc.size());
   memcpy(K_out, K.data(), 32 * K.size());
   return 1;
-}
-void spz_round_grid_probe(const uint64_t* F, int axes, const uint64_t* challenges, uint64_t* msgs) {
-  FqVec f = limbs_vec(F, (size_t)1 << (2 * axes)), ch = limbs_vec(challenges, (size_t)axes), m;
-  round_grid_probe(f, axes, ch, &m);
-  memcpy(msgs, m.data(), 32 * m.size());
 }
 int spz_unipoly_probe(const uint64_t* evals, size_t n, const uint64_t r[4], uint64_t* coeffs, uint64_t* compressed, uint64_t eval_at_r[4]) {
   try {
@@ -197,8 +191,8 @@ size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
   if (out && cap >= v.size()) memcpy(out, v.data(), v.size());
   return v.size();
 }
-// few-term commitments: where they run (0 device, 1 this core through sp_host_commit_small, -1 SPARTAN_SMALL_MSM)
-void spz_set_small_msm_mode(int mode) { small_msm_set_mode(mode); }
+// library options of the context (include/spartan_hip.h: sp_ctx_set_option); ctx == NULL: the process-wide defaults
+int spz_ctx_set_option(void* ctx, const char* key, const char* value) { return sp_ctx_set_option(ctx ? ((Ctx*)ctx)->h : nullptr, key, value); }
 // window width of the fixed-base tables of a generator stream (0: gens_r1cs_sat, 1: gens_r1cs_eval)
 int spz_snark_gens_window_bits(void* g, int which) { return sp_gens_window_bits(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
 size_t spz_snark_gens_table_bytes(void* g, int which) { return sp_gens_table_bytes(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }

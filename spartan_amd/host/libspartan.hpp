@@ -30,6 +30,13 @@ struct Error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
+// value of a library option of the context (spartan_amd/csrc/options.hpp; sp_ctx_set_option): the driver's own switches live in the same table
+inline long long ctx_opt(const sp_ctx* c, const char* key) {
+  int64_t v = 0;
+  if (sp_ctx_get_option(c, key, &v) != SP_OK) throw std::runtime_error(std::string("unknown library option ") + key);
+  return (long long)v;
+}
+
 // ---- device handles (RAII) ----
 struct Ctx {
   sp_ctx* h = nullptr;
@@ -53,7 +60,6 @@ void cubic_coeffs_probe(const Fq S[12], const Fq& r, Fq ev[3]);                 
 void cubic_tail_probe(FqVec& tab, size_t ni, size_t m, const FqVec& coeffs, const FqVec& challenges, FqVec* evs);  // test hook (spark.inc)
 bool eq_factor_probe(const FqVec& rho, size_t np, size_t ni, const FqVec& coeffs, const FqVec& claims, const FqVec& ev4, const FqVec& challenges, FqVec* evc_out,
                      FqVec* K_out);  // test hook (spark.inc)
-void round_grid_probe(const FqVec& F, int axes, const FqVec& challenges, FqVec* msgs);                                  // test hook (spark.inc)
 typedef int (*CommitGatherFn)(void* user, uint8_t* buf, size_t total, size_t off, size_t len);
 void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* user);
 void rccl_unique_id(uint8_t out[128]);
@@ -68,7 +74,7 @@ void commit_shard_note_gather(sp_ctx* c, size_t bytes);
 // callback / RCCL transport configured: this rank's place among the lock-step ranks, and the table length (log2) from which a sum-check is
 // residue-sharded over it (resolved once when the sharding was configured, identical on every rank: shard.cc, check_switches_agree)
 bool commit_shard_transport(sp_ctx* c, int* rank, int* world, int* residue_min_log2 = nullptr);
-bool commit_shard_residue_off(sp_ctx* c);  // SPARTAN_NO_RESIDUE_SHARDS as resolved when the sharding was configured
+bool commit_shard_residue_off(sp_ctx* c);  // option shard.residues = 0 as resolved when the sharding was configured
 void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per);   // all-gather of `per` bytes per rank over that transport (rank order)
 double rccl_allgather_probe(sp_ctx* c, size_t bytes, int iters);  // us per H2D + ncclAllGather + D2H + sync of `bytes` per rank
 bool commit_shard_shared_seed(sp_ctx* c, Fq* seed);  // multi-rank transports only: a hash of every rank's OS-entropy contribution, the same on every rank
@@ -317,8 +323,7 @@ std::vector<uint8_t> serialize_r1cs_proof(const R1CSProof& p);
 
 // Where the few-term commitments of the Sigma protocols run: on the proving thread's core through the library's host-side
 // engine (sp_host_commit_small / sp_host_zk_ahead_*, csrc/host_commit.hip — the default) or on the GPU (sp_msm_indexed;
-// SPARTAN_SMALL_MSM=device). Byte-identical proofs either way.
-bool small_msm_on_host();
-void small_msm_set_mode(int mode);  // 0 device, 1 host, -1 environment (tests)
+// option commit.small_device = 1). Byte-identical proofs either way.
+inline bool small_msm_on_host(const sp_ctx* c) { return ctx_opt(c, "commit.small_device") == 0; }
 
 }  // namespace spz

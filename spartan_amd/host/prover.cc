@@ -19,12 +19,12 @@ namespace spz {
 using namespace sp;
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-// optional per-entry-point wall-clock accounting (SPARTAN_CALLSTATS=1): where the latency of a proof accumulates.
+// optional per-entry-point wall-clock accounting (option host.callstats = 1): where the latency of a proof accumulates.
 // Diagnostic only: the table is process-wide and unsynchronised, so use it with one proving thread.
 struct CallStats {
   struct E { double t = 0; size_t n = 0; };
   std::map<std::string, E> m;
-  bool on = getenv("SPARTAN_CALLSTATS") != nullptr;
+  bool on = ctx_opt(nullptr, "host.callstats") != 0;  // process-wide option (SPARTAN_OPTIONS=testing.unlock=1,host.callstats=1)
   ~CallStats() { dump(); }
   void dump() {
     if (!on || m.empty()) return;
@@ -341,7 +341,7 @@ static std::vector<CP> msm_rows(sp_ctx* c, const sp_gens* g, const std::vector<u
   REQUIRE(scalars.size() == rows * idx.size());
   std::vector<uint8_t> out(32 * rows);
   // few-term commitments: on this core unless told otherwise (the library's host-side engine, csrc/host_commit.hip)
-  if (idx.size() <= 8 && small_msm_on_host()) SPX(sp_host_commit_small(g, idx.data(), idx.size(), U(scalars), rows, nullptr, out.data()));
+  if (idx.size() <= 8 && small_msm_on_host(c)) SPX(sp_host_commit_small(g, idx.data(), idx.size(), U(scalars), rows, nullptr, out.data()));
   else SPX(sp_msm_indexed(c, g, idx.data(), idx.size(), U(scalars), rows, out.data()));
   std::vector<CP> r(rows);
   for (size_t i = 0; i < rows; i++) r[i] = to_cp(&out[32 * i]);
@@ -483,17 +483,6 @@ static ProductProof product_prove(sp_ctx* c, const MultiCommitGens& g, Transcrip
 }
 
 // Where the few-term commitments run (libspartan.hpp)
-static std::atomic<int> g_small_mode{-1};  // -1: read SPARTAN_SMALL_MSM on first use; 0: device; 1: host
-void small_msm_set_mode(int mode) { g_small_mode.store(mode, std::memory_order_relaxed); }
-bool small_msm_on_host() {
-  int m = g_small_mode.load(std::memory_order_relaxed);
-  if (m < 0) {
-    const char* e = getenv("SPARTAN_SMALL_MSM");
-    m = (e && strcmp(e, "device") == 0) ? 0 : 1;
-    g_small_mode.store(m, std::memory_order_relaxed);
-  }
-  return m == 1;
-}
 
 // The tape-only halves of a ZK sum-check's commitments, computed ahead of the rounds by the library's helper thread
 // (sp_host_zk_ahead_*, csrc/host_commit.hip) while the proving thread is in its first evaluation: the DotProductProof's
@@ -553,7 +542,7 @@ struct ResidueShards {
       // SURVEY 8e over real ranks: every rank has the full tables (it computed them like every other rank) and keeps only its residue
       // class from here on; a round's partial sums travel over the transport the sharded commitments use (96 bytes per rank). Chosen by
       // TABLE LENGTH: the exchange (26 us over RCCL) must be shorter than the round it shortens — tables of >= 2^22 entries (DESIGN.md,
-      // section 6); SPARTAN_RESIDUE_MIN_LOG2 moves the threshold, SPARTAN_RESIDUE_TRANSPORT=1 is the old "always"
+      // section 6); option shard.residue_min_log2 moves the threshold, shard.residue_transport = 1 is the old "always"
       W = (size_t)world; me = (size_t)rank; remote = true;
       ctxs.assign(1, c);
     } else {
@@ -652,8 +641,8 @@ static ZKSumcheckInstanceProof zk_sumcheck_prove(sp_ctx* c, int kind, const Fq& 
   idx_u.push_back(g1.h);
   size_t nn = gn.n(), W = idx_u.size();
   // The round's 2..5-term commitments: on this core (small_msm.cc) while the device binds and evaluates, or — with
-  // SPARTAN_SMALL_MSM=device — two launches per round on the device
-  const bool on_host = small_msm_on_host() && gn.g == g1.g;
+  // option commit.small_device = 1 — two launches per round on the device
+  const bool on_host = small_msm_on_host(c) && gn.g == g1.g;
   ZkAhead ahead;
   if (on_host) {
     ahead.d.resize(num_rounds); ahead.r_delta.resize(num_rounds); ahead.r_beta.resize(num_rounds);
@@ -876,10 +865,11 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
   SPX(sp_ipa_begin_dev(c, gn.g, gn.G[0], n, g1.G[0], gn.h, x.h, U(a), U(blind_x), Cx.data(), &ipa));
   // the first round's kernel needs neither r nor the blinds: in flight while this core absorbs Cx, Cy and `a` (no device call in between:
   // Cy comes from the host-side engine)
-  if (small_msm_on_host() && n >= 2 && sp_ipa_round_prelaunch(ipa) != SP_OK) { sp_ipa_free(ipa); throw Error("sp_ipa_round_prelaunch failed"); }
+  if (small_msm_on_host(c) && n >= 2 && sp_ipa_round_prelaunch(ipa) != SP_OK) { sp_ipa_free(ipa); throw Error("sp_ipa_round_prelaunch failed"); }
   DotProductProofLog p;
   Fq blind_hat, r;
   CP Cy;
+  const bool invert_chain = ctx_opt(c, "host.invert_chain") != 0;
   try {
     t.append_point("Cx", Cx.data());
     Cy = commit_scalar(c, y, blind_y, g1);
@@ -898,7 +888,7 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
       u = t.challenge_scalar("u"); }
       { HSPAN("ipa_invert");
       // u is a public challenge: division steps (fq_inv.hpp, ~1 us) instead of the a^(q-2) chain (~6 us), same value
-      static const bool chain = getenv("SPARTAN_INVERT_CHAIN") != nullptr;  // A/B switch
+      const bool chain = invert_chain;  // A/B switch (option host.invert_chain, read once per argument)
       u_inv = chain ? fq_invert(u) : fq_invert_vartime(u); }
       SPX(sp_ipa_round_fold(ipa, U(u), U(u_inv)));
       blind_hat = blind_hat + v1[k] * u * u + v2[k] * u_inv * u_inv;
@@ -1007,8 +997,8 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
     if (!vars_resident && nvars_given && !upload_commit) SPX(sp_table_write(c, poly_vars.h, 0, vars[0].l, nvars_given));
     // A copy out of pageable memory keeps the calling thread busy until the bytes have left the caller's buffer (0.75 ms for 32 MB), and
     // the transcript prefix (the computation commitment: 0.65 ms of Keccak at 2^20) needs no device: the upload + commit is issued by a
-    // helper thread while this one hashes; the context is not touched here before the join. SPARTAN_NO_UPLOAD_THREAD=1: one thread (A/B).
-    static const bool upload_thread = getenv("SPARTAN_NO_UPLOAD_THREAD") == nullptr;
+    // helper thread while this one hashes; the context is not touched here before the join. Option upload.thread = 0: one thread (A/B).
+    const bool upload_thread = ctx_opt(c, "upload.thread") != 0;
     std::thread uploader;
     int32_t up_rc = SP_OK;
     if (upload_commit && upload_thread && transcript_prefix)

@@ -83,21 +83,22 @@ struct ShardState {
   // Switches that decide whether a rank ENTERS a collective. They are read from the environment ONCE, when the sharding is configured,
   // kept here, and — for the multi-process transports — compared across the ranks before the first proof (a rank whose environment
   // differs would otherwise deadlock in ncclAllGather or diverge from the others' transcripts).
-  bool no_shard_cols = false;    // SPARTAN_NO_SHARD_COLS: few-row commitments are not column-sharded
-  bool no_residue = false;       // SPARTAN_NO_RESIDUE_SHARDS: sum-check tables are never residue-sharded
-  bool device_encode = false;    // SPARTAN_DEVICE_ENCODE (read by sp_ctx_create too): sp_commit_rows_partial is unavailable -> no column sharding
-  int residue_min_log2 = 22;     // multi-process transports: tables of >= 2^k entries are residue-sharded (SPARTAN_RESIDUE_MIN_LOG2; DESIGN.md section 6:
+  bool no_shard_cols = false;    // option shard.cols = 0: few-row commitments are not column-sharded
+  bool no_residue = false;       // option shard.residues = 0: sum-check tables are never residue-sharded
+  bool device_encode = false;    // option encode.device: sp_commit_rows_partial is unavailable -> no column sharding
+  int residue_min_log2 = 22;     // multi-process transports: tables of >= 2^k entries are residue-sharded (option shard.residue_min_log2; DESIGN.md section 6:
                                  // a round must outlast the ~26 us exchange, i.e. >= 2^22 entries per table; 0 = always, 64 = never)
 };
 std::mutex g_mu;
 std::map<sp_ctx*, ShardState> g_state;
 
-void read_switches(ShardState& s) {
-  s.no_shard_cols = getenv("SPARTAN_NO_SHARD_COLS") != nullptr;
-  s.no_residue = getenv("SPARTAN_NO_RESIDUE_SHARDS") != nullptr;
-  s.device_encode = getenv("SPARTAN_DEVICE_ENCODE") != nullptr;
-  if (const char* e = getenv("SPARTAN_RESIDUE_MIN_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 64) s.residue_min_log2 = v; }
-  if (getenv("SPARTAN_RESIDUE_TRANSPORT")) s.residue_min_log2 = 0;  // the round-3 opt-in: every sum-check, whatever its size
+// the sharding-related options of the context (options.hpp), resolved ONCE when the sharding is configured and compared across the ranks
+void read_switches(sp_ctx* c, ShardState& s) {
+  s.no_shard_cols = !ctx_opt(c, "shard.cols");
+  s.no_residue = !ctx_opt(c, "shard.residues");
+  s.device_encode = ctx_opt(c, "encode.device") != 0;
+  s.residue_min_log2 = (int)ctx_opt(c, "shard.residue_min_log2");
+  if (ctx_opt(c, "shard.residue_transport")) s.residue_min_log2 = 0;  // the round-3 opt-in: every sum-check, whatever its size
 }
 void release(ShardState& s) {
   if (s.comm || s.dbuf || s.stream) (void)hipSetDevice(s.dev);
@@ -122,8 +123,8 @@ void check_switches_agree(ShardState& s) {
   gather_bytes(s, all.data(), 8);
   for (size_t r = 0; r < W; r++)
     if (memcmp(&all[8 * r], mine, 8) != 0)
-      throw Error("set_commit_shard: rank " + std::to_string(r) + " resolved the sharding switches (SPARTAN_NO_SHARD_COLS / SPARTAN_NO_RESIDUE_SHARDS / "
-                  "SPARTAN_DEVICE_ENCODE / SPARTAN_RESIDUE_MIN_LOG2) differently from rank " + std::to_string(s.rank) + ": the ranks would not enter the same collectives");
+      throw Error("set_commit_shard: rank " + std::to_string(r) + " resolved the sharding options (shard.cols / shard.residues / "
+                  "encode.device / shard.residue_min_log2) differently from rank " + std::to_string(s.rank) + ": the ranks would not enter the same collectives");
 }
 
 }  // namespace
@@ -146,7 +147,7 @@ void set_commit_shard(Ctx& c, int rank, int world, CommitGatherFn gather, void* 
   if (!gather || rank < 0 || rank >= world) throw Error("set_commit_shard: bad arguments");
   ShardState s;
   s.mode = 1; s.rank = rank; s.world = world; s.gather = gather; s.user = user;
-  read_switches(s);
+  read_switches(c.h, s);
   check_switches_agree(s);
   std::lock_guard<std::mutex> lk(g_mu);
   g_state[c.h] = s;
@@ -168,7 +169,7 @@ void set_commit_shard_rccl(Ctx& c, int rank, int world, const uint8_t unique_id[
   memcpy(id.internal, unique_id, 128);
   hip_ok(hipSetDevice(s.dev), "hipSetDevice");  // the communicator and its stream belong to the context's GPU, whatever the calling thread had current
   hip_ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
-  read_switches(s);
+  read_switches(c.h, s);
   try {
     nccl_ok(rccl().CommInitRank(&s.comm, world, id, rank), "ncclCommInitRank");
     check_switches_agree(s);
@@ -184,11 +185,12 @@ void set_commit_shard_virtual(Ctx& c, int nshards) {
   if (nshards <= 1) return;
   ShardState s;
   s.mode = 3; s.rank = 0; s.world = nshards;
-  read_switches(s);
+  read_switches(c.h, s);
   int dev = s.dev = sp_ctx_device(c.h);
   for (int k = 1; k < nshards; k++) {
     sp_ctx* v = nullptr;
     if (sp_ctx_create(dev, &v) != SP_OK) { release(s); throw Error("set_commit_shard_virtual: sp_ctx_create failed"); }
+    (void)sp_ctx_copy_options(v, c.h);  // a virtual shard runs with its parent's settings
     s.vctx.push_back(v);
   }
   std::lock_guard<std::mutex> lk(g_mu);
@@ -365,7 +367,7 @@ void commit_shard_gather(sp_ctx* c, uint8_t* all, size_t per) {
 // rendering of the north-star's "partial bucket sums": shard k sums the generators [k Rs/W, (k+1) Rs/W) of every row into one partial
 // point per row (sp_commit_rows_partial), the W x Ls points (128 bytes each) are gathered — RCCL has no elliptic-curve reduction, so
 // the "all-reduce" is an all-gather and a local addition — and every rank adds them, adds the blind terms and encodes
-// (sp_host_points_sum_encode): the same points as the unsharded sum, hence the same bytes. Off with SPARTAN_NO_SHARD_COLS=1.
+// (sp_host_points_sum_encode): the same points as the unsharded sum, hence the same bytes. Off with option shard.cols = 0.
 static bool sharded_commit_cols(ShardState& s, sp_ctx* c, const sp_gens* g, size_t g_off, size_t h_idx, const sp_table* Z, size_t Ls, size_t Rs,
                                 const uint64_t* blinds, uint8_t* out /*32*Ls*/) {
   const size_t W = (size_t)s.world;

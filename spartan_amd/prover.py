@@ -37,6 +37,12 @@ class Ctx:
         """the underlying sp_ctx* (for profiling calls through spartan_amd.capi.lib)"""
         return vp(H.spz_ctx_raw(self.h))
 
+    def set_option(self, key, value):
+        """a library option of this context (sp_ctx_set_option; table: spartan_amd/csrc/options.hpp). Tier-1 (A/B / test) options need
+        set_option("testing.unlock", 1) first."""
+        if H.spz_ctx_set_option(self.h, key.encode(), str(int(value)).encode()) != 0:
+            raise SpartanHipError(f"set_option({key}, {value}) refused")
+
     def set_commit_shard(self, dist, device="cpu"):
         """row-shard every DensePolynomial::commit over the ranks of `dist`, the bytes moved by torch.distributed
         (spartan_amd/shard.py; gloo in the CPU tests); None clears it. All ranks must then run identical prove() calls in lock-step."""

@@ -12,6 +12,12 @@ vp = ctypes.c_void_p
 sz = ctypes.c_size_t
 
 
+
+def options_env(**kv):
+    """SPARTAN_OPTIONS value (the library's one environment hook, spartan_amd/csrc/options.hpp) for a worker process: keys are written
+    with `__` for the dot (msm__flat=0 -> msm.flat=0); A/B / test options are unlocked first"""
+    return ",".join(["testing.unlock=1"] + ["%s=%d" % (k.replace("__", "."), int(v)) for k, v in kv.items()])
+
 def _build_if_missing(path, cmd, cwd=ROOT):
     if not os.path.exists(path):
         subprocess.check_call(cmd, cwd=cwd, shell=True)

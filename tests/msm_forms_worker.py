@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_kernels.py::test_row_msm_forms_match_oracle: the row MSM's launch form is chosen once per process
-(SPARTAN_MSM_FLAT = 0 strip form / 1 balanced, rolled / 2 balanced, two entries in flight; SPARTAN_MSM_FLAT_BG=1: the balanced background
-form), so every form runs in a process of its own. Shapes that only these plans select, each against the oracle's orc_commit_rows:
+(option msm.flat = 0 strip form / 1 balanced, rolled / 2 balanced, two entries in flight; msm.flat_bg = 1: the balanced background
+form; msm.form = 1 with msm.lds_bits = 10: the LDS-staged small-window form — all through SPARTAN_OPTIONS), so every form runs in a process of its own. Shapes that only these plans select, each against the oracle's orc_commit_rows:
 blinds (an extra column that starts or ends a run in the middle of a scalar), rows of zeros, short scalars (the early exit of the strip form
 and the ballot skip of the balanced form: SNARK::encode's addresses and timestamps, src/sparse_mlpoly.rs:483-503), scalars with only high
 bits set (carries into the top window), a run boundary inside the signed recoding's carry chain, and the background kernel."""
@@ -51,7 +51,7 @@ def check(rows, cols, kind, blinds, background=False):
         got = g.commit_rows_wait(g.commit_rows_begin(t, rows, cols, g_off=0))
     else:
         got = g.commit_rows(t, rows, cols, bl, g_off=0, h_idx=cols)
-    assert got == bytes(want), "row MSM mismatch: %dx%d %s blinds=%s bg=%s FLAT=%s" % (rows, cols, kind, blinds, background, os.environ.get("SPARTAN_MSM_FLAT"))
+    assert got == bytes(want), "row MSM mismatch: %dx%d %s blinds=%s bg=%s FLAT=%s" % (rows, cols, kind, blinds, background, os.environ.get("SPARTAN_OPTIONS"))
     t.free(); g.free()
     checked += 1
 
@@ -63,5 +63,16 @@ check(1024, 48, "mixed", True)           # four row-blocks
 check(2048, 40, "short", False)          # eight row-blocks: strip form in every mode (heterogeneous rows)
 check(768, 128, "uniform", False, background=True)
 check(768, 128, "zero_rows", False, background=True)
+if ctx.get_option("msm.form") == 1:
+    # the LDS-staged small-window form (msm_lds.hip) takes every launch of >= 512 rows: row-blocks that are not a multiple of a wavefront,
+    # two and three row-blocks, runs that start inside a scalar, the blind as the last column, every scalar kind, the persistent background form
+    for kind in ("uniform", "short", "zero_rows", "high", "carry", "mixed"):
+        check(576, 40, kind, True)
+    check(1000, 33, "uniform", True)
+    check(1536, 24, "mixed", False)
+    check(1100, 20, "carry", True)
+    check(2112, 10, "uniform", True)
+    check(768, 128, "mixed", False, background=True)
+    check(1536, 300, "uniform", False, background=True)
 print("MSM_FORMS_OK %d" % checked)
 ctx.close()

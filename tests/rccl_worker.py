@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_shard.py::test_rccl_transport_on_every_visible_gpu: one of WORLD_SIZE lock-step ranks, ONE GPU EACH, the
 library's own RCCL transport (ncclAllGather on device buffers over xGMI, spartan_amd/host/shard.cc) carrying everything the sharded proof
-exchanges: the row-sharded commitments, the shared tape seed, and — with SPARTAN_RESIDUE_TRANSPORT=1 — the partial sums and hand-overs of
+exchanges: the row-sharded commitments, the shared tape seed, and — with option shard.residue_transport = 1 — the partial sums and hand-overs of
 the residue-sharded ZK and batched cubic sum-checks and the chunk-sharded evaluations. The sharded proofs (SNARK with a fixed tape, NIZK,
 and a SNARK with an OS-entropy tape checked for equality ACROSS ranks) must equal the unsharded ones."""
 import os, sys

@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_shard.py::test_residue_sharded_sumchecks_over_the_process_transport: one of two lock-step ranks (gloo) on the
-test box's single GPU. With SPARTAN_RESIDUE_TRANSPORT=1 each rank keeps one residue class of the ZK sum-check tables and the rounds'
+test box's single GPU. With option shard.residue_transport = 1 each rank keeps one residue class of the ZK sum-check tables and the rounds'
 partial sums travel over the commit transport (SURVEY 8e, K3/K4 over real ranks): the proof must equal the one the same rank computed
 before sharding was configured, on both ranks, and the transport must have carried the rounds."""
 import os, sys
@@ -30,7 +30,7 @@ assert ngot == nref, "sharded NIZK proof differs on rank %d" % rank
 lw = 1
 want_rounds = (s - lw + 1) + (s + 1 - lw + 1)
 assert st["gathers"] >= 2 + want_rounds, (st, want_rounds)
-if os.environ.get("SPARTAN_CUBIC_SHARD_MIN_LEN"):
+if "shard.cubic_min_len" in os.environ.get("SPARTAN_OPTIONS", ""):
     # the batched cubic sum-checks sharded over the two ranks as well (pack -> gather -> scatter hand-over), plus the two chunk-sharded
     # evaluation batches of the hash layer: strictly more exchanges than the ZK sum-checks alone
     assert st["gathers"] >= 2 + want_rounds + 2 + 5, (st, want_rounds)

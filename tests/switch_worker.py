@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_proofs.py::test_every_ab_switch_gives_the_same_proof: most A/B switches of the library and of the host driver are
-read once per process, so each setting proves in a process of its own: SNARK::prove at 2^17 (the smallest size at which the batched sum-checks
+"""Worker of tests/test_gpu_proofs.py::test_every_ab_switch_gives_the_same_proof: the options of the library and of the host driver
+are handed to a fresh process through SPARTAN_OPTIONS, so each setting proves in a process of its own: SNARK::prove at 2^17 (the smallest size at which the batched sum-checks
 have throughput-sized rounds, i.e. at which the eq-factor path and its hand-over run), seed and tape fixed; prints the SHA-256 of the proof."""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -117,9 +117,54 @@ def test_rust_seams_call_what_the_driver_calls():
             found |= {m for m in re.findall(r"\b(sp_\w+)\s*\(", src) if m in declared}
         return found
     host = os.path.join(ROOT, "spartan_amd", "host")
-    driver = calls([os.path.join(host, "prover.cc"), os.path.join(host, "spark.inc"), os.path.join(host, "shard.cc")])
+    driver = calls([os.path.join(host, "prover.cc"), os.path.join(host, "spark.inc"), os.path.join(host, "shard.cc"), os.path.join(host, "libspartan.hpp")])
     seams = calls(glob.glob(os.path.join(ROOT, "rust_shim", "seams", "*.rs")) + [os.path.join(ROOT, "rust_shim", "src", "gpu_tail.rs.in")])
     assert len(driver) >= 55
     assert driver - seams == set(), f"called by the C++ driver, by no Rust seam: {sorted(driver - seams)}"
     # what only the Rust side touches: helpers of its own handle types (the C++ side keeps its shard contexts in shard.cc)
     assert seams - driver <= {"sp_gens_upload", "sp_table_download", "sp_ctx_device"}, f"called by a seam, never by the driver: {sorted(seams - driver)}"
+
+
+def test_option_table_and_tiers():
+    """The library's tunables are named options (spartan_amd/csrc/options.hpp, sp_ctx_set_option), not environment variables: unknown keys and
+    out-of-range values are refused, A/B / test options (tier 1) are refused until testing.unlock is set, every option has a documented
+    default inside its range. (Process-wide defaults: no GPU needed.)"""
+    import subprocess, sys
+    from spartan_amd import capi
+    table = capi.options_table()
+    assert len(table) >= 40 and len({k for k, *_ in table}) == len(table)
+    for key, default, lo, hi, tier, doc in table:
+        assert lo <= default <= hi and tier in (0, 1) and len(doc) > 10, key
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from spartan_amd import capi
+L = capi.lib
+v = ctypes.c_int64()
+assert L.sp_ctx_set_option(None, b"no.such.option", b"1") == -1
+assert L.sp_ctx_set_option(None, b"bg.eighths", b"9") == -1 and L.sp_ctx_set_option(None, b"bg.eighths", b"x") == -1
+assert L.sp_ctx_set_option(None, b"spark.eq_factor", b"0") == -1          # tier 1: locked
+assert L.sp_ctx_get_option(None, b"spark.eq_factor", ctypes.byref(v)) == 0 and v.value == 1
+assert L.sp_ctx_set_option(None, b"testing.unlock", b"1") == 0 and L.sp_ctx_set_option(None, b"spark.eq_factor", b"0") == 0
+assert L.sp_ctx_get_option(None, b"spark.eq_factor", ctypes.byref(v)) == 0 and v.value == 0
+assert L.sp_ctx_get_option(None, b"bg.eighths", ctypes.byref(v)) == 0 and v.value == 6      # from SPARTAN_OPTIONS
+print("OPTIONS_OK")
+""" % ROOT
+    env = dict(os.environ, SPARTAN_OPTIONS="bg.eighths=6")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OPTIONS_OK" in r.stdout, r.stderr[-2000:]
+    # a misspelt or locked entry in SPARTAN_OPTIONS must not silently measure the default: the process stops
+    for bad in ("bg.eigths=6", "spark.eq_factor=0", "bg.eighths=99"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPARTAN_OPTIONS=bad), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "refused" in r.stderr, (bad, r.stderr[-500:])
+
+
+def test_no_environment_switches_in_the_product_sources():
+    """one getenv in the library (SPARTAN_OPTIONS, options.hip) and none in the host driver"""
+    import glob, re
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "spartan_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "spartan_amd", "host", "*")):
+        if os.path.isfile(f):
+            for m in re.finditer(r'getenv\("(\w+)"\)', open(f, errors="ignore").read()):
+                hits.append((os.path.basename(f), m.group(1)))
+    assert hits == [("options.hip", "SPARTAN_OPTIONS")], hits

@@ -110,11 +110,11 @@ def test_commit_rows_launch_plans_match_oracle(ctx, orc, gens301, rows, cols, bl
 
 @pytest.mark.parametrize("wbits", [5, 6, 8, 10, 12, 13, 14, 15])
 def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
-    """the window width is a property of the generator set, chosen at upload (core.hip choose_wbits; SPARTAN_MSM_WBITS forces
+    """the window width is a property of the generator set, chosen at upload (core.hip choose_wbits; option msm.wbits forces
     it): every width gives the same commitments through every launch plan (one-launch small, windowed trees, row strips, the
     indexed lookups of the inner-product argument)"""
     from spartan_amd import capi
-    monkeypatch.setenv("SPARTAN_MSM_WBITS", str(wbits))
+    ctx.set_option("msm.wbits", wbits)   # read when a generator set is built
     label = b"gens_width_%d" % wbits      # fresh points per width: a resident table set would be reused whatever its width
     g = capi.Gens(ctx, compressed=gens_bytes(orc, 130, label))
     assert g.window_bits() == wbits
@@ -136,6 +136,7 @@ def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
         assert orc.orc_pt_msm(mont_array(S[r * 5:(r + 1) * 5]), pts, sz(5), out) == 1
         assert got[32 * r:32 * r + 32] == bytes(out)
     g.free()
+    ctx.set_option("msm.wbits", 0)
 
 
 def test_commit_rows_dev_and_offset(ctx, orc, gens40):
@@ -424,17 +425,22 @@ def test_dot3_many_matches_reference_arithmetic(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"SPARTAN_MSM_FLAT": "0"}, {"SPARTAN_MSM_FLAT": "1"}, {"SPARTAN_MSM_FLAT": "2"}, {"SPARTAN_MSM_FLAT": "2", "SPARTAN_MSM_FLAT_BG": "1"},
-                                 {"SPARTAN_MSM_FLAT": "2", "SPARTAN_MSM_WBITS": "13", "SPARTAN_MSM_FLAT_ROUNDS": "3"}])
-def test_row_msm_forms_match_oracle(env):
+@pytest.mark.parametrize("opts,count", [({"msm__flat": 0}, 11), ({"msm__flat": 1}, 11), ({"msm__flat": 2}, 11), ({"msm__flat": 2, "msm__flat_bg": 1}, 11),
+                                        ({"msm__flat": 2, "msm__wbits": 13, "msm__flat_rounds": 3}, 11), ({"msm__lds_bits": 10, "msm__form": 1}, 23),
+                                        ({"msm__lds_bits": 8, "msm__form": 1, "bg__eighths": 3}, 23)])
+def test_row_msm_forms_match_oracle(opts, count):
     """Every launch form of the fixed-base row MSM (DensePolynomial::commit_inner, src/dense_mlpoly.rs:164-177) against the oracle: the strip
     form with its short-scalar early exit, the balanced (column, window) form rolled and with two entries in flight, its background
-    variant, another window width with three rounds of workgroups. The form is a per-process choice: tests/msm_forms_worker.py runs in a
-    process of its own per form (11 shapes each: blinds, zero rows, short / high-bit / carry-chain scalars, 1..8 row-blocks)."""
+    variant, another window width with three rounds of workgroups, and the LDS-staged small-window form (msm_lds.hip: 10-bit sub-tables
+    double-buffered in LDS; 8-bit ones on another background share) with shapes of its own — row-blocks that are not a multiple of a
+    wavefront, two and three row-blocks, runs that start inside a scalar, the persistent background form. The form is an option of the
+    context; tests/msm_forms_worker.py runs in a process of its own per setting (11 shapes each, 12 more for the LDS form: blinds, zero
+    rows, short / high-bit / carry-chain scalars, 1..8 row-blocks)."""
     import subprocess, sys
-    e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "msm_forms_worker.py"), "7"], env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "MSM_FORMS_OK 11" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    from tests.helpers import options_env
+    e = dict(os.environ, SPARTAN_OPTIONS=options_env(**opts))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "msm_forms_worker.py"), "7"], env=e, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "MSM_FORMS_OK %d" % count in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
 @pytest.mark.gpu

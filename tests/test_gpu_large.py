@@ -399,7 +399,7 @@ def test_inner_product_argument_exceptional_sums(ctx, orc, case):
         # the re-run really happened: with it switched off (test-only switch) the same argument must fail in its first round
         import os
         from spartan_amd import capi
-        os.environ["SPARTAN_IPA_NO_RERUN"] = "1"
+        ctx.set_option("testing.unlock", 1); ctx.set_option("ipa.rerun_exceptional", 0)
         try:
             g = capi.Gens(ctx, compressed=b"".join(P))
             ipa = vp()
@@ -409,7 +409,7 @@ def test_inner_product_argument_exceptional_sums(ctx, orc, case):
             capi.lib.sp_ipa_free(ipa)
             g.free()
         finally:
-            del os.environ["SPARTAN_IPA_NO_RERUN"]
+            ctx.set_option("ipa.rerun_exceptional", 1); ctx.set_option("testing.unlock", 0)
 
 
 def test_witness_sized_commit_every_row_matches_oracle(ctx, orc):
@@ -575,69 +575,6 @@ def test_short_tables_are_handed_over_with_the_round(ctx, ell, nbind):
         assert tables[0] == 0xFFFFFFFFFFFFFFFF
     for t in tA + tB + [tCpar] + tCseq:
         t.free()
-
-
-def _grid_reference(tabs_per_inst, weights, kd):
-    """sum over instances of w_i * F_i on {0,1,2,3}^kd, F_i(y) = sum_z prod_T T~(y, z), T~ multilinear in the top kd index bits"""
-    G = 4 ** kd
-    out = [0] * G
-    for (A, B, C), w in zip(tabs_per_inst, weights):
-        n2 = len(A)
-        ng = n2 >> kd
-
-        def ext(T, y):   # values T~(y, z) for all z: fold the top axis first
-            cur = T
-            for yi in y:
-                h = len(cur) // 2
-                cur = [(cur[z] + yi * (cur[h + z] - cur[z])) % Q for z in range(h)]
-            return cur
-        for g in range(G):
-            y = [(g // 4 ** (kd - 1 - i)) % 4 for i in range(kd)]
-            a, b, c = ext(A, y), ext(B, y), ext(C, y)
-            out[g] = (out[g] + w * sum(a[z] * b[z] * c[z] for z in range(ng))) % Q
-    return out
-
-
-@pytest.mark.parametrize("ell,nbind,kd", [(3, 0, 3), (5, 0, 3), (6, 3, 3), (7, 2, 3), (10, 3, 3), (10, 1, 3), (4, 0, 1), (5, 3, 2), (4, 1, 0), (3, 3, 0), (11, 1, 3), (2, 0, 2)])
-def test_grid_rounds_per_launch_match_reference_arithmetic(ctx, ell, nbind, kd):
-    """sp_sumcheck_grid_batched (spark.hip k_cubic_grid): up to three binds and the 4^kd sums of the grid {0,1,2,3}^kd from which
-    the host derives the next kd rounds of prove_cubic_batched (sumcheck.rs:287-393). Against Python integers: the grid (weighted
-    over 3 instances that share their C table and 2 that own theirs), the bound tables left on the device, the tables handed over
-    when they are short. 2^10 -> the longest tables the driver sends down this path (two workgroup levels of summation)."""
-    from spartan_amd import capi
-    n = 1 << ell
-    rng = random.Random(9300 + 16 * ell + 4 * nbind + kd)
-    npar, nseq = 3, 2
-    ni = npar + nseq
-    A = [fast_scalars(rng, n) for _ in range(ni)]
-    B = [fast_scalars(rng, n) for _ in range(ni)]
-    Cpar = fast_scalars(rng, n)
-    Cseq = [fast_scalars(rng, n) for _ in range(nseq)]
-    W = fast_scalars(rng, ni)
-    tA, tB = [up(ctx, a) for a in A], [up(ctx, b) for b in B]
-    tCpar, tCseq = up(ctx, Cpar), [up(ctx, c) for c in Cseq]
-    hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
-    hC = (vp * ni)(*([tCpar.h] * npar + [t.h for t in tCseq]))
-    rs = [rng.getrandbits(251) for _ in range(nbind)]
-    for r in rs:
-        A = [bind(a, r) for a in A]; B = [bind(b, r) for b in B]; Cpar = bind(Cpar, r); Cseq = [bind(c, r) for c in Cseq]
-    n2 = n >> nbind
-    grid = (ctypes.c_uint64 * (4 * 4 ** max(kd, 1)))()
-    tables = (ctypes.c_uint64 * (4 * ni * 3 * 8))()
-    rc = capi.lib.sp_sumcheck_grid_batched(ctx.h, hA, hB, hC, sz(ni), mont_bulk(rs) if rs else None, sz(nbind), mont_bulk(W), sz(kd), grid if kd else None, tables)
-    assert rc == 0
-    assert len(tA[0]) == n2 and len(tCpar) == n2 and len(tCseq[1]) == n2
-    assert from_mont_bulk(tA[1].download(n2), n2) == A[1] and from_mont_bulk(tB[4].download(n2), n2) == B[4]
-    assert from_mont_bulk(tCpar.download(n2), n2) == Cpar and from_mont_bulk(tCseq[0].download(n2), n2) == Cseq[0]
-    Cs = [Cpar] * npar + Cseq
-    if kd:
-        assert from_mont_bulk(grid, 4 ** kd) == _grid_reference([(A[i], B[i], Cs[i]) for i in range(ni)], W, kd)
-    if n2 <= 8:
-        got = from_mont_bulk(tables, ni * 3 * n2)
-        want = [x for i in range(ni) for T in (A[i], B[i], Cs[i]) for x in T]
-        assert got == want
-    else:
-        assert tables[0] == 2 ** 64 - 1 and tables[1] == 0
     for t in tA + tB + tCseq + [tCpar]:
         t.free()
 

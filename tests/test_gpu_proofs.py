@@ -420,17 +420,15 @@ def test_tiny_r1cs_of_the_reference(P, ctx, orc):
 
 def test_host_and_device_point_encoding_give_the_same_proof(P, orc, monkeypatch):
     """Commitments of up to 8 rows are summed on the GPU and encoded (RFC 9496 §4.3.2) by the calling host core, because one
-    serial inverse-square-root chain takes ~3 us there and ~100 us on a lone wavefront. SPARTAN_DEVICE_ENCODE
+    serial inverse-square-root chain takes ~3 us there and ~100 us on a lone wavefront. Option encode.device = 1
     keeps that chain on the GPU: both contexts must produce the oracle's bytes."""
     s, seed = 9, 21
     N = 1 << s
     proofs = []
     for device_encode in (False, True):
+        c = P.Ctx(0)
         if device_encode:
-            monkeypatch.setenv("SPARTAN_DEVICE_ENCODE", "1")
-        else:
-            monkeypatch.delenv("SPARTAN_DEVICE_ENCODE", raising=False)
-        c = P.Ctx(0)   # the knob is read when the context is created
+            c.set_option("testing.unlock", 1); c.set_option("encode.device", 1)
         inst = P.Instance.produce_synthetic_r1cs(c, N, N, 10, seed=seed)
         gens = P.SNARKGens(c, N, N, 10, N)
         enc = P.SNARK.encode(c, inst, gens)
@@ -445,7 +443,7 @@ def test_host_and_device_point_encoding_give_the_same_proof(P, orc, monkeypatch)
 
 def test_small_commitments_on_host_core_or_device_and_resident_assignment_give_the_same_proof(P, ctx, orc):
     """The 2..5-term commitments of the Sigma protocols run on the proving thread's core by default (small_msm.cc) and on
-    the GPU with SPARTAN_SMALL_MSM=device; the assignment may be a host buffer or a VarsAssignment already in HBM. Four
+    the GPU with option commit.small_device = 1; the assignment may be a host buffer or a VarsAssignment already in HBM. Four
     combinations, one proof — the oracle's — for SNARK and NIZK."""
     s, seed = 10, 33
     N = 1 << s
@@ -459,12 +457,12 @@ def test_small_commitments_on_host_core_or_device_and_resident_assignment_give_t
     snark, nizk = [], []
     try:
         for mode in (1, 0):
-            P.H.spz_set_small_msm_mode(ctypes.c_int(mode))
+            ctx.set_option("testing.unlock", 1); ctx.set_option("commit.small_device", 1 - mode)
             for v in (inst.vars, va):
                 snark.append(P.SNARK.prove(ctx, inst, enc, v, inst.inputs, gens, b"snark_example", tape))
                 nizk.append(P.NIZK.prove(ctx, inst, v, inst.inputs, ngens, b"nizk_example", tape))
     finally:
-        P.H.spz_set_small_msm_mode(ctypes.c_int(-1))
+        ctx.set_option("commit.small_device", 0); ctx.set_option("testing.unlock", 0)
     oi = vp(orc.orc_instance_synthetic(sz(N), sz(N), sz(10), ctypes.c_uint64(seed)))
     og = vp(orc.orc_snark_gens_new(sz(N), sz(N), sz(10), sz(N)))
     oe = vp(orc.orc_snark_encode(oi, og))
@@ -477,12 +475,15 @@ def test_small_commitments_on_host_core_or_device_and_resident_assignment_give_t
 
 
 def test_every_ab_switch_gives_the_same_proof(orc):
-    """Every optimisation of round 4's second half has an A/B switch that restores the form it replaced. All of them must give the oracle's
-    bytes: the eq table as a factor vs bound like any table (SPARTAN_NO_EQ_FACTOR), hash layers fused with the first multiplication layer
-    vs separate (SPARTAN_NO_HASH_FUSE), dedicated vs unified addition in the inner-product trees (SPARTAN_IPA_UNIFIED_TREE), the end of the
-    inner-product arguments on the proving core vs on the device (SPARTAN_IPA_FINISH_DEVICE), challenge inversion by division steps vs the
-    a^(q-2) chain (SPARTAN_INVERT_CHAIN), each Keccak-f form, the proof gate. One process per setting (tests/switch_worker.py) at 2^17 —
-    the smallest size with throughput-sized batched rounds — against the oracle's proof of the same instance and tape."""
+    """Every tier-1 option of the library (spartan_amd/csrc/options.hpp: the A/B switches that restore the form an optimisation replaced, or
+    move a piece of work between the proving core and the device) must give the oracle's bytes, and so must the tier-0 ones that change
+    launch plans: the eq table as a factor vs bound like any table, hash layers fused with the first multiplication layer vs separate,
+    dedicated vs unified addition in the inner-product trees, the end of the inner-product arguments on the proving core vs on the device,
+    challenge inversion by division steps vs the a^(q-2) chain, each Keccak-f form, the proof gate, one- vs two-round trips, the host tail,
+    the kernel-raised completion flag, inline kernel arguments, the upload thread and chunks, the overlap placements, every row-MSM form
+    including the LDS-staged one. One process per setting (tests/switch_worker.py, SPARTAN_OPTIONS) at 2^17 — the smallest size with
+    throughput-sized batched rounds — against the oracle's proof of the same instance and tape. The test also checks that no tier-1 option
+    of the table is left out of the list."""
     import hashlib, os, subprocess, sys
     s_, seed = 17, 5
     N = 1 << s_
@@ -493,15 +494,24 @@ def test_every_ab_switch_gives_the_same_proof(orc):
     oe = vp(orc.orc_snark_encode(oi, og))
     op = vp(orc.orc_snark_prove(oi, og, oe, b"snark_example", tape, None))
     want = hashlib.sha256(oracle_bytes(orc, op)).hexdigest()
-    settings = [{}, {"SPARTAN_NO_EQ_FACTOR": "1"}, {"SPARTAN_NO_HASH_FUSE": "1"}, {"SPARTAN_IPA_UNIFIED_TREE": "1"}, {"SPARTAN_IPA_FINISH_DEVICE": "1"},
-                {"SPARTAN_INVERT_CHAIN": "1"}, {"SPARTAN_KECCAK": "plain"}, {"SPARTAN_KECCAK": "bmi2"}, {"SPARTAN_KECCAK": "avx512"}, {"SPARTAN_PROOF_GATE": "1"},
-                {"SPARTAN_NO_EQ_FACTOR": "1", "SPARTAN_NO_HASH_FUSE": "1", "SPARTAN_IPA_UNIFIED_TREE": "1", "SPARTAN_IPA_FINISH_DEVICE": "1", "SPARTAN_INVERT_CHAIN": "1"}]
+    from tests.helpers import options_env
+    from spartan_amd import capi
+    settings = [{}, {"spark.eq_factor": 0}, {"spark.hash_fuse": 0}, {"ipa.unified_tree": 1}, {"ipa.finish_device": 1}, {"host.invert_chain": 1},
+                {"host.keccak": 1}, {"host.keccak": 2}, {"host.keccak": 3}, {"host.proof_gate": 1},
+                {"spark.eq_factor": 0, "spark.hash_fuse": 0, "ipa.unified_tree": 1, "ipa.finish_device": 1, "host.invert_chain": 1},
+                {"sync.kernel_signal": 0, "sumcheck.inline_args": 0, "msm.fused_tree": 0}, {"ipa.fused": 0}, {"encode.device": 1}, {"commit.small_device": 1},
+                {"sumcheck.double_round_max_len": 0, "sumcheck.host_tail": 0}, {"sumcheck.double_round_max_len": 512},
+                {"spark.prod_layer2": 0}, {"spark.prod_layer2_max_log2": 14}, {"upload.overlap": 0, "upload.thread": 0}, {"upload.chunks": 2},
+                {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"overlap.col_half": 1, "bg.eighths": 4}, {"bg.eighths": 0},
+                {"msm.flat": 0, "msm.prefetch": 1}, {"msm.flat": 1, "msm.flat_bg": 1, "msm.flat_rounds": 2}, {"msm.strip_threads": 131072, "msm.flat": 0},
+                {"msm.lds_bits": 10, "msm.form": 1}, {"msm.lds_bits": 9, "msm.form": 1, "overlap.derefs": 0}, {"msm.wbits": 11}]
+    covered = {k for st in settings for k in st}
+    not_proof_shaping = {"ipa.rerun_exceptional", "shard.residue_transport", "shard.cubic_min_len", "host.callstats", "debug.ktime"}  # their own tests (test_gpu_large, test_gpu_shard) / diagnostics
+    tier1 = {k for k, _d, _lo, _hi, tier, _doc in capi.options_table() if tier == 1}
+    assert tier1 - covered - not_proof_shaping == set(), "tier-1 options without an A/B run: %s" % sorted(tier1 - covered - not_proof_shaping)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for st in settings:
-        e = dict(os.environ)
-        for k in ("SPARTAN_NO_EQ_FACTOR", "SPARTAN_NO_HASH_FUSE", "SPARTAN_IPA_UNIFIED_TREE", "SPARTAN_IPA_FINISH_DEVICE", "SPARTAN_INVERT_CHAIN", "SPARTAN_KECCAK", "SPARTAN_PROOF_GATE"):
-            e.pop(k, None)
-        e.update(st)
+        e = dict(os.environ, SPARTAN_OPTIONS=options_env(**{k.replace(".", "__"): v for k, v in st.items()}))
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "switch_worker.py"), str(s_), str(seed)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (st, r.stdout[-2000:], r.stderr[-2000:])
         line = [l for l in r.stdout.splitlines() if l.startswith("PROOF_SHA256")]

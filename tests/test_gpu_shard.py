@@ -97,7 +97,7 @@ def test_batched_cubic_sumchecks_shard_by_residue(s, nshards, min_len):
     """SURVEY 8e for the phase that dominates the proof (ProductCircuitEvalProofBatched::prove -> prove_cubic_batched, src/product_tree.rs:259-383,
     src/sumcheck.rs:254-424): every table of a batch split by index residue over W virtual shards, the throughput-sized rounds run per shard
     with 96 * ninst bytes of partial evaluations exchanged per round, then the sub-tables are packed, gathered and scattered back
-    (sp_tables_pack / sp_tables_unpack_residues) and the latency-sized rounds continue unsharded. SPARTAN_CUBIC_SHARD_MIN_LEN lowers the
+    (sp_tables_pack / sp_tables_unpack_residues) and the latency-sized rounds continue unsharded. Option shard.cubic_min_len lowers the
     hand-over length (8192 by default) so that a 2^10 / 2^12 instance has sharded rounds. Bytes must equal the unsharded proof's, and the
     exchange count must be the formula's."""
     from spartan_amd import prover as P
@@ -108,17 +108,18 @@ def test_batched_cubic_sumchecks_shard_by_residue(s, nshards, min_len):
     enc = P.SNARK.encode(ctx, inst, gens)
     tape = P.seed_scalar(b"tape", s)
     ref = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
-    os.environ["SPARTAN_CUBIC_SHARD_MIN_LEN"] = "1073741824"   # no batched sum-check is long enough: the round-3 exchanges alone
+    ctx.set_option("testing.unlock", 1)
+    ctx.set_option("shard.cubic_min_len", 1073741824)   # no batched sum-check is long enough: the round-3 exchanges alone
     try:
         ctx.set_commit_shard_virtual(nshards)
         ctx.shard_stats(reset=True)
         assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
         base = ctx.shard_stats(reset=True)["gathers"]
-        os.environ["SPARTAN_CUBIC_SHARD_MIN_LEN"] = str(min_len)
+        ctx.set_option("shard.cubic_min_len", min_len)
         assert P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape) == ref
         got = ctx.shard_stats(reset=True)["gathers"]
     finally:
-        del os.environ["SPARTAN_CUBIC_SHARD_MIN_LEN"]
+        ctx.set_option("shard.cubic_min_len", 0)
     # Two product-circuit batches per proof (row/col layers of the ops circuits: leaves 2^s; of the memory circuits: leaves 2^(s+1)); a
     # layer sum-check over tables of L = 2^k * min_len entries (k >= 2) costs 1 first evaluation + (k + 1) binds + 1 hand-back exchanges
     def per_circuit(leaves):
@@ -135,7 +136,7 @@ def test_batched_cubic_sumchecks_shard_by_residue(s, nshards, min_len):
 
 def test_residue_shards_can_be_switched_off_and_nizk_matches():
     """NIZK::prove under 8 virtual shards (residue-sharded sum-checks, row-sharded bound, chunked evaluate) equals the unsharded
-    proof; SPARTAN_NO_RESIDUE_SHARDS=1 keeps only the commitment sharding (the A/B switch of DESIGN.md section 6)."""
+    proof; option shard.residues = 0 keeps only the commitment sharding (the A/B switch of DESIGN.md section 6)."""
     from spartan_amd import prover as P
     s = 14
     N = 1 << s
@@ -149,14 +150,14 @@ def test_residue_shards_can_be_switched_off_and_nizk_matches():
     ctx.shard_stats(reset=True)
     assert P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape) == ref
     full = ctx.shard_stats(reset=True)["gathers"]
-    os.environ["SPARTAN_NO_RESIDUE_SHARDS"] = "1"
+    ctx.set_option("shard.residues", 0)
     try:
         ctx.set_commit_shard_virtual(8)  # the switch is resolved when the sharding is configured (and compared across ranks there), not per proof
         ctx.shard_stats(reset=True)
         assert P.NIZK.prove(ctx, inst, inst.vars, inst.inputs, gens, b"nizk_example", tape) == ref
         assert ctx.shard_stats()["gathers"] == 1 and full == 1 + (s - 3 + 1) + (s - 3 + 2) + 1 + 1   # commit | + sum-checks, bound, evaluate
     finally:
-        del os.environ["SPARTAN_NO_RESIDUE_SHARDS"]
+        ctx.set_option("shard.residues", 1)
     ctx.set_commit_shard_virtual(1)
     gens.free(); inst.free(); ctx.close()
 
@@ -208,7 +209,7 @@ def test_column_sharded_commitment_of_a_small_instance_is_byte_identical():
     """SURVEY §8e, the north-star's "partial sums": a commitment with fewer rows than a shard is worth (2^6 constraints: the witness is
     8 rows x 8 columns) is sharded by COLUMNS — every shard sums its slice of the generators into one partial point per row
     (sp_commit_rows_partial), the points are gathered and added, the blind terms added and the sums encoded
-    (sp_host_points_sum_encode). Same points, same bytes; SPARTAN_NO_SHARD_COLS=1 is the single-GPU path for comparison."""
+    (sp_host_points_sum_encode). Same points, same bytes; option shard.cols = 0 is the single-GPU path for comparison."""
     from spartan_amd import prover as P
     s = 6
     N = 1 << s
@@ -265,12 +266,12 @@ def test_commit_rows_partial_and_sum_encode_equal_the_whole_commitment():
 def test_residue_sharded_sumchecks_over_the_process_transport():
     """SURVEY §8e K3/K4 over REAL ranks (not only virtual shards): two processes, each keeping one residue class of the ZK sum-check
     tables, the rounds' partial sums (96 bytes per rank) and the final hand-back over the callback transport. Opt-in
-    (SPARTAN_RESIDUE_TRANSPORT=1: at 2^20 the exchange costs more than the round); the proofs equal the unsharded ones."""
+    (option shard.residue_transport = 1: at 2^20 the exchange costs more than the round); the proofs equal the unsharded ones."""
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARTAN_RESIDUE_TRANSPORT="1",
-                   SPARTAN_CUBIC_SHARD_MIN_LEN="128")  # (round 4) the batched cubic sum-checks of SPARK and the hash layer's evaluations shard over the two ranks too
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SPARTAN_OPTIONS="testing.unlock=1,shard.residue_transport=1,shard.cubic_min_len=128")  # (round 4) the batched cubic sum-checks of SPARK and the hash layer's evaluations shard over the two ranks too
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "residue_transport_worker.py"), "12"], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -283,7 +284,7 @@ def test_residue_sharded_sumchecks_over_the_process_transport():
 
 def test_rccl_transport_on_every_visible_gpu():
     """Armed for the first multi-GPU box (SCALE runs): world = torch.cuda.device_count() lock-step ranks, one GPU each, the library's RCCL
-    transport over xGMI carrying the sharded commitments, the agreed tape seed and — SPARTAN_RESIDUE_TRANSPORT=1, a lowered hand-over length —
+    transport over xGMI carrying the sharded commitments, the agreed tape seed and — shard.residue_transport = 1, a lowered hand-over length —
     every residue-sharded sum-check (ZK and batched cubic) and the chunk-sharded evaluations. Skips on a single-GPU box, where the same
     transport has only ever been driven with a 1-rank communicator (test_rccl_transport_inside_the_library_single_rank)."""
     import torch
@@ -294,8 +295,8 @@ def test_rccl_transport_on_every_visible_gpu():
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPARTAN_RESIDUE_TRANSPORT="1",
-                   SPARTAN_CUBIC_SHARD_MIN_LEN="256", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SPARTAN_OPTIONS="testing.unlock=1,shard.residue_transport=1,shard.cubic_min_len=256", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), "14"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:

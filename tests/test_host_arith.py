@@ -212,40 +212,6 @@ def test_cubic_in_the_next_challenge_on_the_host():
     assert from_mont_array(ev, 3) == _cubic_evals(_bind(A, r), _bind(B, r), _bind(C, r))
 
 
-def test_round_grid_messages_and_contraction():
-    """RoundGrid (spark.inc): from F on {0,1,2,3}^k the host sends k rounds — s(t) = sum over the other axes' {0,1}, then the
-    Lagrange contraction at the challenge. Checked against the sum-check run directly on random multilinear tables in Python."""
-    import ctypes, random
-    from spartan_amd import prover
-    rng = random.Random(77)
-    for k in (1, 2, 3):
-        n = 1 << (k + 2)
-        tabs = [[rng.randrange(Q) for _ in range(n)] for _ in range(3)]
-
-        def ext(T, y):
-            cur = T
-            for yi in y:
-                h = len(cur) // 2
-                cur = [(cur[z] + yi * (cur[h + z] - cur[z])) % Q for z in range(h)]
-            return cur
-        F = []
-        for g in range(4 ** k):
-            y = [(g // 4 ** (k - 1 - i)) % 4 for i in range(k)]
-            a, b, c = (ext(T, y) for T in tabs)
-            F.append(sum(x * y_ * z for x, y_, z in zip(a, b, c)) % Q)
-        ch = [rng.randrange(Q) for _ in range(k)]
-        msgs = (ctypes.c_uint64 * (16 * k))()
-        prover.H.spz_round_grid_probe(mont_array(F), ctypes.c_int(k), mont_array(ch), msgs)
-        got = from_mont_array(msgs, 4 * k)
-        cur = tabs
-        for j in range(k):
-            want = []
-            for t in range(4):
-                a, b, c = (ext(T, [t]) for T in cur)
-                want.append(sum(x * y_ * z for x, y_, z in zip(a, b, c)) % Q)
-            assert got[4 * j:4 * j + 4] == want, (k, j)
-            cur = [ext(T, [ch[j]]) for T in cur]
-
 
 def test_challenge_inversion_by_division_steps():
     """fq_inv.hpp: the inner-product rounds invert their (public) challenge with Bernstein-Yang division steps instead of the
