@@ -1,13 +1,14 @@
 #!/bin/bash
-# A/B harness: `bash scripts/gpu_ab.sh OUTDIR REPS "NAME1:ENV1=..,ENV2=.." "NAME2:" ...` runs bench.py (headline step only) REPS times per
-# variant, interleaved, and prints the per-variant ms/step (min / median) — box-to-box and run-to-run noise is +-0.5 ms per proof.
+# A/B harness: `bash scripts/gpu_ab.sh OUTDIR REPS "NAME1:opt.a=1,opt.b=0" "NAME2:" ...` runs bench.py (headline step only) REPS times per
+# variant, interleaved, each with its library options (spartan_amd/csrc/options.hpp) handed over through SPARTAN_OPTIONS, and prints the
+# per-variant ms/step (min / median) — box-to-box and run-to-run noise is +-0.5 ms per proof. AB_LOG2 (default 20) picks the size.
 O=gpurun_out/$1; REPS=$2; shift 2
 mkdir -p $O
-Q="--no-cpu-baseline --concurrent 0 --steps 20 --warmup 2 --no-side-metrics --no-strong"
+Q="--no-cpu-baseline --concurrent 0 --steps ${AB_STEPS:-20} --warmup 2 --no-side-metrics --no-strong --log2-cons ${AB_LOG2:-20}"
 for rep in $(seq 1 $REPS); do
   for v in "$@"; do
     name=${v%%:*}; envs=${v#*:}
-    env $(echo $envs | tr ',' ' ') timeout 200 python bench.py $Q > $O/ab_${name}_$rep.json 2>$O/ab_${name}_$rep.err
+    SPARTAN_OPTIONS="testing.unlock=1${envs:+,$envs}" BENCH_NO_GATHER_PROBE=1 timeout ${AB_TIMEOUT:-200} python bench.py $Q > $O/ab_${name}_$rep.json 2>$O/ab_${name}_$rep.err
   done
 done
 python - $O <<'PY'

@@ -25,7 +25,6 @@
 // (DPP point-addition trees, k_msm_reduce / k_pt_encode).
 #include "internal.hpp"
 
-#include <atomic>
 
 static_assert(sizeof(NielsP) == 96, "packed Niels entry");
 
@@ -41,26 +40,81 @@ struct MsmLdsArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// one run of tiles for one row-block; blockDim.x lanes, lanes >= rows_per_wg (or past the last row) only help with the DMA
-__device__ __forceinline__ void msm_lds_run(const MsmLdsArgs& A, unsigned wg, uint8_t* lds) {
+// DIAG (timing experiments of `make variant NAME=ldsdiag FLAGS=-DSP_LDS_DIAG` only; WRONG RESULTS unless 0): bit 0 no DMA, bit 1 no barrier,
+// bit 2 no LDS gather (one fixed entry), bit 3 no addition — what each stage of a tile costs (bench/msm_lds_probe.py ... diag).
+// First measurement (profiles/r5_lds_diag_v1.txt, 1536 x 4096): the additions alone 7.1 of 8.1 ms; the DMA costs 0.8 ms although it has a
+// whole addition to land in — its ISSUE does: right after the barrier every wave of the CU queues its 3-4 LDS-DMA pieces (~100 cycles of
+// issue each) before any of them starts multiplying. So the pieces are issued from INSIDE the addition, one after each of its first
+// multiplications, by whichever wave gets there: the other waves of the SIMD multiply meanwhile.
+__device__ __forceinline__ Fp lds_fp(const uint8_t* p) {  // 32 bytes of an entry out of LDS (two ds_read_b128)
+  const uint4* e = reinterpret_cast<const uint4*>(p);
+  uint4 a = e[0], b = e[1];
+  return Fp{{(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32), (uint64_t)b.z | ((uint64_t)b.w << 32)}};
+}
+// = pt_madd (curve.hpp) against the entry at `e` in LDS: branch-free, each field of the entry read just before the multiplication that
+// needs it (8 live registers of entry instead of 24), hook(k) after multiplication k
+template <class Hook>
+__device__ __forceinline__ Pt pt_madd_lds(const Pt& p, const uint8_t* e, bool neg, Hook&& hook) {
+  // p - n = p + (-n), and -n swaps y+x with y-x and negates 2dxy: no branch on the sign anywhere
+  Fp A = fp_mul(fp_sub(p.Y, p.X), lds_fp(e + (neg ? 0 : 32)));   // n.ym, or n.yp for a subtraction
+  hook(0);
+  Fp B = fp_mul(fp_add(p.Y, p.X), lds_fp(e + (neg ? 32 : 0)));
+  hook(1);
+  Fp t2 = lds_fp(e + 64);
+  Fp C = fp_mul(p.T, fp_select(t2, fp_neg(t2), neg));
+  hook(2);
+  Fp Dd = fp_add(p.Z, p.Z);
+  Fp E = fp_sub(B, A), H = fp_add(B, A);
+  Fp F = fp_sub(Dd, C), G = fp_add(Dd, C);
+  Fp X3 = fp_mul(E, F);
+  hook(3);
+  return Pt{X3, fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
+}
+
+// one run of tiles (bk of nb) for one row-block rb; blockDim.x lanes, lanes >= rows_per_wg (or past the last row) only help with the DMA
+template <int DIAG>
+__device__ __forceinline__ void msm_lds_run(const MsmLdsArgs& A, unsigned rb, unsigned bk, uint8_t* lds) {
   const unsigned T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
-  const unsigned rb = wg % A.nrb, bk = wg / A.nrb;
   const size_t row = (size_t)rb * A.rows_per_wg + tid;
   const bool live = tid < A.rows_per_wg && row < A.rows;
   const int nwin = A.nwin, c = A.wbits;
   const size_t ncol = A.cols + (A.blinds ? 1 : 0);
   const size_t U = ncol * (size_t)nwin;
   const size_t u0 = U * bk / A.nb, u1 = U * (bk + 1) / A.nb;
-  const unsigned sub_bytes = (unsigned)A.tent * 96u;   // a multiple of 1 KB for every width >= 5: the DMA loop's trip count is wave-uniform
+  const unsigned sub_bytes = (unsigned)A.tent * 96u;   // a multiple of 1 KB for every width >= 5: the number of DMA pieces is wave-uniform
+  const unsigned npieces = ((sub_bytes >> 10) + (T >> 6) - 1) / (T >> 6);  // 1 KB pieces per wavefront when every wavefront issues its share
+  // LDS: [buffer 0][buffer 1][the neutral entry (1, 1, 0): what a lane with a zero digit adds]
+  const unsigned ident_off = 2 * sub_bytes;
+  if (tid < 6) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tid == 0 || tid == 2) v.x = 1;  // yp = 1, ym = 1 (limb 0), t2d = 0
+    reinterpret_cast<uint4*>(lds + ident_off)[tid] = v;
+  }
   auto scalar_ptr = [&](size_t jj) { return jj < A.cols ? A.Z + row * A.z_row_stride + jj : A.blinds + row; };
-  auto dma = [&](size_t u, unsigned buf) {
-    const size_t jj = u / (size_t)nwin;
-    const int ww = (int)(u % (size_t)nwin);
+  auto col_base = [&](size_t jj) {  // the window tables of column jj's generator (wave-uniform)
     const size_t pt = jj < A.cols ? (A.idx ? (size_t)A.idx[jj] : A.g_off + jj) : A.h_idx;
-    const uint8_t* src = reinterpret_cast<const uint8_t*>(A.table + (pt * (size_t)nwin + (size_t)ww) * (size_t)A.tent);
-    uint8_t* dst = lds + buf * sub_bytes;
-    for (unsigned off = tid * 16u; off < sub_bytes; off += T * 16u)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + off), (lds_ptr_t)(dst + (off - lane * 16u)), 16, 0, 0);
+    return reinterpret_cast<const uint8_t*>(A.table + pt * (size_t)nwin * (size_t)A.tent);
+  };
+  // Who issues the LDS-DMA of a sub-table (1 KB pieces: 64 lanes x 16 bytes, LDS side = wave-uniform base + lane * 16):
+  //  * a workgroup with wavefronts to spare (rows_per_wg <= 768: the launch adds up to four LOADER wavefronts that own no rows) has the
+  //    loaders issue every piece while the row wavefronts do nothing but multiply — the loader / consumer split; the loaders also fill the
+  //    CU's register file, so no other kernel's workgroup lands on a CU that runs this one (the background launch relies on that);
+  //  * a full workgroup (1024 rows) has every wavefront issue its share from inside its addition, one piece after each of the first
+  //    multiplications (pt_madd_lds hooks): the issue cost (~100 cycles a piece) is covered by the other wavefronts of the SIMD.
+  const unsigned wave = tid >> 6, nwaves = T >> 6, nlive = (A.rows_per_wg + 63) >> 6;
+  const unsigned nload = nwaves > nlive ? nwaves - nlive : 0;
+  const bool loader = wave >= nlive;  // wave-uniform
+  const unsigned kb = sub_bytes >> 10;
+  auto piece = [&](const uint8_t* src, unsigned buf, unsigned p) {  // piece p of the sub-table at src into buffer buf
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + p * 1024u + lane * 16u), (lds_ptr_t)(lds + buf * sub_bytes + p * 1024u), 16, 0, 0);
+  };
+  auto dma_piece = [&](const uint8_t* src, unsigned buf, unsigned k) {  // hooked form: this wavefront's k-th piece
+    const unsigned p = k * nwaves + wave;
+    if (nload == 0 && p < kb) piece(src, buf, p);
+  };
+  auto dma_all = [&](const uint8_t* src, unsigned buf) {  // everything this wavefront owes to a sub-table, at once
+    if (nload) { if (loader) for (unsigned p = wave - nlive; p < kb; p += nload) piece(src, buf, p); }
+    else for (unsigned p = wave; p < kb; p += nwaves) piece(src, buf, p);
   };
   Pt acc = pt_identity();
   if (u1 > u0) {
@@ -80,7 +134,15 @@ __device__ __forceinline__ void msm_lds_run(const MsmLdsArgs& A, unsigned wg, ui
       s2 = (s2 >> c) | (s3 << (64 - c));
       s3 >>= c;
     };
-    dma(u0, 0);
+    // the tile after the current one: column, window and where its sub-table lies (all wave-uniform, advanced without divisions)
+    size_t jn = j;
+    int wn = w;
+    const uint8_t* cbase = col_base(jn);
+    if (!(DIAG & 1)) dma_all(cbase + (size_t)wn * sub_bytes, 0);
+    auto advance_next = [&]() {
+      if (++wn == nwin) { wn = 0; jn++; if (jn < ncol) cbase = col_base(jn); }
+    };
+    advance_next();
     Fq raw_next = fq_zero();
     if (live) {
       take(ld_fq(scalar_ptr(j)));
@@ -105,28 +167,43 @@ __device__ __forceinline__ void msm_lds_run(const MsmLdsArgs& A, unsigned wg, ui
       const uint32_t m = (uint32_t)(d < 0 ? -d : d);
       shift();
       w++;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's share of tile u has landed in LDS
-      __syncthreads();                                   // ... and everyone's; and every lane is done reading the other buffer (tile u - 1)
-      if (u + 1 < u1) dma(u + 1, buf ^ 1u);
-      if (fetch_next && live && j + 1 < ncol) raw_next = ld_fq(scalar_ptr(j + 1));
-      if (live && m != 0) {
-        const uint4* e = reinterpret_cast<const uint4*>(lds + buf * sub_bytes + (size_t)(m - 1) * 96u);
-        uint4 a0 = e[0], a1 = e[1], a2 = e[2], a3 = e[3], a4 = e[4], a5 = e[5];
-        Niels n;
-        n.yp = Fp{{(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32), (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)}};
-        n.ym = Fp{{(uint64_t)a2.x | ((uint64_t)a2.y << 32), (uint64_t)a2.z | ((uint64_t)a2.w << 32), (uint64_t)a3.x | ((uint64_t)a3.y << 32), (uint64_t)a3.z | ((uint64_t)a3.w << 32)}};
-        n.t2d = Fp{{(uint64_t)a4.x | ((uint64_t)a4.y << 32), (uint64_t)a4.z | ((uint64_t)a4.w << 32), (uint64_t)a5.x | ((uint64_t)a5.y << 32), (uint64_t)a5.z | ((uint64_t)a5.w << 32)}};
-        acc = pt_madd(acc, n, d < 0);
+      if (!(DIAG & 2)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's share of tile u has landed in LDS
+        __syncthreads();                                   // ... and everyone's; and every lane is done reading the other buffer (tile u - 1)
       }
+      if (fetch_next && live && j + 1 < ncol) raw_next = ld_fq(scalar_ptr(j + 1));
+      const bool more = !(DIAG & 1) && u + 1 < u1;
+      const uint8_t* src = cbase + (size_t)wn * sub_bytes;
+      // a zero digit (and a lane without a row) adds the neutral entry: the same point in other coordinates, so the canonical bytes of
+      // the sum do not change — and the addition, with the DMA pieces inside it, runs outside any divergent branch
+      const unsigned eoff = (m == 0 || (DIAG & 4)) ? ident_off : buf * sub_bytes + (m - 1) * 96u;
+      const uint8_t* e = lds + eoff;
+      if (loader) {  // (wave-uniform) no rows here: the next sub-table, then the barrier
+        if (more) dma_all(src, buf ^ 1u);
+      } else if (DIAG & 8) {
+        acc.X.v[0] ^= lds_fp(e).v[0] ^ lds_fp(e + 32).v[1] ^ lds_fp(e + 64).v[2];
+        if (more) dma_all(src, buf ^ 1u);
+      } else {
+        acc = pt_madd_lds(acc, e, d < 0, [&](unsigned k) { if (more) dma_piece(src, buf ^ 1u, k); });
+        if (more) for (unsigned k = 4; k < npieces; k++) dma_piece(src, buf ^ 1u, k);  // narrow workgroups: the rest of the pieces
+      }
+      advance_next();
     }
     __syncthreads();  // persistent form: the next run's first DMA must not overtake this run's last reads
   }
   if (live) A.partial[row * A.nb + bk] = acc;
 }
 
+template <int DIAG>
 __global__ void __launch_bounds__(1024) k_msm_lds(MsmLdsArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t msm_lds_buf[];
-  for (unsigned wg = blockIdx.x; wg < A.n_wg; wg += gridDim.x) msm_lds_run(A, wg, msm_lds_buf);
+  // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own L2): the row-blocks of one run stream the SAME sub-tables, so
+  // they are given to the same XCD, back to back — the second one's DMA hits in L2
+  const bool xcd = gridDim.x == A.n_wg && A.nrb > 1 && A.n_wg % (8 * A.nrb) == 0;
+  for (unsigned wg = blockIdx.x; wg < A.n_wg; wg += gridDim.x) {
+    const unsigned rb = xcd ? (wg / 8) % A.nrb : wg % A.nrb, bk = xcd ? (wg / (8 * A.nrb)) * 8 + wg % 8 : wg / A.nrb;
+    msm_lds_run<DIAG>(A, rb, bk, msm_lds_buf);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -135,6 +212,7 @@ static void msm_lds_shape(size_t rows, unsigned* nrb, unsigned* rows_per_wg, uns
   size_t b = (rows + 1023) / 1024;
   size_t per = (rows + b - 1) / b;
   size_t t = (per + 63) / 64 * 64;
+  for (int k = 0; k < 4 && t + 64 <= 1024; k++) t += 64;  // up to four loader wavefronts (they own no rows: the LDS-DMA of the sub-tables)
   *nrb = (unsigned)b; *rows_per_wg = (unsigned)per; *threads = (unsigned)t;
 }
 size_t msm_lds_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t wg_slots) {
@@ -159,13 +237,18 @@ void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, 
   A.wbits = g->geom_lds.wbits; A.nwin = g->geom_lds.nwin; A.tent = g->geom_lds.tent;
   unsigned grid = A.n_wg;
   if (grid_limit && grid > grid_limit) grid = grid_limit;
-  size_t lds = 2 * (size_t)A.tent * 96;
-  if (lds < 81920 && grid_limit) lds = 81920;  // background share: more than half of a CU's LDS, so that a CU never holds two of these
-  static std::atomic<uint64_t> attr_set{0};  // per device: the kernel may claim more than the default 64 KB of dynamic LDS
-  const uint64_t bit = 1ull << (c->dev & 63);
-  if (!(attr_set.load() & bit)) {
-    (void)hipFuncSetAttribute((const void*)k_msm_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set.fetch_or(bit);
+  size_t lds = 2 * (size_t)A.tent * 96 + 96;
+  if (lds < 81920) lds = 81920;  // more than half of a CU's LDS: a CU never holds two of these (narrow windows)
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // more than the default 64 KB of dynamic LDS
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(thr), (unsigned)lds, st, A);
+  };
+#ifdef SP_LDS_DIAG
+  switch ((int)c->opt.v[OPT_MSM_FLAT_ROUNDS] - 1) {  // variant build only: the stage mask rides on msm.flat_rounds - 1 (1..16 -> 0..15)
+    case 1: launch(k_msm_lds<1>); return; case 2: launch(k_msm_lds<2>); return; case 3: launch(k_msm_lds<3>); return; case 4: launch(k_msm_lds<4>); return;
+    case 5: launch(k_msm_lds<5>); return; case 6: launch(k_msm_lds<6>); return; case 7: launch(k_msm_lds<7>); return; case 8: launch(k_msm_lds<8>); return;
+    case 12: launch(k_msm_lds<12>); return; case 15: launch(k_msm_lds<15>); return; default: break;
   }
-  hipLaunchKernelGGL(k_msm_lds, dim3(grid), dim3(thr), (unsigned)lds, st, A);
+#endif
+  launch(k_msm_lds<0>);
 }
