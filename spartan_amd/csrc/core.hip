@@ -1373,6 +1373,7 @@ constexpr size_t SP_HOST_ENCODE_ROWS = 8;  // commitments of up to this many row
 struct MsmPlan {
   bool windowed, two_pass;
   bool lds = false;  // the LDS-staged small-window form (msm_lds.hip), P = runs per row-block
+  bool ring = false; // the loader / consumer ring form over the wide tables (msm_lds.hip, k_msm_ring), P = runs per row-block
   int flat;  // 0: strip form; 1 / 2: balanced form (k_msm_flat<0> / <1>), P = runs per row
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
@@ -1441,6 +1442,11 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
       size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
       m.lds = true; m.flat = 0;
       m.P = msm_lds_runs(g, launch_rows, cols, has_blinds, slots);
+    } else if (opt.v[OPT_MSM_FORM] == 2 && launch_rows >= 512) {  // fewer rows per launch (the witness upload chunks of a 2^20 proof: 256) leave the consumer wavefronts one per SIMD
+      const size_t cus = (size_t)g->ctx->n_cus;
+      size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
+      m.ring = true; m.flat = 0;
+      m.P = msm_ring_runs(g, launch_rows, cols, has_blinds, slots);
     }
   }
   m.chunk = 1024; m.nchunks = (m.P + m.chunk - 1) / m.chunk;
@@ -1478,7 +1484,9 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * g->geom.nwin, shape);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
-    if (m.lds) {
+    if (m.ring) {
+      msm_ring_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
+    } else if (m.lds) {
       msm_lds_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
     } else if (m.flat) {
       MsmFlatArgs A{dZ, z_stride, rows, cols, (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, (unsigned)m.P, (unsigned)(rows / 256), g->geom};

@@ -266,6 +266,11 @@ size_t msm_lds_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds,
 void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                      const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit);
 
+// ring form (msm_lds.hip, k_msm_ring): the same tiles over the WIDE tables, each row's entry gathered into LDS by loader wavefronts
+size_t msm_ring_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t wg_slots);
+void msm_ring_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
+                      const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit);
+
 static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {
   size_t b = (work + 255) / 256;
   if (b < 1) b = 1;

@@ -63,8 +63,9 @@ check(1024, 48, "mixed", True)           # four row-blocks
 check(2048, 40, "short", False)          # eight row-blocks: strip form in every mode (heterogeneous rows)
 check(768, 128, "uniform", False, background=True)
 check(768, 128, "zero_rows", False, background=True)
-if ctx.get_option("msm.form") == 1:
-    # the LDS-staged small-window form (msm_lds.hip) takes every launch of >= 512 rows: row-blocks that are not a multiple of a wavefront,
+if ctx.get_option("msm.form") >= 1:
+    # the LDS-staged small-window form (msm_lds.hip; msm.form = 1) takes every launch of >= 512 rows, the ring form (loader / consumer
+    # wavefronts over the wide tables; msm.form = 2) every launch of >= 256 rows: row-blocks that are not a multiple of a wavefront,
     # two and three row-blocks, runs that start inside a scalar, the blind as the last column, every scalar kind, the persistent background form
     for kind in ("uniform", "short", "zero_rows", "high", "carry", "mixed"):
         check(576, 40, kind, True)
