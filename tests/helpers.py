@@ -24,7 +24,7 @@ def _build_if_missing(path, cmd, cwd=ROOT):
 
 
 def load_oracle():
-    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    so = os.environ.get("ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")  # the override: the sanitizer build (tests/test_sanitizers.py)
     _build_if_missing(so, "make -C oracle")
     L = ctypes.CDLL(so)
     for f in ("orc_instance_synthetic", "orc_instance_new", "orc_instance_new_padded", "orc_snark_gens_new", "orc_nizk_gens_new", "orc_snark_encode",
