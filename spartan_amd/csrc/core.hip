@@ -460,6 +460,14 @@ __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, s
 // same canonical bytes). All roles run ONE instruction stream — operands are chosen by LDS address and by selects, never
 // by branches — and the code is three multiplication bodies instead of nine (it is fetched cold by these few waves).
 __device__ __forceinline__ Fe10 fe10_pick(const Fe10& a, const Fe10& b, bool take_b) { return fe10_select(a, b, take_b); }
+// Hand-over between two tree levels that live in ONE wavefront (no block barrier): the LDS unit executes a wave's accesses in order, but
+// the compiler sees no dependence between a lane's store of its sum and ANOTHER lane's load of it in the next level and may hoist that
+// load; a workgroup-scope release/acquire fence pair plus a wave barrier pins the order in the instruction stream.
+__device__ __forceinline__ void tree_wave_handover() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #ifdef SP_TREE_LDS
 // Round 1-3 form (A/B variant: make variant NAME=treelds FLAGS=-DSP_TREE_LDS): the quad exchanges A, B, C, D through LDS, three block
 // barriers per level.
@@ -561,6 +569,7 @@ __device__ __forceinline__ void pt10_tree_quad(Pt10* sm, Fe10* /*xch*/, size_t n
       }
     }
     if (s > 16) __syncthreads();  // the next level pairs points written by other wavefronts (additions q and q + s/2 sit 4 s/2 >= 64 lanes apart)
+    else tree_wave_handover();    // levels inside wavefront 0: the hardware orders a wave's LDS accesses, the COMPILER is told not to reorder them
   }
   __syncthreads();  // sm[0] is the sum for every thread of the block
 }
@@ -616,6 +625,7 @@ __device__ __forceinline__ void pt10_tree_quad_ded(Pt10* sm, unsigned char* idf,
       }
     }
     if (s > 16) __syncthreads();
+    else tree_wave_handover();
   }
   __syncthreads();
 }

@@ -152,10 +152,14 @@ void spz_seed_scalar(const char* domain, uint64_t seed, uint64_t out[4]) { Fq s 
 void spz_instance_set_digest(void* inst, const uint8_t* d, size_t n) { ((Instance*)inst)->set_digest(d, n); }
 // zlib header variant of the COMPUTED digest: 0 = 0x78 0x9C (miniz >= 2.2, miniz_oxide >= 0.4: FLEVEL from the level), 1 = 0x78 0x01 (older).
 // An explicit parameter of the instance (not an environment switch); call before the digest is first used.
-void spz_instance_set_digest_header(void* inst, int old_header) { ((Instance*)inst)->digest_old_header = old_header != 0; }
+int spz_instance_set_digest_header(void* inst, int old_header) {  // 0 = ok, -1 = a digest with the other header has already been computed (or set)
+  if (((Instance*)inst)->set_digest_header(old_header != 0)) return 0;
+  g_err = "set_digest_header after the digest was first used";
+  return -1;
+}
 // R1CSShape::get_digest (r1cs.rs:154-158): the zlib stream; and the bincode it compresses (for the round-trip tests)
 size_t spz_instance_digest(void* inst, uint8_t* out, size_t cap) {
-  const std::vector<uint8_t>& d = ((Instance*)inst)->compute_digest();
+  const std::vector<uint8_t> d = ((Instance*)inst)->compute_digest();
   if (out && cap >= d.size()) memcpy(out, d.data(), d.size());
   return d.size();
 }

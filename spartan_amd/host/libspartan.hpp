@@ -55,6 +55,10 @@ struct Ctx {
 //                             holds this rank's bytes, on return buf[0, total) is complete (tests: gloo)
 //   set_commit_shard_virtual  W shards on ONE GPU (W sub-contexts, in-process gather): the partitioning under test
 // world <= 1 (or nshards <= 1) clears the setting. All ranks must then run identical prove() calls.
+// CONTRACT OF THE TWO MULTI-PROCESS TRANSPORTS: configuring the sharding is itself a collective — set_commit_shard / set_commit_shard_rccl
+// exchange 8 bytes per rank over the transport they were just given (check_switches_agree, shard.cc: ranks whose sharding options differ
+// fail there with a message instead of deadlocking in the first proof). Every rank must therefore call it at the same point, and the
+// gather callback must already work when it is handed over.
 void unipoly_probe(const FqVec& evals, const Fq& r, FqVec* coeffs, FqVec* compressed, Fq* eval_at_r);  // test hook
 void cubic_coeffs_probe(const Fq S[12], const Fq& r, Fq ev[3]);                                                // test hook (spark.inc)
 void cubic_tail_probe(FqVec& tab, size_t ni, size_t m, const FqVec& coeffs, const FqVec& challenges, FqVec* evs);  // test hook (spark.inc)
@@ -159,7 +163,8 @@ struct Instance {  // src/lib.rs:110-273 (R1CSInstance after padding) with the m
   bool digest_old_header = false;  // zlib header 0x78 0x01 (miniz < 2.2, miniz_oxide 0.3) instead of 0x78 0x9C; set before the first compute_digest()
   mutable std::mutex digest_mu;
   std::vector<uint8_t> shape_bincode() const;  // bincode(R1CSShape): r1cs.rs:18-26, sparse_mlpoly.rs:19-38
-  const std::vector<uint8_t>& compute_digest() const;
+  std::vector<uint8_t> compute_digest() const;
+  bool set_digest_header(bool old_header);
   void set_digest(const uint8_t* d, size_t n);
   // Instance::new (lib.rs:121-228): padding of num_cons / num_vars and the column shift are applied here.
   Instance(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, const std::vector<SparseEntry>& A,

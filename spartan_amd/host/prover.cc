@@ -256,7 +256,7 @@ std::vector<uint8_t> Instance::shape_bincode() const {
   }
   return b;
 }
-const std::vector<uint8_t>& Instance::compute_digest() const {
+std::vector<uint8_t> Instance::compute_digest() const {  // by value, copied under the lock: a concurrent set_digest cannot pull the bytes from under a proof
   std::lock_guard<std::mutex> lk(digest_mu);
   if (digest.empty()) {
     static std::once_flag said;
@@ -272,6 +272,12 @@ const std::vector<uint8_t>& Instance::compute_digest() const {
 void Instance::set_digest(const uint8_t* d, size_t n) {
   std::lock_guard<std::mutex> lk(digest_mu);
   digest.assign(d, d + n);
+}
+bool Instance::set_digest_header(bool old_header) {  // false once a digest exists: the header variant is a property of the bytes already handed out
+  std::lock_guard<std::mutex> lk(digest_mu);
+  if (!digest.empty() && old_header != digest_old_header) return false;
+  digest_old_header = old_header;
+  return true;
 }
 
 Fq seed_scalar(const char* domain, uint64_t seed) {
@@ -1141,7 +1147,7 @@ VarsAssignment::VarsAssignment(Ctx& ctx, const Fq* vars, size_t n_) : c(ctx.h), 
 NIZK NIZK::prove(Ctx& ctx, const Instance& inst, const Fq* vars, size_t nvars_given, const FqVec& inputs, const NIZKGens& gens, Transcript& t,
                  const Fq* tape_seed, ProveTimes* tm, const sp_table* vars_resident) {  // lib.rs:501-546
   double t0 = now_s();
-  const std::vector<uint8_t>& digest = inst.compute_digest();  // lib.rs:514 absorbs inst.digest (r1cs.rs:154-158); computed once per instance, under its lock
+  const std::vector<uint8_t> digest = inst.compute_digest();  // lib.rs:514 absorbs inst.digest (r1cs.rs:154-158); computed once per instance, under its lock
   Fq shared_seed;  // lock-step ranks of a sharded proof must share one tape: rank 0 draws it (shard.cc)
   if (!tape_seed && commit_shard_shared_seed(ctx.h, &shared_seed)) tape_seed = &shared_seed;
   RandomTape tape = tape_seed ? RandomTape("proof", *tape_seed) : RandomTape("proof");  // random.rs:11-18

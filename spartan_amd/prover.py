@@ -104,7 +104,8 @@ class Instance:
 
     def set_digest_header(self, old_header):
         """zlib header variant of the computed digest: False = 0x78 0x9C (miniz >= 2.2, miniz_oxide >= 0.4), True = 0x78 0x01"""
-        H.spz_instance_set_digest_header(self.h, ctypes.c_int(1 if old_header else 0))
+        if H.spz_instance_set_digest_header(self.h, ctypes.c_int(1 if old_header else 0)) != 0:
+            raise SpartanHipError("set_digest_header: " + H.spz_last_error().decode())
 
     def free(self):
         if self.h:
