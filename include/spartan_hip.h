@@ -98,6 +98,9 @@ int sp_msm_window_bits(void);
  * FIXED PUBLIC BASES ONLY: every multi-scalar multiplication of this library (sp_commit_rows*, sp_msm_indexed, the inner-product
  * argument) runs over the points of a sp_gens through its precomputed tables. There is no variable-base device MSM — the prover
  * never needs one (every base on the path is a public generator). */
+/* A caller-supplied list may hold points with known relations between them (repeats, torsion shifts): the inner-product argument over such a
+ * set always uses the COMPLETE addition formula in its trees; sets the library derives itself (sp_gens_from_uniform) use the faster dedicated one,
+ * whose exceptional pairs cannot occur between sums over independent hash-to-curve points. */
 int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n, sp_gens** out);
 /* MultiCommitGens::new body (commitments.rs:21-30): n blocks of 64 uniform bytes from the caller's
  * SHAKE256 stream -> from_uniform_bytes on the device. compressed_out (32*n) may be NULL. */

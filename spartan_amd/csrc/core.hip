@@ -928,7 +928,12 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
   DoneSig sig = sig_make(c, 2 * (size_t)A->nblk + A->nd);
   {
     ProfScope ps(c, PF_IPA, 32.0 * 3 * (double)A->n0 + 160.0 * 2 * (double)A->nblk, nullptr, (double)(2 * P));
-    const bool always_unified = c->opt.v[OPT_IPA_UNIFIED_TREE] != 0;
+    // The dedicated (two-multiplication) tree is incomplete, and its exceptional pairs are detected at the root only for P = Q and
+    // P = Q + (0, -1) (an all-zero quadruple propagates to Z = 0); for Q = P +- (i, 0) the formula gives Y3 = Z3 = 0 with X3 != 0, which a
+    // later addition can turn back into Z != 0 — undetected. Such pairs need a known relation between partial
+    // sums over disjoint generators: impossible for points the library derived itself by hash-to-curve (MultiCommitGens::new), possible in
+    // principle for a caller-supplied list (sp_gens_upload). Caller-supplied sets therefore always get the complete (unified) tree.
+    const bool always_unified = c->opt.v[OPT_IPA_UNIFIED_TREE] != 0 || (!g->derived && !c->opt.v[OPT_IPA_DEDICATED_UPLOADED]);
     if (unified || always_unified) hipLaunchKernelGGL(k_ipa_round<false>, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
     else hipLaunchKernelGGL(k_ipa_round<true>, dim3(2 * A->nblk + A->nd), dim3(256), 0, c->stream, *A, (const Niels*)g->table, g->geom, sig);
   }
@@ -1347,6 +1352,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   g->n = n;
   g->table = hit->table;
   g->geom = msm_geom(hit->wbits);
+  g->derived = hit->mode == 1;
   g->table_lds = hit->table_lds;
   g->geom_lds = msm_geom(hit->wbits_lds ? hit->wbits_lds : 10);
   g->cache_entry = hit;

@@ -30,6 +30,7 @@
   X(HOST_PROOF_GATE, "host.proof_gate", 0, 0, 1, 0, "PROC. several proofs in flight on one device: admit one at a time to the throughput-bound part") \
   X(SYNC_KERNEL_SIGNAL, "sync.kernel_signal", 1, 0, 1, 1, "completion raised by the last kernel of a trip (0: a flag kernel behind it)")     \
   X(IPA_UNIFIED_TREE, "ipa.unified_tree", 0, 0, 1, 1, "inner-product rounds always with the unified (complete) addition tree")               \
+  X(IPA_DEDICATED_UPLOADED, "ipa.dedicated_uploaded", 0, 0, 1, 1, "dedicated (incomplete, two-multiplication) addition tree also for caller-supplied generator lists (default: only for sets the library derived by hash-to-curve)") \
   X(IPA_FUSED, "ipa.fused", 1, 0, 1, 1, "one launch per inner-product round (0: prepare + lookups + reduce)")                                \
   X(IPA_RERUN_EXCEPTIONAL, "ipa.rerun_exceptional", 1, 0, 1, 1, "re-run a round with the unified tree when the dedicated tree met an exceptional sum") \
   X(IPA_FINISH_DEVICE, "ipa.finish_device", 0, 0, 1, 1, "the end of an inner-product argument on the device instead of the proving core")     \

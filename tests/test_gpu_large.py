@@ -380,9 +380,12 @@ def test_inner_product_argument_exceptional_sums(ctx, orc, case):
     re-runs the round with the unified formula. The cases that reach those paths, against the reference's folded-generator algorithm:
     a generator list that repeats points under equal scalars (two sub-trees with limb-identical sums: the re-run), under opposite
     scalars (a computed neutral element as an operand), an all-zero vector (every leaf is the marked neutral element), a vector with a
-    few non-zero entries (marked and unmarked operands mixed), and an ordinary small argument."""
+    few non-zero entries (marked and unmarked operands mixed), and an ordinary small argument. Caller-supplied generator lists (sp_gens_upload,
+    as here) get the complete tree by default since round 5 — the dedicated tree cannot detect every exceptional pair — so the test turns the
+    dedicated tree on for them (option ipa.dedicated_uploaded) to keep driving its marks and its re-run; the last case runs the default."""
     n = 16
     rng = random.Random(sum(map(ord, case)))
+    ctx.set_option("testing.unlock", 1); ctx.set_option("ipa.dedicated_uploaded", 0 if case == "plain_small" else 1)
     base = gens_bytes(orc, n + 1, b"gens_ipa_exc")
     P = [base[32 * i:32 * i + 32] for i in range(n + 2)]
     a, b = fast_scalars(rng, n), fast_scalars(rng, n)
@@ -399,7 +402,7 @@ def test_inner_product_argument_exceptional_sums(ctx, orc, case):
         # the re-run really happened: with it switched off (test-only switch) the same argument must fail in its first round
         import os
         from spartan_amd import capi
-        ctx.set_option("testing.unlock", 1); ctx.set_option("ipa.rerun_exceptional", 0)
+        ctx.set_option("ipa.rerun_exceptional", 0)
         try:
             g = capi.Gens(ctx, compressed=b"".join(P))
             ipa = vp()
@@ -409,7 +412,8 @@ def test_inner_product_argument_exceptional_sums(ctx, orc, case):
             capi.lib.sp_ipa_free(ipa)
             g.free()
         finally:
-            ctx.set_option("ipa.rerun_exceptional", 1); ctx.set_option("testing.unlock", 0)
+            ctx.set_option("ipa.rerun_exceptional", 1)
+    ctx.set_option("ipa.dedicated_uploaded", 0); ctx.set_option("testing.unlock", 0)
 
 
 def test_witness_sized_commit_every_row_matches_oracle(ctx, orc):

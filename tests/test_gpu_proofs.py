@@ -506,7 +506,7 @@ def test_every_ab_switch_gives_the_same_proof(orc):
                 {"msm.flat": 0, "msm.prefetch": 1}, {"msm.flat": 1, "msm.flat_bg": 1, "msm.flat_rounds": 2}, {"msm.strip_threads": 131072, "msm.flat": 0},
                 {"msm.lds_bits": 10, "msm.form": 1}, {"msm.lds_bits": 9, "msm.form": 1, "overlap.derefs": 0}, {"msm.wbits": 11}]
     covered = {k for st in settings for k in st}
-    not_proof_shaping = {"ipa.rerun_exceptional", "shard.residue_transport", "shard.cubic_min_len", "host.callstats", "debug.ktime"}  # their own tests (test_gpu_large, test_gpu_shard) / diagnostics
+    not_proof_shaping = {"ipa.rerun_exceptional", "ipa.dedicated_uploaded", "shard.residue_transport", "shard.cubic_min_len", "host.callstats", "debug.ktime"}  # their own tests (test_gpu_large, test_gpu_shard) / diagnostics
     tier1 = {k for k, _d, _lo, _hi, tier, _doc in capi.options_table() if tier == 1}
     assert tier1 - covered - not_proof_shaping == set(), "tier-1 options without an A/B run: %s" % sorted(tier1 - covered - not_proof_shaping)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
