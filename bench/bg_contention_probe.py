@@ -1,4 +1,4 @@
-"""What a background row commitment (k_msm_rows_bg on SPARTAN_BG_EIGHTHS/8 of the CUs) costs the latency-bound foreground:
+"""What a background row commitment (k_msm_rows_bg on bg.eighths/8 of the CUs) costs the latency-bound foreground:
 microseconds per call of (a) a few-term table-lookup commitment on the device (sp_msm_indexed over 1024 generators: the shape of
 an inner-product round), (b) a launch-sized pure-ALU kernel (sp_sumcheck_eval_coeffs_batched on 64-entry tables), (c) a
 32 MB streaming pass (sp_evaluate of a 2^20 table), each alone and while background commits are in flight."""

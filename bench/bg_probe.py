@@ -1,4 +1,4 @@
-"""Scratch probe: time a 1024x1024 commit on the background stream under SPARTAN_BG_EIGHTHS=k (is the CU mask honoured?)."""
+"""Scratch probe: time a 1024x1024 commit on the background stream under SPARTAN_OPTIONS=bg.eighths=k (is the CU mask honoured?)."""
 import ctypes, hashlib, sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,4 +14,4 @@ for it in range(3):
     t0 = time.perf_counter()
     j = g.commit_rows_begin(t, rows, cols)
     out = g.commit_rows_wait(j)
-    print("EIGHTHS", os.environ.get("SPARTAN_BG_EIGHTHS"), "bg commit ms", (time.perf_counter() - t0) * 1e3)
+    print("OPTIONS", os.environ.get("SPARTAN_OPTIONS"), "bg commit ms", (time.perf_counter() - t0) * 1e3)

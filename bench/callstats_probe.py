@@ -1,4 +1,4 @@
-"""Scratch probe: SPARTAN_CALLSTATS=1 python bench/callstats_probe.py [log2] -> per-entry-point wall time of ONE proof."""
+"""Scratch probe: SPARTAN_OPTIONS=testing.unlock=1,host.callstats=1 python bench/callstats_probe.py [log2] -> per-entry-point wall time of ONE proof."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spartan_amd import prover as P

@@ -1,5 +1,5 @@
 """Probe: K independent SNARK::prove streams on ONE GPU (one context + host thread each), with and without the proof gate
-(SPARTAN_PROOF_GATE: one proof at a time in the throughput-bound first part, spark.inc). A single proof leaves the GPU idle during its
+(option host.proof_gate: one proof at a time in the throughput-bound first part, spark.inc). A single proof leaves the GPU idle during its
 latency-bound second part, so concurrent proofs fill each other's gaps; the gate turns that into a pipeline.
 usage: python bench/concurrent_probe.py [log2_constraints] [max_K] [steps]"""
 import sys, os, time, threading, json
@@ -21,7 +21,7 @@ for w in workers:  # warm-up, and the bytes every later proof of this worker mus
     ref.append(P.SNARK.prove(w[0], w[1], w[3], w[1].vars, w[1].inputs, w[2], b"snark_example", w[4]))
 out = []
 for gate in (0, 1):
-    os.environ["SPARTAN_PROOF_GATE"] = str(gate)
+    P.H.spz_ctx_set_option(None, b"host.proof_gate", str(gate).encode())
     for K in range(1, KMAX + 1):
         ok = [True] * K
         def run(i):
@@ -37,6 +37,6 @@ for gate in (0, 1):
         r = {"gate": gate, "proofs_in_flight": K, "ms_per_proof_slot": dt / steps * 1e3, "M_constraints_per_s": K * steps * N / dt / 1e6, "bytes_identical": all(ok)}
         out.append(r)
         print(json.dumps(r), flush=True)
-os.environ["SPARTAN_PROOF_GATE"] = "0"
+P.H.spz_ctx_set_option(None, b"host.proof_gate", b"0")
 for w in workers:
     w[3].free(); w[2].free(); w[1].free(); w[0].close()

@@ -3,12 +3,12 @@ k_cubic_bind2_eval (the two-rounds-per-trip batched sum-check kernel, spark.hip)
 core.hip) — from the DIAGNOSTIC build of the library (make -C spartan_amd/csrc ktime: -DSP_KTIME adds wall-clock stamps of
 the first workgroup at the phase boundaries) and prints, per phase, the time between stamps next to the host-side time of
 the whole call. 100 MHz device wall clock: 10 ns resolution.
-Run on the GPU box from the repo root:  SPARTAN_KTIME=1 python bench/ktime_probe.py"""
+Run on the GPU box from the repo root:  python bench/ktime_probe.py   (sets the library option debug.ktime through SPARTAN_OPTIONS)"""
 import ctypes, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("SPARTAN_HIP_LIB", os.path.join(ROOT, "spartan_amd", "lib", "libspartan_hip_ktime.so"))
-os.environ.setdefault("SPARTAN_KTIME", "1")
+os.environ.setdefault("SPARTAN_OPTIONS", "testing.unlock=1,debug.ktime=1")
 from spartan_amd import capi
 from tests.helpers import mont_bulk, fast_scalars, sz, vp, Q, load_oracle, gens_bytes
 

@@ -1,5 +1,5 @@
 """Row-MSM alone: the derefs column half (1280 x 4096 scalars over the 4098-point gens_r1cs_eval stream) at the window width
-SPARTAN_MSM_WBITS forces, three launches — the launch shape whose ALU fraction drops with the size of the table set. Run under
+option msm.wbits (SPARTAN_OPTIONS=msm.wbits=14) forces, three launches — the launch shape whose ALU fraction drops with the size of the table set. Run under
 rocprofv3 --pmc to collect address-translation / fabric counters per width (profiles/collect_r3_msm_counters.sh)."""
 import ctypes, hashlib, os, sys, time
 import numpy as np

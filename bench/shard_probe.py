@@ -66,10 +66,10 @@ def timed(k=5):
 ms0, ref = timed()
 ctx.set_commit_shard_virtual(8); ctx.shard_stats(reset=True)
 ms8, p8 = timed(); st8 = ctx.shard_stats(reset=True)
-os.environ["SPARTAN_NO_RESIDUE_SHARDS"] = "1"
+ctx.set_option("shard.residues", 0)
 ctx.set_commit_shard_virtual(8); ctx.shard_stats(reset=True)  # the switch is resolved when the sharding is configured
 ms8c, p8c = timed(); st8c = ctx.shard_stats()
-del os.environ["SPARTAN_NO_RESIDUE_SHARDS"]
+ctx.set_option("shard.residues", 1)
 ctx.set_commit_shard_virtual(1)
 assert p8 == ref and p8c == ref
 out["snark_prove_2p%d_ms" % s] = {"unsharded": round(ms0, 2), "8_virtual_shards_commits_only": round(ms8c, 2), "8_virtual_shards_commits_rounds_bound_evaluate": round(ms8, 2),

@@ -8,7 +8,7 @@ Writes profiles/pmc_traffic.json with the digest of the kernel sources it was co
 bench.py reports `roofline.traffic` only when that digest matches the sources it is running."""
 import csv, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_flat": "msm_rows_fixed", "k_msm_flat_bg": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed", "k_msm_windows_tree_fused": "msm_windows_fixed", "k_ipa_round": "ipa_round",
+FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_flat": "msm_rows_fixed", "k_msm_flat_bg": "msm_rows_fixed", "k_msm_lds": "msm_rows_fixed", "k_msm_ring": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed", "k_msm_windows_tree_fused": "msm_windows_fixed", "k_ipa_round": "ipa_round",
           "k_msm_reduce": "msm_reduce_compress", "k_pt_encode": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
           "k_cubic_bind_eval_batched": "sumcheck_bind_eval", "k_sc_bind_eval": "sumcheck_bind_eval", "k_sc_eval": "sumcheck_eval",
           "k_cubic_eval_batched": "sumcheck_eval", "k_cubic_bind_eval_batched_eq": "sumcheck_bind_eval", "k_cubic_eval_batched_eq": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand",
@@ -32,7 +32,7 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
         fam_n[FAMILY[k]] += nf[k]
 out = {fam: fam_bytes[fam] / max(fam_n[fam], 1) for fam in fam_bytes}
 # msm_rows_fixed per launch SHAPE is what the bench line's dominant-kernel entry averages over: keep the two kernels apart too
-for k in ("k_msm_rows", "k_msm_rows_bg", "k_msm_flat", "k_msm_flat_bg"):
+for k in ("k_msm_rows", "k_msm_rows_bg", "k_msm_flat", "k_msm_flat_bg", "k_msm_lds", "k_msm_ring"):
     if k in f:
         out[k] = (2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024) / nf[k]
 from bench import kernel_source_digest

@@ -5,7 +5,7 @@ for rep in 1 2 3; do
 for b in 14 15; do
   for lib in libspartan_hip.so libspartan_hip_$2.so; do
     echo "== $lib wbits $b" >> $O/msm_variant.txt
-    SPARTAN_HIP_LIB=$R/spartan_amd/lib/$lib SPARTAN_MSM_WBITS=$b timeout 300 python bench/msm_probe.py 2>&1 | tail -2 >> $O/msm_variant.txt
+    SPARTAN_HIP_LIB=$R/spartan_amd/lib/$lib SPARTAN_OPTIONS=msm.wbits=$b timeout 300 python bench/msm_probe.py 2>&1 | tail -2 >> $O/msm_variant.txt
   done
 done
 done
