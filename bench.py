@@ -394,7 +394,7 @@ def main():
         wb = [gens.window_bits(0), gens.window_bits(1)]
         # entries per (point, window) sub-table = 2^(c-1); the stride of a table entry follows from the table's size
         ent = [(len(gens.stream(k)) // 32) * (-(-254 // wb[k])) * (1 << (wb[k] - 1)) for k in (0, 1)]
-        stride = int(round(gens.table_bytes(0) / ent[0])) if ent[0] else 128
+        stride = 128  # one 128-byte line per entry of the gathered tables (table_bytes also counts the packed LDS-form tables when they are built)
         gath = gather_ceiling([gens.table_bytes(0) / 1e9, gens.table_bytes(1) / 1e9], [1 << (wb[0] - 1), 1 << (wb[1] - 1)], stride)
     if sharded:
         proof = step()  # unsharded bytes: every sharded proof below must equal them

@@ -1364,7 +1364,10 @@ int32_t sp_gens_from_uniform(sp_ctx* c, const uint8_t* uniform, size_t n, uint8_
   return gens_build(c, uniform, 1, n, compressed_out, out);
 }
 size_t sp_gens_len(const sp_gens* g) { return g ? g->n : 0; }
-size_t sp_gens_table_bytes(const sp_gens* g) { return g ? g->n * g->geom.pt_entries * sizeof(Niels) : 0; }
+size_t sp_gens_table_bytes(const sp_gens* g) {  // everything the set holds in HBM: the gathered tables and, when built, the packed LDS-form tables
+  if (!g) return 0;
+  return g->n * g->geom.pt_entries * sizeof(Niels) + (g->table_lds ? g->n * g->geom_lds.pt_entries * sizeof(NielsP) : 0);
+}
 void sp_gens_free(sp_gens* g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->dev);
