@@ -48,3 +48,5 @@ python bench.py --log2-cons 24 --no-cpu-baseline --steps 3 --concurrent 0 --no-s
 SPARTAN_OPTIONS=msm.lds_bits=10,msm.form=1,msm.wbits=10 python bench.py --no-cpu-baseline --concurrent 0 --no-side-metrics > $O/bench_line_small_memory.json 2> $O/bench_line_small_memory.err
 ./bench/ubench_fpmul > $O/ubench_fpmul.txt 2>&1
 ls -la $O
+# A/B of the row-MSM forms in the proof at 2^22 (BASELINE config 5's size)
+AB_LOG2=22 AB_STEPS=8 AB_TIMEOUT=600 bash scripts/gpu_ab.sh r5prof_ab22 1 "wide:" "ring6:msm.form=2,bg.eighths=6" "lds6:msm.lds_bits=10,msm.form=1,bg.eighths=6" 2>&1 | tail -8 > $O/ab_2p22.txt
