@@ -122,12 +122,5 @@ impl NIZK {
     NIZK { r1cs_sat_proof: proof, r: (rx, ry) }
   }
 }
-
-pub use random::seed_scalar;
-impl Instance {
-  pub fn produce_synthetic_r1cs_seeded(num_cons: usize, num_vars: usize, num_inputs: usize, seed: u64) -> (Instance, VarsAssignment, InputsAssignment) {
-    let (inst, vars, inputs) = R1CSShape::produce_synthetic_r1cs_seeded(num_cons, num_vars, num_inputs, seed);
-    let digest = inst.get_digest();
-    (Instance { inst, digest }, VarsAssignment { assignment: vars, #[cfg(feature = "gpu")] dev: None }, InputsAssignment { assignment: inputs })
-  }
-}
+// (seed_scalar, Instance::produce_synthetic_r1cs_seeded and the CPU path's prove_with_tape_seed come with rust_shim/seed_hooks.patch, which
+// gpu_feature.patch applies on top of; under the gpu feature VarsAssignment additionally carries `dev: None`.)

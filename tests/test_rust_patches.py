@@ -42,8 +42,6 @@ def test_seed_hooks_and_gpu_feature_patches_apply_to_the_reference(tmp_path):
     assert "gpu = []" in open(os.path.join(d, "Cargo.toml")).read()
     assert open(os.path.join(d, "src", "gpu.rs")).read() == open(os.path.join(ROOT, "rust_shim", "src", "gpu.rs")).read()
     for seam in os.listdir(os.path.join(ROOT, "rust_shim", "seams")):
-        if seam in ("random.rs", "r1cs.rs"):
-            continue   # the two seed hooks are seed_hooks.patch
         assert open(os.path.join(d, "src", "gpu_seams", seam)).read() == open(os.path.join(ROOT, "rust_shim", "seams", seam)).read(), seam
     assert 'include!("gpu_seams/sumcheck.rs");' in open(os.path.join(d, "src", "sumcheck.rs")).read()
     assert 'include!("../gpu_seams/bullet.rs");' in open(os.path.join(d, "src", "nizk", "bullet.rs")).read()
