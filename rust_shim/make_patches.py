@@ -326,6 +326,18 @@ fn main() {
         for sig in REDEFINED.get(target, []):
             assert s.count(sig) >= 1, (target, sig)
             s = s.replace(sig, "  #[cfg(not(feature = \"gpu\"))]\n" + sig, 1)
+        if target == "src/lib.rs":
+            # the seam redefines SNARK::{prove, prove_with_tape_seed, prove_with_tape} and NIZK::prove: the CPU bodies (as left by seed_hooks.patch)
+            # are compiled only without the feature; NIZK's seeded CPU twin stays (the seam has none)
+            gate = "  #[cfg(not(feature = \"gpu\"))]\n"
+            i_snark, i_nizk = s.index("impl SNARK {"), s.index("impl NIZK {")
+            snark, rest = s[i_snark:i_nizk], s[i_nizk:]
+            for sig in ("  pub fn prove(\n", "  pub fn prove_with_tape_seed(\n", "  fn prove_with_tape(\n"):
+                assert snark.count(sig) == 1, sig
+                snark = snark.replace(sig, gate + sig)
+            assert rest.count("  pub fn prove(\n") == 1
+            rest = rest.replace("  pub fn prove(\n", gate + "  pub fn prove(\n", 1)
+            s = s[:i_snark] + snark + rest
         open(p, "w").write(s)
 
 
