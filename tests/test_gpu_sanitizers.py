@@ -15,8 +15,10 @@ def test_threaded_host_driver_under_thread_sanitizer():
     if not rt:
         pytest.skip("no ThreadSanitizer runtime in this toolchain")
     lib = os.path.join(ROOT, "spartan_amd", "lib")
-    if not (os.path.exists(os.path.join(lib, "libspartan_hip_tsan.so")) and os.path.exists(os.path.join(lib, "libspartan_host_tsan.so"))):
-        subprocess.check_call(["bash", os.path.join(ROOT, "scripts", "build_tsan.sh")], stdout=subprocess.DEVNULL)
+    built = [os.path.join(lib, "libspartan_hip_tsan.so"), os.path.join(lib, "libspartan_host_tsan.so")]
+    srcs = glob.glob(os.path.join(ROOT, "spartan_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "spartan_amd", "host", "*")) + [os.path.join(ROOT, "include", "spartan_hip.h")]
+    if not all(os.path.exists(b) for b in built) or max(os.path.getmtime(x) for x in srcs) > min(os.path.getmtime(b) for b in built):
+        subprocess.check_call(["bash", os.path.join(ROOT, "scripts", "build_tsan.sh")], stdout=subprocess.DEVNULL)   # the sanitizer build follows the sources
     env = dict(os.environ, LD_PRELOAD=rt[0], SPARTAN_HIP_LIB=os.path.join(lib, "libspartan_hip_tsan.so"), SPARTAN_HOST_LIB=os.path.join(lib, "libspartan_host_tsan.so"),
                TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:history_size=4:second_deadlock_stack=1:exitcode=0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tsan_worker.py"), "12"], env=env, capture_output=True, text=True, timeout=900)
