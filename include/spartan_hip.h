@@ -93,7 +93,9 @@ int sp_msm_window_bits(void);
  * under option msm.wide_gb (default 80), otherwise the widest of 14/13/12/10/8 that fits msm.table_gb (default 170 per set);
  * msm.wbits forces a width. 2^20: 15 bits for the 1025-point stream (36.6 GB), 14 for the 4098-point one (81.6 GB). With
  * msm.lds_bits = 10 the set also gets the packed 10-bit tables of the LDS-staged row MSM (1.25 MB per point: 1.3 + 5.2 GB at
- * 2^20; msm.form = 1 selects that form for commits of >= 512 rows). SP_ENOMEM (with a message on stderr) if not even 8-bit
+ * 2^20; msm.form = 1 selects that form for commits of >= 512 rows). THE DEFAULT IS PER SET (msm.form = 0): the gathered wide-window forms
+ * while the set's tables keep >= 12 bits — they win at 2^20, 2^22 and 2^24 — and the LDS-staged form, with its tables built alongside, when
+ * device memory was so short that the wide tables came out at 10 or 8 bits (stderr says so). SP_ENOMEM (with a message on stderr) if not even 8-bit
  * tables fit in free device memory.
  * FIXED PUBLIC BASES ONLY: every multi-scalar multiplication of this library (sp_commit_rows*, sp_msm_indexed, the inner-product
  * argument) runs over the points of a sp_gens through its precomputed tables. There is no variable-base device MSM — the prover

@@ -1231,8 +1231,9 @@ struct GensCacheEntry {
   size_t n, refs;
   std::vector<uint8_t> in, comp;
   Niels* table;
-  NielsP* table_lds = nullptr;  // LDS-form tables (msm_lds.hip), built with the set when SPARTAN_MSM_LDS asks for them
+  NielsP* table_lds = nullptr;  // LDS-form tables (msm_lds.hip), built with the set when option msm.lds_bits asks for them — or when the wide tables came out narrow
   int wbits_lds = 0;
+  bool prefer_lds = false;
 };
 static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
@@ -1307,11 +1308,20 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     Niels* table = nullptr;
     HIPCHK(hipMalloc((void**)&table, n * geom.pt_entries * sizeof(Niels)));
     NielsP* table_lds = nullptr;
-    const int lds_bits = c->opt.v[OPT_MSM_LDS_BITS] >= 5 ? (int)c->opt.v[OPT_MSM_LDS_BITS] : 0;  // 10 bits: 512 x 96 B = 48 KB per sub-table, double-buffered in 96 of a CU's 160 KB of LDS
+    int lds_bits = c->opt.v[OPT_MSM_LDS_BITS] >= 5 ? (int)c->opt.v[OPT_MSM_LDS_BITS] : 0;  // 10 bits: 512 x 96 B = 48 KB per sub-table, double-buffered in 96 of a CU's 160 KB of LDS
+    // THE DEFAULT PER GENERATOR SET (measured: profiles/r5_ab_msm_forms.txt). While the wide tables keep >= 12 bits (17-22 additions per scalar)
+    // the gathered forms win at every size measured (2^20, 2^22, 2^24). When HBM is short and the policy above lands on 10 or 8 bits (26-32
+    // additions, at 0.68 of the addition ceiling), the LDS-staged form does the same 26 additions at 0.83 from tables that are SMALLER (96-byte
+    // packed entries instead of 128-byte lines): the set then gets the packed tables too and its row commits take that form unless msm.form says otherwise.
+    bool prefer_lds = false;
+    if (!lds_bits && wbits <= 10 && n >= 512) { lds_bits = 10; prefer_lds = true; }
     if (lds_bits && hipMalloc((void**)&table_lds, n * msm_geom(lds_bits).pt_entries * sizeof(NielsP)) != hipSuccess) {
-      (void)hipFree(table);
-      return SP_ENOMEM;
+      (void)hipGetLastError();
+      table_lds = nullptr;
+      if (!prefer_lds) { (void)hipFree(table); return SP_ENOMEM; }   // asked for by option: an error; chosen by the policy: do without
+      lds_bits = 0; prefer_lds = false;
     }
+    if (prefer_lds) fprintf(stderr, "spartan_hip: %zu generators with %d-bit gathered tables: row commitments of this set take the LDS-staged form (10-bit windows streamed through LDS)\n", n, wbits);
     {
       ProfScope ps(c, PF_GENS_TABLE, (double)n * geom.pt_entries * sizeof(Niels));
       hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
@@ -1334,7 +1344,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
       if (table_lds) (void)hipFree(table_lds);
       return rc != SP_OK ? rc : SP_EPOINT;
     }
-    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table, table_lds, lds_bits});
+    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table, table_lds, lds_bits, prefer_lds});
     hit = &g_gens_cache.back();
   }
   sp_gens* g = new (std::nothrow) sp_gens();
@@ -1353,6 +1363,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   g->table = hit->table;
   g->geom = msm_geom(hit->wbits);
   g->derived = hit->mode == 1;
+  g->prefer_lds = hit->prefer_lds;
   g->table_lds = hit->table_lds;
   g->geom_lds = msm_geom(hit->wbits_lds ? hit->wbits_lds : 10);
   g->cache_entry = hit;
@@ -1454,7 +1465,7 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
       if (nb >= 1) { m.flat = bg_subblocks ? 1 : flat_mode; m.P = nb; }
     }
     // LDS-staged small-window form: a workgroup is up to 1024 rows, so it needs rows to fill a CU with (>= 768 for 3 waves per SIMD)
-    if (g->table_lds && opt.v[OPT_MSM_FORM] == 1 && launch_rows >= 512) {
+    if (g->table_lds && (opt.v[OPT_MSM_FORM] == 1 || (opt.v[OPT_MSM_FORM] == 0 && g->prefer_lds)) && launch_rows >= 512) {
       const size_t cus = (size_t)g->ctx->n_cus;
       // one workgroup per CU (96 KB of LDS each); next to a background commit the launch is cut three times finer, so that the CUs
       // the background job leaves free are handed runs as they come

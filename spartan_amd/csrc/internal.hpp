@@ -117,6 +117,7 @@ struct sp_gens {
   size_t n;
   Niels* table;  // [n][nwin][tent]; owned by the process-wide table cache (core.hip), shared between contexts
   MsmGeom geom;  // window geometry these tables were built with
+  bool prefer_lds = false;  // the set's wide tables came out narrow (<= 10 bits: HBM was short): its row commits take the LDS-staged form by default
   bool derived = false;  // the points came out of the library's own hash-to-curve (sp_gens_from_uniform: MultiCommitGens::new), not from a caller's list
   NielsP* table_lds = nullptr;  // [n][nwin][tent] packed entries of the LDS-staged form (msm_lds.hip), or null when the set was built without it
   MsmGeom geom_lds;

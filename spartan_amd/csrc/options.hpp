@@ -16,7 +16,7 @@
 // X(id, key, default, min, max, tier, doc)
 #define SP_OPTION_TABLE(X)                                                                                                                  \
   X(TESTING_UNLOCK, "testing.unlock", 0, 0, 1, 0, "1: accept tier-1 (A/B / test) options on this context")                                   \
-  X(MSM_FORM, "msm.form", 0, 0, 2, 0, "row MSM of many rows: 0 = wide-window tables gathered by the lanes themselves, 1 = LDS-staged small windows (needs msm.lds_bits at set creation), 2 = wide-window tables with loader wavefronts gathering each row's entry into an LDS ring") \
+  X(MSM_FORM, "msm.form", 0, 0, 3, 0, "row MSM of many rows: 0 = per generator set (gathered wide-window tables; LDS-staged when the set's wide tables came out <= 10 bits), 3 = gathered always, 1 = LDS-staged small windows (needs msm.lds_bits at set creation), 2 = wide-window tables with loader wavefronts gathering each row's entry into an LDS ring") \
   X(MSM_LDS_BITS, "msm.lds_bits", 0, 0, 10, 0, "window width of the LDS-staged form's tables built with a generator set (0 = not built; 10 = 48 KB sub-tables, double-buffered)") \
   X(MSM_WBITS, "msm.wbits", 0, 0, 15, 0, "force the wide tables' window width (4..15); 0 = chosen by the policy below")                       \
   X(MSM_TABLE_GB, "msm.table_gb", 170, 1, 100000, 0, "HBM budget of one generator set's wide tables, GB")                                    \

@@ -139,6 +139,33 @@ def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
     ctx.set_option("msm.wbits", 0)
 
 
+def test_narrow_wide_tables_switch_the_set_to_the_lds_staged_form(ctx, orc):
+    """The default per generator set (core.hip gens_build; profiles/r5_ab_msm_forms.txt): a set whose gathered tables come out at <= 10 bits — HBM
+    was short, or the width was forced — also gets the packed 10-bit tables and its row commitments of >= 512 rows run the LDS-staged form
+    (msm_lds.hip); msm.form = 3 keeps the gathered forms. Same commitments either way, equal to the oracle's."""
+    from spartan_amd import capi
+    ctx.set_option("msm.wbits", 10)
+    try:
+        n = 520
+        g = capi.Gens(ctx, compressed=gens_bytes(orc, n, b"gens_auto_lds"))
+        per_point = 26 * 512
+        assert capi.lib.sp_gens_table_bytes(g.h) == (n + 1) * per_point * (128 + 96)    # both table kinds were built
+        rows, cols = 640, n
+        rng = random.Random(77)
+        Z = rand_scalars(rng, rows * cols, "uniform")
+        bl = rand_scalars(rng, rows, "uniform")
+        gb = g.compressed
+        want = (ctypes.c_uint8 * (32 * rows))()
+        assert orc.orc_commit_rows(gb[:32 * cols], sz(cols), gb[32 * n:], mont_array(Z), sz(rows), sz(cols), mont_array(bl), want) == 0
+        got_auto = g.commit_rows(mont_array(Z), rows, cols, mont_array(bl), g_off=0, h_idx=n)
+        ctx.set_option("msm.form", 3)
+        got_gathered = g.commit_rows(mont_array(Z), rows, cols, mont_array(bl), g_off=0, h_idx=n)
+        assert got_auto == got_gathered == bytes(want)
+        g.free()
+    finally:
+        ctx.set_option("msm.form", 0); ctx.set_option("msm.wbits", 0)
+
+
 def test_commit_rows_dev_and_offset(ctx, orc, gens40):
     from spartan_amd import capi
     rng = random.Random(5)
