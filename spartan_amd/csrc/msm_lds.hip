@@ -12,8 +12,8 @@
 //     which is streamed from the table into LDS by global_load_lds_dwordx4 (LDS-DMA: coalesced 1 KB per wave-instruction, no staging
 //     registers) into one half of a double buffer while the lanes work out of the other half;
 //   * the lane's gather is a 96-byte LDS read at its own digit; the mixed addition (7 F_p multiplications) follows; one workgroup
-//     barrier per tile hands the buffers over (the DMA of tile t+1 is issued right after the barrier of tile t and has the whole
-//     addition to land);
+//     barrier per tile hands the buffers over (the DMA of tile t+1 is issued during the addition of tile t — by loader wavefronts, or
+//     from inside the addition — and has until the next barrier to land);
 //   * HBM sees a sequential stream: rows/1024 x cols x 26 x 48 KB per commit (1.3 GB for the 2^20 witness, ~1.3 TB/s while the
 //     kernel runs) instead of 107-126 B of random gather per addition at 88-93 % L2 miss.
 //

@@ -60,7 +60,7 @@ static void defaults_init_locked() {
   }
   g_defaults_ready = true;
 }
-const SpOptions& sp_default_options() {
+SpOptions sp_default_options() {  // a copy, taken under the lock: sp_ctx_set_option(NULL, ...) may run on another thread
   std::lock_guard<std::mutex> lk(g_opt_mu);
   defaults_init_locked();
   return g_defaults;

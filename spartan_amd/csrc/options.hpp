@@ -70,4 +70,4 @@ struct SpOptDesc { const char* key; long long def, lo, hi; int tier; const char*
 extern const SpOptDesc kOptDesc[OPT_COUNT];
 struct SpOptions { long long v[OPT_COUNT]; };
 // process-wide defaults (compiled-in defaults overlaid by SPARTAN_OPTIONS once, then by sp_ctx_set_option(NULL, ...))
-const SpOptions& sp_default_options();
+SpOptions sp_default_options();
