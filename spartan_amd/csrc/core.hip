@@ -1095,6 +1095,8 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->done_seq = 0;
   HIPCHK(hipMalloc((void**)&c->done_counter, 64));
   HIPCHK(hipMemset(c->done_counter, 0, 64));
+  HIPCHK(hipMalloc((void**)&c->q_heads, 64 * 64));
+  HIPCHK(hipMemset(c->q_heads, 0, 64 * 64));
 #ifdef SP_KTIME
   if (c->opt.v[OPT_DEBUG_KTIME]) { HIPCHK(hipMalloc((void**)&c->ktime, 64 * 8)); HIPCHK(hipMemset(c->ktime, 0, 64 * 8)); }
 #endif
@@ -1127,6 +1129,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
+  if (c->q_heads) (void)hipFree(c->q_heads);
   if (c->ktime) (void)hipFree(c->ktime);
   if (c->vm_pinned) (void)hipHostFree(c->vm_pinned);
   if (c->vm_dstage) (void)hipFree(c->vm_dstage);
@@ -1404,6 +1407,7 @@ struct MsmPlan {
   bool windowed, two_pass;
   bool lds = false;  // the LDS-staged small-window form (msm_lds.hip), P = runs per row-block
   bool ring = false; // the loader / consumer ring form over the wide tables (msm_lds.hip, k_msm_ring), P = runs per row-block
+  bool queue = false; // the queue form (msm_queue.hip, k_msm_q): P = runs per row
   int flat;  // 0: strip form; 1 / 2: balanced form (k_msm_flat<0> / <1>), P = runs per row
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
@@ -1423,7 +1427,8 @@ static size_t msm_flat_slots(int pipe) {
   if (e != hipSuccess || per_cu < 1) per_cu = 3;
   return slots[{dev, pipe}] = (size_t)per_cu * (size_t)prop.multiProcessorCount;
 }
-static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t bg_subblocks = 0 /* background launch: 256-thread tiles it runs at once */,
+// (c: the LAUNCHING context — options, CU count and background share are its own; a virtual shard launches its parent's generator set)
+static MsmPlan msm_plan(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t bg_subblocks = 0 /* background launch: 256-thread tiles it runs at once */,
                         size_t launch_rows = 0 /* rows per launch when the commit is issued in row chunks (sp_commit_rows_upload_start) */,
                         bool shares_chip = false /* a background commit of this context is in flight */) {
   MsmPlan m;
@@ -1435,7 +1440,7 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
   if (m.windowed) {
     m.P = ncol * NWIN;
   } else {
-    const SpOptions& opt = g->ctx->opt;
+    const SpOptions& opt = c->opt;
     const size_t target_threads = (size_t)opt.v[OPT_MSM_STRIP_THREADS];
     m.strip = total / target_threads;  // enough threads for >= 4 waves per SIMD on 256 CUs
     if (m.strip < 1) m.strip = 1;
@@ -1466,17 +1471,20 @@ static MsmPlan msm_plan(const sp_gens* g, size_t rows, size_t cols, bool has_bli
     }
     // LDS-staged small-window form: a workgroup is up to 1024 rows, so it needs rows to fill a CU with (>= 768 for 3 waves per SIMD)
     if (g->table_lds && (opt.v[OPT_MSM_FORM] == 1 || (opt.v[OPT_MSM_FORM] == 0 && g->prefer_lds)) && launch_rows >= 512) {
-      const size_t cus = (size_t)g->ctx->n_cus;
+      const size_t cus = (size_t)c->n_cus;
       // one workgroup per CU (96 KB of LDS each); next to a background commit the launch is cut three times finer, so that the CUs
       // the background job leaves free are handed runs as they come
       size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
       m.lds = true; m.flat = 0;
       m.P = msm_lds_runs(g, launch_rows, cols, has_blinds, slots);
     } else if (opt.v[OPT_MSM_FORM] == 2 && launch_rows >= 512) {  // fewer rows per launch (the witness upload chunks of a 2^20 proof: 256) leave the consumer wavefronts one per SIMD
-      const size_t cus = (size_t)g->ctx->n_cus;
+      const size_t cus = (size_t)c->n_cus;
       size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
       m.ring = true; m.flat = 0;
       m.P = msm_ring_runs(g, launch_rows, cols, has_blinds, slots);
+    } else if (opt.v[OPT_MSM_FORM] == 4) {
+      m.queue = true; m.flat = 0;
+      m.P = msm_q_runs(c, g, launch_rows, cols, has_blinds, bg_subblocks != 0);
     }
   }
   m.chunk = 1024; m.nchunks = (m.P + m.chunk - 1) / m.chunk;
@@ -1514,7 +1522,9 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     ProfScope ps(c, PF_MSM_ROWS, 32.0 * (double)total + 32.0 * (double)rows, st, (double)total * g->geom.nwin, shape);
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
-    if (m.ring) {
+    if (m.queue) {
+      msm_q_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0);
+    } else if (m.ring) {
       msm_ring_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
     } else if (m.lds) {
       msm_lds_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
@@ -1566,7 +1576,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, uint8_t* out_host, size_t idx_row_stride, Pt* points_out) {
   if (idx_row_stride && (!didx || rows > SP_HOST_ENCODE_ROWS)) return SP_EINVAL;
   if (points_out && (rows > SP_HOST_ENCODE_ROWS || c->device_encode)) return SP_EINVAL;  // row sums as points: the few-row path only
-  MsmPlan m = msm_plan(g, rows, cols, dblinds != nullptr, 0, 0, c->bg_inflight > 0);
+  MsmPlan m = msm_plan(c, g, rows, cols, dblinds != nullptr, 0, 0, c->bg_inflight > 0);
   size_t out_al = (32 * rows + 255) & ~(size_t)255;
   SPCHK(ensure(&c->scratch, &c->scratch_cap, m.part_bytes + m.part2_bytes + out_al + sizeof(Pt) * rows));
   if (rows <= SP_HOST_ENCODE_ROWS) {  // latency path: the device sums, the host core runs the encode chain
@@ -1638,7 +1648,7 @@ int32_t sp_commit_rows_dev_begin(sp_ctx* c, const sp_gens* g, size_t g_off, cons
                                  sp_job** out) {
   if (!c || !g || !Z || !out || rows == 0 || cols == 0 || g_off + cols > g->n || z_off + rows * cols > Z->cap) return SP_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  MsmPlan m = msm_plan(g, rows, cols, false, c->bg_blocks > 0 ? (size_t)c->bg_blocks * 4 : 0);
+  MsmPlan m = msm_plan(c, g, rows, cols, false, c->bg_blocks > 0 ? (size_t)c->bg_blocks * 4 : 0);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream_bg;
@@ -1678,7 +1688,7 @@ int32_t sp_commit_rows_dev_start(sp_ctx* c, const sp_gens* g, size_t g_off, size
     SPCHK(stage_in(c, 0, blinds, 32 * rows));
     dbl = (const Fq*)c->dstage;
   }
-  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, 0, c->bg_inflight > 0);
+  MsmPlan m = msm_plan(c, g, rows, cols, blinds != nullptr, 0, 0, c->bg_inflight > 0);
   sp_job* j = new (std::nothrow) sp_job();
   if (!j) return SP_ENOMEM;
   j->ctx = c; j->rows = rows; j->scratch = nullptr; j->stream = c->stream;
@@ -1708,7 +1718,7 @@ int32_t sp_commit_rows_upload_start(sp_ctx* c, const sp_gens* g, size_t g_off, s
   HIPCHK(hipSetDevice(c->dev));
   const size_t nch = (size_t)c->opt.v[OPT_UPLOAD_CHUNKS];
   const bool chunked_on = c->opt.v[OPT_UPLOAD_OVERLAP] != 0;  // A/B switch
-  MsmPlan m = msm_plan(g, rows, cols, blinds != nullptr, 0, chunked_on && rows % (256 * nch) == 0 ? rows / nch : 0, c->bg_inflight > 0);
+  MsmPlan m = msm_plan(c, g, rows, cols, blinds != nullptr, 0, chunked_on && rows % (256 * nch) == 0 ? rows / nch : 0, c->bg_inflight > 0);
   if (!chunked_on || m.windowed || rows % (256 * nch) != 0) {
     HIPCHK(hipMemcpyAsync(Z->d + z_off, src, 32 * rows * cols, hipMemcpyHostToDevice, c->stream));
     return sp_commit_rows_dev_start(c, g, g_off, h_idx, Z, z_off, rows, cols, blinds, out);

@@ -72,6 +72,8 @@ struct sp_ctx {
   int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
   int bg_inflight = 0;    // background commits queued and not yet collected: while one runs, foreground commits keep the strip form (core.hip, msm_plan)
   size_t bg_lds;          // dynamic LDS each of them claims (a whole CU's)
+  unsigned* q_heads = nullptr;  // queue form of the row MSM (msm_queue.hip): a ring of 64 item counters (64 bytes apart), one per launch in flight
+  unsigned q_next = 0;
   // scratch
   void* scratch;
   size_t scratch_cap;
@@ -272,6 +274,12 @@ void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, 
 size_t msm_ring_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t wg_slots);
 void msm_ring_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                       const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit);
+
+// queue form (msm_queue.hip, k_msm_q): self-contained wavefronts with private LDS rings, items pulled from a device-side queue; the options and
+// the queue heads are those of the LAUNCHING context c (a virtual shard launches its parent's generator set on its own streams)
+size_t msm_q_runs(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, bool background);
+void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, bool background);
 
 static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {
   size_t b = (work + 255) / 256;

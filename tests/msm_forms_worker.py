@@ -75,5 +75,12 @@ if ctx.get_option("msm.form") >= 1:
     check(2112, 10, "uniform", True)
     check(768, 128, "mixed", False, background=True)
     check(1536, 300, "uniform", False, background=True)
+if ctx.get_option("msm.form") == 4:
+    # the queue form (msm_queue.hip) takes every launch that is not lookup-sized: a last row group that is not a whole wavefront, fewer
+    # rows than a wavefront, items of four units (runs that start and end inside every scalar), whole wavefronts of zero rows in the background
+    check(100, 400, "mixed", True)
+    check(40, 900, "carry", False)
+    check(200, 300, "short", True)
+    check(832, 96, "zero_rows", False, background=True)
 print("MSM_FORMS_OK %d" % checked)
 ctx.close()

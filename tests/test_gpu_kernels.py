@@ -454,7 +454,8 @@ def test_dot3_many_matches_reference_arithmetic(ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("opts,count", [({"msm__flat": 0}, 11), ({"msm__flat": 1}, 11), ({"msm__flat": 2}, 11), ({"msm__flat": 2, "msm__flat_bg": 1}, 11),
                                         ({"msm__flat": 2, "msm__wbits": 13, "msm__flat_rounds": 3}, 11), ({"msm__lds_bits": 10, "msm__form": 1}, 23),
-                                        ({"msm__lds_bits": 8, "msm__form": 1, "bg__eighths": 3}, 23), ({"msm__form": 2}, 23), ({"msm__form": 2, "msm__wbits": 12, "bg__eighths": 6}, 23)])
+                                        ({"msm__lds_bits": 8, "msm__form": 1, "bg__eighths": 3}, 23), ({"msm__form": 2}, 23), ({"msm__form": 2, "msm__wbits": 12, "bg__eighths": 6}, 23),
+                                        ({"msm__form": 4}, 27), ({"msm__form": 4, "msm__q_depth": 3, "msm__q_waves": 8, "msm__q_bg_waves": 4, "msm__q_units": 4, "msm__wbits": 12, "bg__eighths": 6}, 27)])
 def test_row_msm_forms_match_oracle(opts, count):
     """Every launch form of the fixed-base row MSM (DensePolynomial::commit_inner, src/dense_mlpoly.rs:164-177) against the oracle: the strip
     form with its short-scalar early exit, the balanced (column, window) form rolled and with two entries in flight, its background
