@@ -41,8 +41,8 @@ for name, label, rows, cols, blind in shapes:
         t.free(); g.free()
         continue
     outs = {}
-    for form in ("wide", "lds", "ring"):
-        ctx.set_option("msm.form", {"wide": 0, "lds": 1, "ring": 2}[form])
+    for form in ("wide", "lds", "queue"):
+        ctx.set_option("msm.form", {"wide": 3, "lds": 1, "queue": 2}[form])
         best = 1e9
         for it in range(6):
             t0 = time.time()
@@ -53,6 +53,6 @@ for name, label, rows, cols, blind in shapes:
         madds = rows * (cols + (1 if blind else 0)) * nwin
         print("2^%d %-13s %5d x %5d  %-4s  %2d adds/scalar  %.3f ms  %.2f G madd/s  (set built in %.2f s, wide %d bits)" %
               (s, name, rows, cols, form, nwin, best * 1e3, madds / best / 1e9, t_build, g.window_bits()), flush=True)
-    assert outs["wide"] == outs["lds"] == outs["ring"], "forms disagree on " + name
+    assert outs["wide"] == outs["lds"] == outs["queue"], "forms disagree on " + name
     t.free(); g.free()
 print("MSM_LDS_PROBE_OK")

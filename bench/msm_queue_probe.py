@@ -1,4 +1,4 @@
-"""The queue form of the row MSM (msm_queue.hip, option msm.form = 4) against the strip / balanced and ring forms on the launch shapes of a 2^s
+"""The queue form of the row MSM (msm_queue.hip, the default) against the strip / balanced forms (msm.form = 3) on the launch shapes of a 2^s
 proof, same process, same generator set: ms per launch (best of N, host clock, reduction and encode included) and G mixed additions/s, for a list
 of queue configurations "waves/depth/units". The commitments of every form must be equal (each is also checked against the oracle by
 tests/msm_forms_worker.py). usage: python bench/msm_queue_probe.py [log2_cons] [configs, e.g. 12/2/64,8/3/64] [shapes: w,h,d]"""
@@ -42,11 +42,10 @@ for key, name, label, rows, cols, blind in shapes:
             best = min(best, time.time() - t0)
         if ref is None:
             ref = out
-        assert out == ref, "forms disagree on %s (%s)" % (name, tag)
+        assert out == ref or os.environ.get("PROBE_NOCHECK"), "forms disagree on %s (%s)" % (name, tag)   # PROBE_NOCHECK: the -DSP_Q_DIAG timing variants
         print("2^%d %-13s %5d x %5d  %-14s %2d adds/scalar  %8.3f ms  %6.2f G madd/s  (%d-bit windows)" % (s, name, rows, cols, tag, nwin, best * 1e3, madds / best / 1e9, g.window_bits()), flush=True)
-    for form, tag in ((0, "wide"), (2, "ring")):
-        ctx.set_option("msm.form", form); run(tag)
-    ctx.set_option("msm.form", 4)
+    ctx.set_option("msm.form", 3); run("strip/balanced")
+    ctx.set_option("msm.form", 0)
     for wv, dp, un in cfgs:
         ctx.set_option("msm.q_waves", wv); ctx.set_option("msm.q_depth", dp); ctx.set_option("msm.q_units", un)
         run("queue %d/%d/%d" % (wv, dp, un))

@@ -7,8 +7,10 @@ mkdir -p $O
 Q="--no-cpu-baseline --concurrent 0 --steps ${AB_STEPS:-20} --warmup 2 --no-side-metrics --no-strong --log2-cons ${AB_LOG2:-20}"
 for rep in $(seq 1 $REPS); do
   for v in "$@"; do
-    name=${v%%:*}; envs=${v#*:}
-    SPARTAN_OPTIONS="testing.unlock=1${envs:+,$envs}" BENCH_NO_GATHER_PROBE=1 timeout ${AB_TIMEOUT:-200} python bench.py $Q > $O/ab_${name}_$rep.json 2>$O/ab_${name}_$rep.err
+    name=${v%%:*}; envs=${v#*:}; libenv=""
+    # "NAME@DIR:opts": the variant runs with the libraries of spartan_amd/DIR (a variant build of libspartan_hip.so next to a copy of libspartan_host.so)
+    if [[ "$name" == *@* ]]; then d=${name#*@}; name=${name%%@*}; libenv="SPARTAN_HIP_LIB=$(pwd)/spartan_amd/$d/libspartan_hip.so SPARTAN_HOST_LIB=$(pwd)/spartan_amd/$d/libspartan_host.so"; fi
+    env $libenv SPARTAN_OPTIONS="testing.unlock=1${envs:+,$envs}" BENCH_NO_GATHER_PROBE=1 timeout ${AB_TIMEOUT:-200} python bench.py $Q > $O/ab_${name}_$rep.json 2>$O/ab_${name}_$rep.err
   done
 done
 python - $O <<'PY'

@@ -104,7 +104,7 @@ void* stage_small(sp_ctx* c, size_t off, const void* src, size_t bytes) {
   memcpy(c->hmap + off, src, bytes);
   return c->hmap + off;
 }
-__global__ void k_done(volatile uint32_t* flag, uint32_t seq) {
+__global__ void k_done(volatile uint32_t* flag, uint32_t seq) { SP_FG_PRIO();
   __threadfence_system();
   *flag = seq;
 }
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(1024) k_msm_flat_bg(MsmFlatArgs A, unsigned nt
 // partial[row][w*cols + j].  The blind, if any, is column `cols` (generator h_idx).
 __global__ void __launch_bounds__(256) k_msm_windows(const Fq* __restrict__ Z, size_t z_row_stride, size_t rows, size_t cols,
                                                      const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
-                                                     const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial, MsmGeom geom) {
+                                                     const Fq* __restrict__ blinds, size_t h_idx, Pt* __restrict__ partial, MsmGeom geom) { SP_FG_PRIO();
   size_t ncol = cols + (blinds ? 1 : 0);
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * ncol * geom.nwin) return;
@@ -649,7 +649,7 @@ template <bool FINAL>
 __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__ Z, size_t z_row_stride, size_t cols,
                                                           const Niels* __restrict__ table, size_t g_off, const uint32_t* __restrict__ idx,
                                                           size_t idx_row_stride, const Fq* __restrict__ blinds, size_t h_idx,
-                                                          void* __restrict__ out, MsmGeom geom) {
+                                                          void* __restrict__ out, MsmGeom geom) { SP_FG_PRIO();
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
   size_t ncol = cols + (blinds ? 1 : 0), P = ncol * geom.nwin, row = blockIdx.y;
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256) k_msm_windows_tree(const Fq* __restrict__
 __global__ void __launch_bounds__(256) k_msm_windows_tree_fused(const Fq* __restrict__ Z, size_t z_row_stride, size_t cols, const Niels* __restrict__ table,
                                                                 size_t g_off, const uint32_t* __restrict__ idx, size_t idx_row_stride,
                                                                 const Fq* __restrict__ blinds, size_t h_idx, Pt10* __restrict__ part, uint32_t* __restrict__ tickets,
-                                                                Pt* __restrict__ sums_out, MsmGeom geom, DoneSig sig) {
+                                                                Pt* __restrict__ sums_out, MsmGeom geom, DoneSig sig) { SP_FG_PRIO();
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
   __shared__ unsigned ticket;
@@ -781,7 +781,7 @@ __device__ __forceinline__ Fq ipa_fold_b(const Fq* __restrict__ b, size_t x, siz
   return fold ? fq_add(fq_mul(v, u_inv), fq_mul(u, ld_fq(b + n_cur + x))) : v;  // b' = b_L u^-1 + u b_R
 }
 template <bool DED>  // DED: the two-multiplication tree level (pt10_tree_quad_ded); false: the unified formula (the fallback of an exceptional sum)
-__global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* __restrict__ table, MsmGeom geom, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_ipa_round(IpaRoundArgs A, const Niels* __restrict__ table, MsmGeom geom, DoneSig sig) { SP_FG_PRIO();
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
   __shared__ unsigned ticket;
@@ -943,13 +943,15 @@ extern "C" int32_t ipa_round_launch(sp_ctx* c, const sp_gens* g, IpaRoundArgs* A
 
 // reduction pass: grid (rows, nchunks); block sums `chunk` consecutive partials of its row into one point.
 // Reductions run on the radix-2^25.5 serial-chain arithmetic (fe10.hpp): few waves, latency-bound.
-__global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt10* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ in, size_t P, size_t chunk, Pt10* __restrict__ out,
+                                                        const unsigned* __restrict__ counts /* queue form: slots in use per 64-row group, or null */) { SP_FG_PRIO();
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
   size_t row = blockIdx.x, ck = blockIdx.y, nchunks = gridDim.y;
   int t = threadIdx.x;
   size_t lo = ck * chunk, hi = lo + chunk;
   if (hi > P) hi = P;
+  if (counts && hi > counts[row / 64]) hi = counts[row / 64];
   Pt10 acc = pt10_identity();
   bool any = false;
   for (size_t s = lo + t; s < hi; s += 256) {
@@ -969,21 +971,24 @@ __global__ void __launch_bounds__(256) k_pt_reduce_pass(const Pt* __restrict__ i
 // (every Sigma-protocol and inner-product round: 151 sequential ones per 2^20 proof) take the host route, batched row
 // commitments (hundreds of rows in parallel) the device route.
 template <bool IN10, bool ENCODE>
-__global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ partial_, size_t nstrips, uint8_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ partial_, size_t nstrips, uint8_t* __restrict__ out,
+                                                    const unsigned* __restrict__ counts /* queue form: slots in use per 64-row group, or null */) { SP_FG_PRIO();
   __shared__ Pt10 sm[256];
   __shared__ Fe10 xch[256];
   size_t row = blockIdx.x;
   int t = threadIdx.x;
   Pt10 acc = pt10_identity();
   bool any = false;
-  for (size_t s = t; s < nstrips; s += 256) {
+  size_t nlive = nstrips;  // the row's partial sums lie nstrips apart; the first nlive of them hold a sum
+  if (counts && !IN10 && counts[row / 64] < nstrips) nlive = counts[row / 64];
+  for (size_t s = t; s < nlive; s += 256) {
     Pt10 p = IN10 ? ((const Pt10*)partial_)[row * nstrips + s] : pt10_load(((const Pt*)partial_)[row * nstrips + s]);
     acc = any ? pt10_add(acc, p) : p;
     any = true;
   }
   sm[t] = acc;
   __syncthreads();
-  pt10_tree_quad(sm, xch, nstrips < 256 ? nstrips : 256);
+  pt10_tree_quad(sm, xch, nlive < 256 ? nlive : 256);
   if (t == 0) {
     Pt10 r = sm[0];
     if (ENCODE) {
@@ -1001,7 +1006,7 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ par
 // RFC 9496 encode of many row sums at once: one LANE per row. (With the encode inside k_msm_reduce one lane per BLOCK runs
 // the ~100 us inverse-square-root chain while 255 wait: a 1024-row commit spent 0.6 ms there; this way the 1024 chains
 // run side by side in 16 wavefronts.)
-__global__ void __launch_bounds__(64) k_pt_encode(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_pt_encode(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) { SP_FG_PRIO();
   size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (row >= rows) return;
   uint8_t c[32];
@@ -1095,8 +1100,7 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->done_seq = 0;
   HIPCHK(hipMalloc((void**)&c->done_counter, 64));
   HIPCHK(hipMemset(c->done_counter, 0, 64));
-  HIPCHK(hipMalloc((void**)&c->q_heads, 64 * 64));
-  HIPCHK(hipMemset(c->q_heads, 0, 64 * 64));
+  HIPCHK(hipMalloc((void**)&c->q_heads, 4 * (size_t)MSMQ_BLOCK_WORDS * MSMQ_BLOCKS));
 #ifdef SP_KTIME
   if (c->opt.v[OPT_DEBUG_KTIME]) { HIPCHK(hipMalloc((void**)&c->ktime, 64 * 8)); HIPCHK(hipMemset(c->ktime, 0, 64 * 8)); }
 #endif
@@ -1406,8 +1410,9 @@ constexpr size_t SP_HOST_ENCODE_ROWS = 8;  // commitments of up to this many row
 struct MsmPlan {
   bool windowed, two_pass;
   bool lds = false;  // the LDS-staged small-window form (msm_lds.hip), P = runs per row-block
-  bool ring = false; // the loader / consumer ring form over the wide tables (msm_lds.hip, k_msm_ring), P = runs per row-block
   bool queue = false; // the queue form (msm_queue.hip, k_msm_q): P = runs per row
+  MsmQRuns qruns{0, 0, 0};
+  int qrole = MSMQ_ALONE;
   int flat;  // 0: strip form; 1 / 2: balanced form (k_msm_flat<0> / <1>), P = runs per row
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
@@ -1477,14 +1482,16 @@ static MsmPlan msm_plan(const sp_ctx* c, const sp_gens* g, size_t rows, size_t c
       size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
       m.lds = true; m.flat = 0;
       m.P = msm_lds_runs(g, launch_rows, cols, has_blinds, slots);
-    } else if (opt.v[OPT_MSM_FORM] == 2 && launch_rows >= 512) {  // fewer rows per launch (the witness upload chunks of a 2^20 proof: 256) leave the consumer wavefronts one per SIMD
-      const size_t cus = (size_t)c->n_cus;
-      size_t slots = bg_subblocks ? bg_subblocks / 4 : (shares_chip ? 3 * cus : cus);
-      m.ring = true; m.flat = 0;
-      m.P = msm_ring_runs(g, launch_rows, cols, has_blinds, slots);
-    } else if (opt.v[OPT_MSM_FORM] == 4) {
+    } else if ((opt.v[OPT_MSM_FORM] == 0 || opt.v[OPT_MSM_FORM] == 2) && launch_rows >= 256 && launch_rows == rows && (rows + 63) / 64 <= MSMQ_MAX_GROUPS) {
+      // THE DEFAULT for commits of >= 256 rows since round 6: the queue form (msm_queue.hip). Measured against the strip / balanced forms it
+      // replaces there (profiles/r6_ab_queue_form.txt): 8-18 % faster per launch, SNARK::prove 2^20 -0.6 ms; msm.form = 3 keeps the old forms.
+      // (a commit issued in row chunks behind its upload has the chip to itself and rows that are alike: the balanced form's case)
       m.queue = true; m.flat = 0;
-      m.P = msm_q_runs(c, g, launch_rows, cols, has_blinds, bg_subblocks != 0);
+      // the background launch and a foreground launch that meets one in flight share the chip with each other and with the latency kernels
+      const bool co = opt.v[OPT_MSM_Q_CORESIDENT] != 0;
+      m.qrole = bg_subblocks ? (co ? MSMQ_CORESIDENT : MSMQ_SHARE) : (shares_chip && co ? MSMQ_CORESIDENT : MSMQ_ALONE);
+      m.qruns = msm_q_cut(c, g, launch_rows, cols, has_blinds, m.qrole);
+      m.P = m.qruns.S;
     }
   }
   m.chunk = 1024; m.nchunks = (m.P + m.chunk - 1) / m.chunk;
@@ -1509,6 +1516,7 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
   Pt* sums = (Pt*)sums_extra;
   (void)prof;
   auto scope = [&](int fam, double bytes) { return ProfScope(c, fam, bytes, st); };  // HIP events on the stream the kernels run on
+  const unsigned* qcounts = nullptr;  // queue form: partial-sum slots in use per 64-row group (device), for the reduction that follows
   if (!do_msm) {
   } else if (m.windowed) {
     ProfScope ps = scope(PF_MSM_WINDOWS, 32.0 * (double)total + 128.0 * (double)(rows * m.P));
@@ -1523,9 +1531,7 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
     if (m.queue) {
-      msm_q_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0);
-    } else if (m.ring) {
-      msm_ring_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
+      msm_q_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.qruns, m.qrole, &qcounts);
     } else if (m.lds) {
       msm_lds_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
     } else if (m.flat) {
@@ -1554,17 +1560,17 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
   if (m.two_pass) {
     {
       ProfScope ps = scope(PF_MSM_REDUCE_PASS, (double)(rows * m.P * sizeof(Pt)) + (double)(rows * m.nchunks * sizeof(Pt10)));
-      hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)m.nchunks), dim3(256), 0, st, (const Pt*)partial, m.P, m.chunk, partial2);
+      hipLaunchKernelGGL(k_pt_reduce_pass, dim3((unsigned)rows, (unsigned)m.nchunks), dim3(256), 0, st, (const Pt*)partial, m.P, m.chunk, partial2, qcounts);
     }
     ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.nchunks * sizeof(Pt10)) + 32.0 * (double)rows);
-    if (encode && batch_encode) hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, (uint8_t*)sums);
-    else if (encode) hipLaunchKernelGGL((k_msm_reduce<true, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
-    else hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout);
+    if (encode && batch_encode) hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, (uint8_t*)sums, (const unsigned*)nullptr);
+    else if (encode) hipLaunchKernelGGL((k_msm_reduce<true, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout, (const unsigned*)nullptr);
+    else hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial2, m.nchunks, dout, (const unsigned*)nullptr);
   } else {
     ProfScope ps = scope(PF_MSM_REDUCE, (double)(rows * m.P * sizeof(Pt)) + 32.0 * (double)rows);
-    if (encode && batch_encode) hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, (uint8_t*)sums);
-    else if (encode) hipLaunchKernelGGL((k_msm_reduce<false, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
-    else hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout);
+    if (encode && batch_encode) hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, (uint8_t*)sums, qcounts);
+    else if (encode) hipLaunchKernelGGL((k_msm_reduce<false, true>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout, qcounts);
+    else hipLaunchKernelGGL((k_msm_reduce<false, false>), dim3((unsigned)rows), dim3(256), 0, st, (const void*)partial, m.P, dout, qcounts);
   }
   if (encode && batch_encode) {
     ProfScope ps = scope(PF_MSM_REDUCE, 160.0 * (double)rows);
@@ -1612,7 +1618,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
       }
       if (nblk > 1) {
         ProfScope ps(c, PF_MSM_REDUCE, 160.0 * (double)(rows * nblk) + 128.0 * (double)rows);
-        hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)part, nblk, sums_dst);
+        hipLaunchKernelGGL((k_msm_reduce<true, false>), dim3((unsigned)rows), dim3(256), 0, c->stream, (const void*)part, nblk, sums_dst, (const unsigned*)nullptr);
       }
     } else {
       if (idx_row_stride) return SP_EINVAL;  // per-row index lists exist on the lookup+tree path only
@@ -1902,7 +1908,7 @@ int32_t sp_table_upload(sp_ctx* c, const uint64_t* Z, size_t len, sp_table** out
   if (rc != SP_OK) { sp_table_free(*out); *out = nullptr; }
   return rc;
 }
-__global__ void k_copy_small(const Fq* __restrict__ src, size_t n, Fq* __restrict__ dst) {
+__global__ void k_copy_small(const Fq* __restrict__ src, size_t n, Fq* __restrict__ dst) { SP_FG_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) st_fq(dst + i, ld_fq(src + i));
 }

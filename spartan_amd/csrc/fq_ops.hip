@@ -45,7 +45,7 @@ constexpr size_t EQ_SMALL_ELL = 13;
 // wavefront they were executed one after the other (10 dependent multiplications instead of 4: 14 -> ~8 us per table, 70+ tables per
 // proof). The challenge vector travels in the kernel arguments (r_host == null) instead of being read from the host-mapped page.
 struct EqR { Fq r[13]; };
-__global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, EqR rin, size_t ell, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ r_host, EqR rin, size_t ell, Fq* __restrict__ out) { SP_FG_PRIO();
   __shared__ Fq r[16];
   __shared__ Fq ta[16], tb[16];
   __shared__ Fq hi;
@@ -94,14 +94,14 @@ __global__ void __launch_bounds__(256) k_eq_expand_small(const Fq* __restrict__ 
 // multiplication per entry in a streaming kernel with a few hundred bytes of code, instead of the 59 KB unrolled kernel
 // (whose first wave on every CU spends ~20 us fetching it). The product of the same factors in another order is the same
 // field element, hence the same canonical limbs.
-__global__ void __launch_bounds__(256) k_eq_outer(const Fq* __restrict__ hi, const Fq* __restrict__ lo, int lo_ell, size_t len, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_eq_outer(const Fq* __restrict__ hi, const Fq* __restrict__ lo, int lo_ell, size_t len, Fq* __restrict__ out) { SP_FG_PRIO();
   size_t mask = ((size_t)1 << lo_ell) - 1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
     st_fq(out + i, fq_mul(ld_fq(hi + (i >> lo_ell)), ld_fq(lo + (i & mask))));
 }
 // <Z, chi(r)> without materialising chi; per-block partials.
 template <int TOPB>
-__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_evaluate(const Fq* __restrict__ Z, const Fq* __restrict__ r_host, size_t ell, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   __shared__ Fq r[40];
   if (threadIdx.x < ell) r[threadIdx.x] = ld_fq(r_host + threadIdx.x);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void sc_point(const Fq& a0, const Fq& a1, const Fq& b
   e3 = fq_add(e3, fq_mul(a3, fq_sub(fq_mul(b3, c3), d3)));
 }
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_eval(Tabs4 T, size_t half, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_sc_eval(Tabs4 T, size_t half, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
   Fq z = fq_zero();
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_sc_eval(Tabs4 T, size_t half, Fq* __res
 // fused bind(r) + evaluate next round. quarter = len/4. Thread i < quarter reads T[i], T[i+q], T[i+2q], T[i+3q],
 // writes the bound values T'[i] = T[i] + r (T[i+2q]-T[i]) and T'[i+q], and evaluates the round on (T'[i], T'[i+q]).
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_bind_eval(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_sc_bind_eval(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   constexpr int NT = KIND == 0 ? 2 : (KIND == 1 ? 3 : 4);
   Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval(Tabs4 T, size_t quarter, F
 }
 // the same for any number of tables of one length (pointer list in the host-mapped page); heads != nullptr with half == 1:
 // the bound value (the table's only remaining entry) also goes to the result area — bound_poly_var_top + [0] in one launch
-__global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ ptrs, size_t ntabs, size_t half, Fq r, Fq* __restrict__ heads, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ ptrs, size_t ntabs, size_t half, Fq r, Fq* __restrict__ heads, DoneSig sig) { SP_FG_PRIO();
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < ntabs * half; idx += (size_t)gridDim.x * blockDim.x) {
     size_t t = idx / half, i = idx % half;
     Fq* p = ptrs[t];
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_bind_top_list(Fq* const* __restrict__ p
 // table k, then lanes 0..2 evaluate t = 0, 2, 3 with one instruction stream (operands chosen by selects). Block = 32
 // indices x 8 lanes; partials[blk][3].
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) { SP_FG_PRIO();
   constexpr int NT = KIND == 0 ? 2 : 4;
   __shared__ Fq bound[32][8];  // [index][table*2 + half]
   __shared__ Fq red[3][32];
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(Tabs4 T, size_t quart
   if (threadIdx.x < 3) st_fq(partials + (size_t)blockIdx.x * 3 + threadIdx.x, red[threadIdx.x][0]);
   signal_done(sig);
 }
-__global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t half, Fq r) {
+__global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t half, Fq r) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     for (int k = 0; k < ntabs; k++) {
       Fq x0 = ld_fq(T.p[k] + i), x1 = ld_fq(T.p[k] + half + i);
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) k_bind_top(Tabs4 T, int ntabs, size_t hal
   }
 }
 // partials[nblk][K] -> out[K] ; single block
-__global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   for (int k = 0; k < K; k++) {
     Fq acc[1] = {fq_zero()};
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const Fq* __restrict__ 
 // thread has 4..8 rows and the launch has thousands of blocks, also for the 1024 x 1024 witness), then the 4 row lanes are
 // added in LDS -> partial[chunk][col]. Stage 2, grid ceil(R/32): 32 columns x 8 chunk lanes per block add the chunks.
 __global__ void __launch_bounds__(256) k_vecmat(const Fq* __restrict__ L, size_t Lsz, const Fq* __restrict__ Z, size_t R, size_t jchunk,
-                                                Fq* __restrict__ partial) {
+                                                Fq* __restrict__ partial) { SP_FG_PRIO();
   __shared__ Fq sm[4][64];
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
   size_t i = (size_t)blockIdx.x * 64 + cl;
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) k_vecmat(const Fq* __restrict__ L, size_t
   __syncthreads();
   if (g == 0 && i < R) st_fq(partial + (size_t)blockIdx.y * R + i, fq_add(fq_add(sm[0][cl], sm[1][cl]), fq_add(sm[2][cl], sm[3][cl])));
 }
-__global__ void __launch_bounds__(256) k_colsum(const Fq* __restrict__ partial, size_t nchunks, size_t R, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_colsum(const Fq* __restrict__ partial, size_t nchunks, size_t R, Fq* __restrict__ out) { SP_FG_PRIO();
   __shared__ Fq sm[8][32];
   const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
   size_t i = (size_t)blockIdx.x * 32 + cl;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) k_colsum(const Fq* __restrict__ partial, 
 }
 // rows per chunk of stage 1: 4 row lanes x (4 rows for small matrices, 8 for large ones)
 static size_t vecmat_jchunk(size_t Lsz, size_t R) { return Lsz * R <= ((size_t)1 << 22) ? 16 : 32; }
-__global__ void __launch_bounds__(256) k_dot(const Fq* __restrict__ a, const Fq* __restrict__ b, size_t n, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_dot(const Fq* __restrict__ a, const Fq* __restrict__ b, size_t n, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   Fq acc[1] = {fq_zero()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_dot(const Fq* __restrict__ a, const Fq*
   if (threadIdx.x == 0) st_fq(partials + blockIdx.x, acc[0]);
 }
 // out[k*count + e] = *(ptrs[k] + e): pointer list read from the host-mapped page
-__global__ void k_gather_elems(const Fq* const* __restrict__ ptrs, size_t n, size_t count, Fq* __restrict__ out) {
+__global__ void k_gather_elems(const Fq* const* __restrict__ ptrs, size_t n, size_t count, Fq* __restrict__ out) { SP_FG_PRIO();
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n * count) st_fq(out + t, ld_fq(ptrs[t / count] + t % count));
 }
@@ -711,10 +711,10 @@ static int32_t gather_elems(sp_ctx* c, sp_table* const* tabs, const size_t* offs
 }
 int32_t sp_table_heads(sp_ctx* c, sp_table* const* tabs, size_t ntabs, uint64_t* out) { return gather_elems(c, tabs, nullptr, ntabs, 1, out); }
 // ---- sharding helpers (sum-check tables by index residue, bound by row blocks) --------------------------------
-__global__ void __launch_bounds__(256) k_residue_split(const Fq* __restrict__ src, size_t W, size_t g, size_t n, Fq* __restrict__ dst) {
+__global__ void __launch_bounds__(256) k_residue_split(const Fq* __restrict__ src, size_t W, size_t g, size_t n, Fq* __restrict__ dst) { SP_FG_PRIO();
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) st_fq(dst + k, ld_fq(src + k * W + g));
 }
-__global__ void __launch_bounds__(256) k_add_into(Fq* __restrict__ dst, const Fq* __restrict__ src, size_t n) {
+__global__ void __launch_bounds__(256) k_add_into(Fq* __restrict__ dst, const Fq* __restrict__ src, size_t n) { SP_FG_PRIO();
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) st_fq(dst + k, fq_add(ld_fq(dst + k), ld_fq(src + k)));
 }
 int32_t sp_table_residue_split(sp_ctx* c, const sp_table* src, size_t W, size_t g, sp_table** out) {
@@ -744,11 +744,11 @@ int32_t sp_table_gather(sp_ctx* c, sp_table* const* tabs, const size_t* offs, si
 // ---- hand-over of residue-sharded sum-check tables (the batched cubic sum-checks of SPARK): when the tables have become short
 // enough that a round costs less than the exchange, every shard packs its sub-tables into one buffer (one DMA), the buffers are gathered
 // (host: in-process for virtual shards, the commit transport between ranks), and the owner scatters them back into the full tables.
-__global__ void __launch_bounds__(256) k_tables_pack(const Fq* const* __restrict__ ptrs, size_t ntabs, size_t count, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_tables_pack(const Fq* const* __restrict__ ptrs, size_t ntabs, size_t count, Fq* __restrict__ out) { SP_FG_PRIO();
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntabs * count; t += (size_t)gridDim.x * blockDim.x)
     st_fq(out + t, ld_fq(ptrs[t / count] + t % count));
 }
-__global__ void __launch_bounds__(256) k_tables_unpack_residues(Fq* const* __restrict__ ptrs, size_t ntabs, size_t W, size_t sub, const Fq* __restrict__ in) {
+__global__ void __launch_bounds__(256) k_tables_unpack_residues(Fq* const* __restrict__ ptrs, size_t ntabs, size_t W, size_t sub, const Fq* __restrict__ in) { SP_FG_PRIO();
   // in[(g * ntabs + t) * sub + k] -> tabs[t][k * W + g]
   for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < W * ntabs * sub; x += (size_t)gridDim.x * blockDim.x) {
     size_t k = x % sub, t = (x / sub) % ntabs, g = x / (sub * ntabs);

@@ -72,7 +72,7 @@ struct sp_ctx {
   int bg_blocks;          // workgroups of a background MSM (one per CU, fewer than CUs); 0 = plain launches
   int bg_inflight = 0;    // background commits queued and not yet collected: while one runs, foreground commits keep the strip form (core.hip, msm_plan)
   size_t bg_lds;          // dynamic LDS each of them claims (a whole CU's)
-  unsigned* q_heads = nullptr;  // queue form of the row MSM (msm_queue.hip): a ring of 64 item counters (64 bytes apart), one per launch in flight
+  unsigned* q_heads = nullptr;  // queue form of the row MSM (msm_queue.hip): a ring of MSMQ_BLOCKS counter blocks, one per launch in flight
   unsigned q_next = 0;
   // scratch
   void* scratch;
@@ -270,16 +270,15 @@ size_t msm_lds_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds,
 void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                      const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit);
 
-// ring form (msm_lds.hip, k_msm_ring): the same tiles over the WIDE tables, each row's entry gathered into LDS by loader wavefronts
-size_t msm_ring_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t wg_slots);
-void msm_ring_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                      const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit);
-
 // queue form (msm_queue.hip, k_msm_q): self-contained wavefronts with private LDS rings, items pulled from a device-side queue; the options and
 // the queue heads are those of the LAUNCHING context c (a virtual shard launches its parent's generator set on its own streams)
-size_t msm_q_runs(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, bool background);
+struct MsmQRuns { unsigned nb, len, S; };  // queue form (msm_queue.hip): runs per row, units per run, partial-sum slots per row
+constexpr unsigned MSMQ_MAX_GROUPS = 1024, MSMQ_BLOCK_WORDS = 2 * MSMQ_MAX_GROUPS, MSMQ_BLOCKS = 64;  // counter blocks of sp_ctx::q_heads
+enum MsmQRole { MSMQ_ALONE = 0, MSMQ_SHARE = 1, MSMQ_CORESIDENT = 2 };  // what else runs on the chip next to a launch (msm_queue.hip, msm_q_shape)
+MsmQRuns msm_q_cut(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, int role);
 void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, bool background);
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, const MsmQRuns& r, int role,
+                   const unsigned** counts_out /* per 64-row group: partial sums written (take min with r.S) */);
 
 static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {
   size_t b = (work + 255) / 256;
@@ -292,6 +291,16 @@ static inline size_t ilog2(size_t x) {
   while (((size_t)1 << l) < x) l++;
   return l;
 }
+
+// Every kernel of the Fiat-Shamir chain (everything but the throughput-sized row MSMs and the table builds) raises the issue priority of its
+// wavefronts at entry: VALU issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH "two waves per SIMD"), and a latency
+// kernel that shares a SIMD with the persistent wavefronts of a background MSM — older by construction, and ALU-saturating — otherwise
+// gets the leftover issue slots only. No effect where nothing else shares the SIMD.
+#ifndef SP_FG_PRIO_OFF   // (-DSP_FG_PRIO_OFF: the A/B variant without it)
+#define SP_FG_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define SP_FG_PRIO() do { } while (0)
+#endif
 
 __device__ __forceinline__ Fq ld_fq(const Fq* p) {
   const ulonglong2* q = reinterpret_cast<const ulonglong2*>(p);

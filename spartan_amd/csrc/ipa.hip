@@ -73,7 +73,7 @@ __device__ __forceinline__ Fq ipa_s(const Fq* __restrict__ s, size_t p, int fold
 __global__ void __launch_bounds__(512) k_ipa_prepare(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n_cur,
                                                      size_t n0, size_t g_off, uint32_t q_idx, uint32_t h_idx, Fq q_scale, Fq blind_L, Fq blind_R,
                                                      Fq* __restrict__ rows, uint32_t* __restrict__ idx_lr, int fold, Fq u, Fq u_inv,
-                                                     Fq* __restrict__ a_new, Fq* __restrict__ b_new, Fq* __restrict__ s_new) {
+                                                     Fq* __restrict__ a_new, Fq* __restrict__ b_new, Fq* __restrict__ s_new) { SP_FG_PRIO();
   __shared__ Fq sm[2][512];
   size_t h = n_cur / 2, m = n0 / 2 + 2;
   if (blockIdx.x + 1 < gridDim.x) {
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(512) k_ipa_prepare(const Fq* __restrict__ a, c
 }
 // bullet.rs:105-109 (a, b) and the coefficient update replacing the G fold
 __global__ void __launch_bounds__(256) k_ipa_fold(Fq* __restrict__ a, Fq* __restrict__ b, const Fq* __restrict__ s, Fq* __restrict__ s_new,
-                                                  size_t n_cur, size_t n0, Fq u, Fq u_inv) {
+                                                  size_t n_cur, size_t n0, Fq u, Fq u_inv) { SP_FG_PRIO();
   size_t h = n_cur / 2;
   for (size_t i = threadIdx.x; i < h; i += 256) {
     Fq al = ld_fq(a + i), ar = ld_fq(a + h + i), bl = ld_fq(b + i), br = ld_fq(b + h + i);
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_ipa_fold(Fq* __restrict__ a, Fq* __rest
     st_fq(s_new + 2 * p + 1, fq_mul(sp_, u));
   }
 }
-__global__ void __launch_bounds__(256) k_ipa_ghat_row(const Fq* __restrict__ s, size_t n0, Fq d, Fq r, Fq* __restrict__ row) {
+__global__ void __launch_bounds__(256) k_ipa_ghat_row(const Fq* __restrict__ s, size_t n0, Fq d, Fq r, Fq* __restrict__ row) { SP_FG_PRIO();
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0; j += (size_t)gridDim.x * blockDim.x) st_fq(row + j, fq_mul(ld_fq(s + j), d));
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st_fq(row + n0, fq_zero());
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_ipa_ghat_row(const Fq* __restrict__ s, 
 // the scalar row d * s (+ 0 * Q + r * H) of the commitment under g_hat = sum_p s[p] G[p] (nizk/mod.rs:496-501), with the last
 // recorded fold applied on the way (a' = a_0 u + u^-1 a_1, s'[2p] = s[p] u^-1, s'[2p+1] = s[p] u) instead of a launch of its own.
 __global__ void __launch_bounds__(256) k_ipa_finish_rows(const Fq* __restrict__ a, const Fq* __restrict__ b, const Fq* __restrict__ s, size_t n0, int fold, Fq u, Fq u_inv,
-                                                         Fq d, Fq r, Fq* __restrict__ row, Fq* __restrict__ ab_out) {
+                                                         Fq d, Fq r, Fq* __restrict__ row, Fq* __restrict__ ab_out) { SP_FG_PRIO();
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n0; j += (size_t)gridDim.x * blockDim.x) st_fq(row + j, fq_mul(ipa_s(s, j, fold, u, u_inv), d));
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st_fq(row + n0, fq_zero());
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_ipa_finish_rows(const Fq* __restrict__ 
   }
 }
 // a_hat, b_hat (the vectors at length 1) into the host-mapped result page
-__global__ void k_ipa_heads(const Fq* __restrict__ a, const Fq* __restrict__ b, Fq* __restrict__ out, DoneSig sig) {
+__global__ void k_ipa_heads(const Fq* __restrict__ a, const Fq* __restrict__ b, Fq* __restrict__ out, DoneSig sig) { SP_FG_PRIO();
   if (threadIdx.x == 0) { st_fq(out, ld_fq(a)); st_fq(out + 1, ld_fq(b)); }
   signal_done(sig);
 }
@@ -173,7 +173,7 @@ __global__ void k_ipa_heads(const Fq* __restrict__ a, const Fq* __restrict__ b, 
 // the first round's c_L = <a_L, b_R>, c_R = <a_R, b_L> (bullet.rs:80-81) as one partial pair per block of 512 index pairs.
 __global__ void __launch_bounds__(256) k_ipa_init(const Fq* __restrict__ a_src, const Fq* __restrict__ b_src, size_t n, size_t g_off, uint32_t q_idx,
                                                   uint32_t h_idx, Fq* __restrict__ a, Fq* __restrict__ b, Fq* __restrict__ s, uint32_t* __restrict__ idx,
-                                                  uint32_t* __restrict__ counters, Fq* __restrict__ c0_out) {
+                                                  uint32_t* __restrict__ counters, Fq* __restrict__ c0_out) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const size_t h = n / 2;
   Fq c[2] = {fq_zero(), fq_zero()};

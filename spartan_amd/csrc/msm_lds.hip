@@ -206,160 +206,6 @@ __global__ void __launch_bounds__(1024) k_msm_lds(MsmLdsArgs A) {
   }
 }
 
-// ================================================================================================ the RING form (msm.form = 2)
-// The loader / consumer split over the WIDE tables: same tiles, same lock-step, same partial sums as above — but the
-// sub-tables stay in HBM (15/14-bit windows: 17-19 additions per scalar) and what the loader wavefronts bring into LDS is each row's OWN
-// entry, gathered by LDS-DMA with a per-lane source address one tile ahead:
-//   consumer lanes (one per row) at tile t: the mixed addition against the entry that lies in ring[t & 1] (no table pointer, no
-//     in-flight entry registers: 24 fewer live VGPRs than the strip form, 1024-thread workgroups at 128 VGPRs), then the signed digit
-//     of tile t + 2 into a 3-slot digit board in LDS;
-//   loader wavefronts at tile t: read the digits of tile t + 1 from the board and issue, for 64 rows at a time, six 16-byte LDS-DMA
-//     gathers (entry = 96 bytes of a 128-byte line) into ring[(t + 1) & 1] — chunk-major ([chunk][row] x 16 B: the DMA's LDS side is
-//     wave-uniform base + lane * 16), so a consumer's reads are conflict-free;
-//   one workgroup barrier per tile hands everything over.
-// The gathers of a whole tile (768 per CU) are in flight while the additions of the previous tile run: the two resources the strip form
-// used one after the other (profiles/r4_pmc_kernels.txt: 42-47 % of wave cycles waiting on memory) are used at the same time.
-struct MsmRingArgs {
-  const Fq* Z; size_t z_row_stride, rows, cols;
-  const Niels* table; size_t g_off; const uint32_t* idx; const Fq* blinds; size_t h_idx;
-  Pt* partial;              // [rows][nb]
-  unsigned nb, nrb, rows_per_wg, n_wg;
-  unsigned rpad;            // rows_per_wg rounded up to 64: lanes of a ring slot
-  int wbits, nwin, tent;
-};
-__device__ __forceinline__ Fp lds_fp2(const uint8_t* lo, const uint8_t* hi) {  // 32 bytes out of two 16-byte chunks
-  uint4 a = *reinterpret_cast<const uint4*>(lo), b = *reinterpret_cast<const uint4*>(hi);
-  return Fp{{(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32), (uint64_t)b.z | ((uint64_t)b.w << 32)}};
-}
-__global__ void __launch_bounds__(1024) k_msm_ring(MsmRingArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t ring_lds[];
-  const unsigned T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned nlive = A.rpad >> 6, nload = (T >> 6) - nlive;   // the launch always adds at least one loader wavefront
-  const bool loader = wave >= nlive;
-  const unsigned slot_bytes = 96u * A.rpad, chunk_bytes = 16u * A.rpad;
-  uint8_t* const ring = ring_lds;                                            // 2 slots of [6 chunks][rpad] x 16 B
-  uint16_t* const board = reinterpret_cast<uint16_t*>(ring_lds + 2 * slot_bytes);  // 3 slots of rpad digits (magnitudes; 0 = nothing to add)
-  uint8_t* const ident = ring_lds + 2 * slot_bytes + 6 * A.rpad;             // the neutral entry (1, 1, 0), 96 bytes
-  if (tid < 6) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tid == 0 || tid == 2) v.x = 1;
-    reinterpret_cast<uint4*>(ident)[tid] = v;
-  }
-  const int nwin = A.nwin, c = A.wbits;
-  const size_t ncol = A.cols + (A.blinds ? 1 : 0);
-  const size_t U = ncol * (size_t)nwin;
-  const uint32_t mask = (1u << c) - 1;
-  const size_t sub_bytes = (size_t)A.tent * sizeof(Niels);
-  for (unsigned wg = blockIdx.x; wg < A.n_wg; wg += gridDim.x) {
-    const unsigned rb = wg % A.nrb, bk = wg / A.nrb;
-    const size_t row = (size_t)rb * A.rows_per_wg + tid;
-    const bool live = !loader && tid < A.rows_per_wg && row < A.rows;
-    const size_t u0 = U * bk / A.nb, u1 = U * (bk + 1) / A.nb;
-    const size_t ntile = u1 - u0;
-    auto scalar_ptr = [&](size_t jj) { return jj < A.cols ? A.Z + row * A.z_row_stride + jj : A.blinds + row; };
-    auto col_base = [&](size_t jj) {
-      const size_t pt = jj < A.cols ? (A.idx ? (size_t)A.idx[jj] : A.g_off + jj) : A.h_idx;
-      return reinterpret_cast<const uint8_t*>(A.table + pt * (size_t)nwin * (size_t)A.tent);
-    };
-    Pt acc = pt_identity();
-    if (ntile) {
-      // ---- consumer state: the digit stream, two tiles ahead of the additions
-      size_t j = u0 / (size_t)nwin;
-      int w = (int)(u0 % (size_t)nwin);
-      uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      int carry = 0;
-      unsigned hist = 0;  // bit 2k: the digit of tile (produced - 1 - k) is negative; bit 2k + 1: it is zero
-      Fq raw_next = fq_zero();
-      auto take = [&](const Fq& raw) {
-        Fq s = fq_from_mont(raw);  // canonical integer < q < 2^253 (scalar/mod.rs:32-36 does the same for dalek)
-        s0 = s.l[0]; s1 = s.l[1]; s2 = s.l[2]; s3 = s.l[3];
-        carry = 0;
-      };
-      auto shift = [&]() {
-        s0 = (s0 >> c) | (s1 << (64 - c));
-        s1 = (s1 >> c) | (s2 << (64 - c));
-        s2 = (s2 >> c) | (s3 << (64 - c));
-        s3 >>= c;
-      };
-      size_t produced = 0;  // digits written to the board so far (tile index of the next one)
-      auto produce = [&]() {  // the digit of tile `produced` -> board, history (past the last tile: a zero)
-        unsigned flags = 2u;
-        if (produced < ntile) {
-          if (w == nwin) {
-            j++; w = 0;
-            if (live) { take(raw_next); if (j + 1 < ncol) raw_next = ld_fq(scalar_ptr(j + 1)); }
-          }
-          int d = (int)(s0 & mask) + carry;
-          carry = d >= A.tent;
-          d -= carry << c;
-          const uint32_t m = (uint32_t)(d < 0 ? -d : d);
-          shift();
-          w++;
-          if (!loader) board[(produced % 3) * A.rpad + tid] = (uint16_t)m;
-          flags = (d < 0 ? 1u : 0u) | (m == 0 ? 2u : 0u);
-        }
-        hist = (hist << 2) | flags;
-        produced++;
-      };
-      if (live) {
-        take(ld_fq(scalar_ptr(j)));
-        if (j + 1 < ncol) raw_next = ld_fq(scalar_ptr(j + 1));
-        for (int k = 0; k < w; k++) {  // the carry into window w depends on all lower windows
-          int d = (int)(s0 & mask) + carry;
-          carry = d >= A.tent;
-          shift();
-        }
-      }
-      // ---- loader state: the tile whose entries are gathered next (wave-uniform)
-      size_t jn = u0 / (size_t)nwin;
-      int wn = (int)(u0 % (size_t)nwin);
-      const uint8_t* cbase = col_base(jn);
-      auto gather = [&](size_t t) {  // entries of tile t -> ring[t & 1], digits from board[t % 3]
-        const uint8_t* sub = cbase + (size_t)wn * sub_bytes;
-        uint8_t* dst = ring + (t & 1) * slot_bytes;
-        const uint16_t* dg = board + (t % 3) * A.rpad;
-        for (unsigned g = wave - nlive; g < nlive; g += nload) {   // 64 rows per piece
-          const uint32_t m = dg[g * 64 + lane];
-          const uint8_t* src = sub + (size_t)(m ? m - 1 : 0) * sizeof(Niels);
-#pragma unroll
-          for (unsigned k = 0; k < 6; k++)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + 16 * k), (lds_ptr_t)(dst + k * chunk_bytes + g * 1024u), 16, 0, 0);
-        }
-        if (++wn == nwin) { wn = 0; jn++; if (jn < ncol) cbase = col_base(jn); }
-      };
-      produce(); produce();            // digits of tiles 0 and 1
-      __syncthreads();
-      if (loader) gather(0);
-      for (size_t t = 0; t < ntile; t++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // entries of tile t are in ring[t & 1]; digits of tile t + 1 are on the board; nobody still reads ring[(t + 1) & 1]
-        if (loader) {
-          if (t + 1 < ntile) gather(t + 1);
-        } else {
-          const unsigned h = (hist >> 2) & 3u;   // produced = t + 2 here: bits 3:2 are tile t's sign and zero flags
-          const bool neg = h & 1u, zero = (h & 2u) != 0;
-          const uint8_t* e = ring + (t & 1) * slot_bytes + tid * 16u;
-          // chunk k of this row's entry at e + k * chunk_bytes; a zero digit adds the neutral entry (same point, other coordinates)
-          const uint8_t* c0 = zero ? ident : e;
-          const unsigned cs = zero ? 16u : chunk_bytes;
-          const unsigned a_off = neg ? 0u : 2u, b_off = neg ? 2u : 0u;  // p - n = p + (-n): -n swaps y+x with y-x and negates 2dxy
-          Fp Am = fp_mul(fp_sub(acc.Y, acc.X), lds_fp2(c0 + a_off * cs, c0 + (a_off + 1) * cs));
-          Fp Bm = fp_mul(fp_add(acc.Y, acc.X), lds_fp2(c0 + b_off * cs, c0 + (b_off + 1) * cs));
-          Fp t2 = lds_fp2(c0 + 4 * cs, c0 + 5 * cs);
-          Fp Cm = fp_mul(acc.T, fp_select(t2, fp_neg(t2), neg));
-          Fp Dd = fp_add(acc.Z, acc.Z);
-          Fp E = fp_sub(Bm, Am), H = fp_add(Bm, Am);
-          Fp F = fp_sub(Dd, Cm), G = fp_add(Dd, Cm);
-          acc = Pt{fp_mul(E, F), fp_mul(G, H), fp_mul(F, G), fp_mul(E, H)};
-          produce();       // the digit of tile t + 2
-        }
-      }
-      __syncthreads();  // the next run's prologue writes the board and the ring
-    }
-    if (live) A.partial[row * A.nb + bk] = acc;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 // rows per workgroup and row-blocks of an LDS-form launch
 static void msm_lds_shape(size_t rows, unsigned* nrb, unsigned* rows_per_wg, unsigned* threads) {
@@ -405,41 +251,4 @@ void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, 
   }
 #endif
   launch(k_msm_lds<0>);
-}
-
-// ---- ring form (wide tables): launch shape = rows per workgroup + loader wavefronts, one workgroup per CU (two ring slots fill the LDS)
-static void msm_ring_shape(size_t rows, unsigned* nrb, unsigned* rows_per_wg, unsigned* rpad, unsigned* threads) {
-  size_t b = (rows + 767) / 768;             // 768 rows: 2 x 72 KB of ring + the digit board in 160 KB of LDS
-  size_t per = (rows + b - 1) / b;
-  size_t rp = (per + 63) / 64 * 64;
-  size_t t = rp;
-  for (int k = 0; k < 4 && t + 64 <= 1024; k++) t += 64;  // one to four loader wavefronts
-  *nrb = (unsigned)b; *rows_per_wg = (unsigned)per; *rpad = (unsigned)rp; *threads = (unsigned)t;
-}
-size_t msm_ring_runs(const sp_gens* g, size_t rows, size_t cols, bool has_blinds, size_t wg_slots) {
-  unsigned nrb, per, rp, thr;
-  msm_ring_shape(rows, &nrb, &per, &rp, &thr);
-  size_t units = (cols + (has_blinds ? 1 : 0)) * (size_t)g->geom.nwin;
-  size_t nb = wg_slots / nrb;
-  if (nb < 1) nb = 1;
-  if (nb > units / 4) nb = units / 4;
-  if (nb < 1) nb = 1;
-  return nb;
-}
-void msm_ring_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                      const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, unsigned grid_limit) {
-  MsmRingArgs A;
-  A.Z = dZ; A.z_row_stride = z_stride; A.rows = rows; A.cols = cols;
-  A.table = g->table; A.g_off = g_off; A.idx = didx; A.blinds = dblinds; A.h_idx = h_idx;
-  A.partial = partial;
-  unsigned thr;
-  msm_ring_shape(rows, &A.nrb, &A.rows_per_wg, &A.rpad, &thr);
-  A.nb = (unsigned)nb; A.n_wg = A.nb * A.nrb;
-  A.wbits = g->geom.wbits; A.nwin = g->geom.nwin; A.tent = g->geom.tent;
-  unsigned grid = A.n_wg;
-  if (grid_limit && grid > grid_limit) grid = grid_limit;
-  size_t lds = 2 * 96 * (size_t)A.rpad + 6 * (size_t)A.rpad + 96;
-  if (lds < 81920) lds = 81920;  // one workgroup per CU
-  (void)hipFuncSetAttribute((const void*)k_msm_ring, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(k_msm_ring, dim3(grid), dim3(thr), (unsigned)lds, st, A);
 }

@@ -14,10 +14,14 @@
 //     conflict-free) and gathers ITS OWN entries with global_load_lds_dwordx4, per-lane source address, D - 1 tiles ahead of the mixed
 //     addition that consumes them. No other wavefront ever reads its slots: there is NO barrier in the loop — a counted s_waitcnt vmcnt
 //     is the only synchronisation — and no register holds an entry in flight;
-//   * the unit of scheduling is an ITEM = (64-row group, run of (column, window) units), a few hundred microseconds of work, pulled
-//     from an atomic head in device memory by whichever wavefront is free. A launch is therefore correct and balanced on ANY number of
-//     workgroups of ANY size: the background launch on a share of the CUs, the foreground launch whose workgroups start as CUs free
-//     up, chunks behind a PCIe copy — all finish within one item of each other (the work-conserving schedule VERDICT r5 asked for);
+//   * the unit of scheduling is an ITEM = (64-row group, run of msm.q_units (column, window) units), ~0.2 ms of work. Every row group has
+//     its own queue of runs (an atomic head in device memory). A wavefront ATTACHES to a group — its home group first — takes a slot of
+//     that group's partial sums, and pulls runs of THAT group into ONE accumulator until the group's queue is empty; only then does it
+//     write its partial sum (one per attachment, not one per item) and look for another group that still has runs (a vector scan of the
+//     heads: work stealing at the tail). A launch is therefore correct and balanced on ANY number of workgroups of ANY size — the
+//     background launch on a share of the CUs, the foreground launch whose workgroups start as CUs free up — it ends within one short
+//     item of the first idle wavefront (the work-conserving schedule VERDICT r5 asked for), and the partial sums stay ~workers / groups
+//     per row however fine the items are (first version: one partial per item — 3 893 per row at 2^22, 8 ms of reduction passes);
 //   * digits come from the same signed recoding as every other form (msm.hpp), produced D - 1 tiles ahead; a zero digit adds the neutral
 //     entry (1, 1, 0) from LDS, so the addition is branch-free; when no lane of the wavefront has anything left in the current scalar
 //     (ballot), the stream jumps to the next column without issuing the remaining gathers (short scalars: SNARK::encode's addresses
@@ -29,52 +33,58 @@
 struct MsmQArgs {
   const Fq* Z; size_t z_row_stride, rows, cols;
   const Niels* table; size_t g_off; const uint32_t* idx; const Fq* blinds; size_t h_idx;
-  Pt* partial;              // [rows][nb]
-  unsigned* head;           // the queue: next item to hand out (zero when the launch starts)
-  unsigned nb, ngroups, n_items;  // runs per row; 64-row groups; nb * ngroups
+  Pt* partial;              // [rows][S]: slot s of a row group belongs to the s-th wavefront that attached to it
+  unsigned* heads;          // [ngroups] next run of each row group (zero when the launch starts)
+  unsigned* nslots;         // [ngroups] attachments so far (may run past S: refused ones count too; the reduction takes min(nslots, S))
+  unsigned nb, ngroups, len, S;  // runs per row; 64-row groups; units per run; partial-sum slots per row
   int wbits, nwin, tent;
 };
 
 typedef __attribute__((address_space(3))) void* q_lds_ptr_t;
 
-constexpr unsigned MSMQ_SLOT = 6 * 1024;  // one tile of one wavefront: [6 chunks][64 lanes] x 16 B
+constexpr unsigned MSMQ_SLOT = 6 * 1024;  // one tile of one wavefront: 64 entries of 96 bytes, row-major
 
-__device__ __forceinline__ Fp q_lds_fp2(const uint8_t* lo, const uint8_t* hi) {  // 32 bytes out of two 16-byte chunks
-  uint4 a = *reinterpret_cast<const uint4*>(lo), b = *reinterpret_cast<const uint4*>(hi);
+__device__ __forceinline__ Fp q_lds_fp(const uint8_t* p) {  // 32 bytes of an entry out of LDS (two ds_read_b128)
+  uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 16);
   return Fp{{(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32), (uint64_t)b.z | ((uint64_t)b.w << 32)}};
 }
-// One tile of one wavefront: six 16-byte LDS-DMA gathers, lane l's 96 bytes from its own source address to chunk k at
-// lds_dst + k * 1024 + l * 16. The LDS side of an LDS-DMA is M0 + instruction offset + lane * 16 — the instruction's immediate offset moves
-// BOTH addresses — so M0 advances by 1024 - 16 per chunk while the offset advances the source by 16. Issued in INLINE ASSEMBLY on purpose: for a
-// __builtin_amdgcn_global_load_lds the compiler knows of a pending write to LDS and puts `s_waitcnt vmcnt(0)` in front of the next ds_read
-// of the kernel's LDS array — every gather would be waited for by the addition issued right behind it, the ring would be one tile deep
-// whatever D says (first build of this kernel: `.s` inspected). What the compiler does not see it does not wait for; the waits are counted
-// by hand (q_wait_tiles). M0 is compiler-reserved and not preserved around a statement: saved and restored inside it.
-__device__ __forceinline__ void q_gather_tile(const uint8_t* src, unsigned lds_dst /* wave-uniform LDS byte address */) {
+// One tile of one wavefront: six LDS-DMA instructions bring the 64 lanes' table entries (96 bytes each) into a 6 KB slot. The LDS side of an
+// LDS-DMA is fixed — M0 + lane * 16 — but the SOURCE address is per lane, so the wavefront fetches TRANSPOSED: lane l of instruction i
+// brings piece (64 i + l) % 6 of the entry of row (64 i + l) / 6. Six consecutive lanes then read the six consecutive 16-byte pieces of ONE
+// entry — one 128-byte line, coalesced by the texture addresser into one request — and the slot comes out row-major (row r at r * 96). The
+// first version had every lane fetch its own six pieces (six requests for the same line, 384 per tile instead of ~70): its gathers alone ran
+// at 28-30 G entries/s against an addition side of 24 G/s in the same loop (profiles/r6_queue_diag.txt: the two sides overlapped badly).
+// Issued in INLINE ASSEMBLY on purpose: for a __builtin_amdgcn_global_load_lds the compiler knows of a pending write to LDS and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of the kernel's LDS array — every gather would be waited for by the addition issued right
+// behind it, the ring would be one tile deep whatever D says (first build of this kernel: `.s` inspected). What the compiler does not see it
+// does not wait for; the waits are counted by hand (q_wait_tiles). M0 is compiler-reserved and not preserved around a statement: saved and
+// restored inside it.
+__device__ __forceinline__ void q_gather_tile(const uint8_t* a0, const uint8_t* a1, const uint8_t* a2, const uint8_t* a3, const uint8_t* a4,
+                                              const uint8_t* a5, unsigned lds_dst /* wave-uniform LDS byte address */) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+      "s_mov_b32 m0, %7\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off\n\t"
-      "s_add_u32 m0, m0, 0x3f0\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off offset:16\n\t"
-      "s_add_u32 m0, m0, 0x3f0\n\t"
+      "global_load_lds_dwordx4 %2, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off offset:32\n\t"
-      "s_add_u32 m0, m0, 0x3f0\n\t"
+      "global_load_lds_dwordx4 %3, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off offset:48\n\t"
-      "s_add_u32 m0, m0, 0x3f0\n\t"
+      "global_load_lds_dwordx4 %4, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off offset:64\n\t"
-      "s_add_u32 m0, m0, 0x3f0\n\t"
+      "global_load_lds_dwordx4 %5, off\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off offset:80\n\t"
+      "global_load_lds_dwordx4 %6, off\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(src), "s"(lds_dst)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "s"(lds_dst)
       : "memory", "scc");
 }
 // At most `tiles` of this wavefront's tiles (6 LDS-DMA instructions each) may still be in flight. VMEM loads of a wavefront complete in
@@ -89,10 +99,27 @@ __device__ __forceinline__ void q_wait_tiles(int tiles) {
   }
 }
 
-template <int D>  // ring depth: D - 1 tiles of gathers in flight per wavefront (LDS: D x 6 KB per wavefront)
-__global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
+// D: ring depth, D - 1 tiles of gathers in flight per wavefront (LDS: D x 6 KB per wavefront).
+// FENCE (the background launch): the wavefronts claim the SIMD's whole register file between them — 168 VGPRs each at 3 per SIMD, 256 at 2 —
+// although the code needs ~120. A CU that runs a background workgroup then has no room for a wavefront of any other kernel, and the launch
+// on bg.eighths/8 of the CUs is the partition a CU mask would give (not honoured on this platform). Without it the main stream's latency
+// kernels are dispatched onto the background CUs as well and lose every issue arbitration against three older, ALU-saturating wavefronts
+// per SIMD: measured, second sum-check 1.2 -> 4.1 ms at 2^20, 2.9 -> 9.4 ms at 2^22 (profiles/r6_ab_queue_form.txt).
+// SP_Q_DIAG (timing experiments of `make variant NAME=qdiagN FLAGS=-DSP_Q_DIAG=N` only; WRONG RESULTS unless 0): bit 0 no gathers (every
+// addition takes the neutral entry), bit 1 no additions (the gathers and their waits alone), bit 2 gathers issued but not waited for (the
+// additions read whatever the slot holds: the cost of ISSUING the gathers without their latency) — what each side of a tile costs in this loop
+#ifndef SP_Q_DIAG
+#define SP_Q_DIAG 0
+#endif
+template <int D, int FENCE>
+__global__ void __launch_bounds__(FENCE == 256 ? 512 : 768) k_msm_q(MsmQArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t q_lds[];
+  if (FENCE == 168) asm volatile("v_mov_b32 v167, 0" ::: "v167");
+  if (FENCE == 256) asm volatile("v_mov_b32 v255, 0" ::: "v255");
   const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+#if SP_Q_DIAG & 8   // bit 3: the shader clock this kernel runs at (shader cycles over the 100 MHz wall clock), printed by one wavefront
+  const unsigned long long dg_c0 = clock64(), dg_w0 = wall_clock64();
+#endif
   uint8_t* const ring = q_lds + wave * (D * MSMQ_SLOT);
   // the ring's LDS byte address, provably wave-uniform for the "s" operand of the gather statement
   const unsigned ring_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(q_lds_ptr_t)ring);
@@ -103,22 +130,44 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
     reinterpret_cast<uint4*>(ident)[tid] = v;
   }
   __syncthreads();  // the only barrier of the kernel
+  // the transposed fetch: which row's entry, and which 16-byte piece of it, this lane brings in gather instruction i
+  int sel[6];        // byte address of the source lane for ds_bpermute
+  unsigned poff[6];  // byte offset of the piece inside the entry
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const unsigned t = 64u * i + lane;
+    sel[i] = (int)((t / 6u) * 4u);
+    poff[i] = (t % 6u) * 16u;
+  }
   const int nwin = A.nwin, c = A.wbits;
   const size_t ncol = A.cols + (A.blinds ? 1 : 0);
   const size_t U = ncol * (size_t)nwin;
   const uint32_t mask = (1u << c) - 1;
   const size_t sub_bytes = (size_t)A.tent * sizeof(Niels);
-  for (;;) {
-    unsigned item = 0;
-    if (lane == 0) item = atomicAdd(A.head, 1u);
-    item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
-    if (item >= A.n_items) break;
-    // consecutive items are the same run of neighbouring row groups: wavefronts that start together walk the same sub-tables
-    const unsigned grp = item % A.ngroups, bk = item / A.ngroups;
+  // this wavefront's walk over the row groups: position 0 is its home group (wavefronts are dealt to the groups round-robin), positions only
+  // ever advance — a group it has left is exhausted, a group that had no slot for it is left to the wavefronts attached there
+  const unsigned home = (blockIdx.x * nwaves + wave) % A.ngroups;
+  for (unsigned pos = 0; pos < A.ngroups;) {
+    {  // the next position whose group still has runs (lanes look at 64 heads at a time)
+      unsigned found = A.ngroups;
+      for (unsigned base = pos; base < A.ngroups && found == A.ngroups; base += 64) {
+        const unsigned q = base + lane;
+        unsigned h = A.nb;
+        if (q < A.ngroups) h = __hip_atomic_load(A.heads + (home + q) % A.ngroups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ok = __ballot(h < A.nb);
+        if (ok) found = base + (unsigned)__builtin_ctzll(ok);
+      }
+      pos = found;
+      if (pos >= A.ngroups) break;
+    }
+    const unsigned grp = (home + pos) % A.ngroups;
+    pos++;
+    unsigned slot = 0;
+    if (lane == 0) slot = atomicAdd(A.nslots + grp, 1u);
+    slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+    if (slot >= A.S) continue;  // every slot of this group is taken (by wavefronts that will finish it)
     const size_t row = (size_t)grp * 64 + lane;
     const bool live = row < A.rows;
-    size_t u = U * bk / A.nb;
-    const size_t u1 = U * (bk + 1) / A.nb;
     auto ld_scalar = [&](size_t jj) {  // Montgomery form of column jj of this lane's row (the blind is column `cols`)
       if (!live) return fq_zero();
       return ld_fq(jj < A.cols ? A.Z + row * A.z_row_stride + jj : A.blinds + row);
@@ -128,24 +177,30 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
       return reinterpret_cast<const uint8_t*>(A.table + pt * (size_t)nwin * (size_t)A.tent);
     };
     Pt acc = pt_identity();
-    if (u1 > u) {
+    for (;;) {
+      unsigned bk = 0;
+      if (lane == 0) bk = atomicAdd(A.heads + grp, 1u);
+      bk = (unsigned)__builtin_amdgcn_readfirstlane((int)bk);
+      if (bk >= A.nb) break;
+      const size_t u = (size_t)bk * A.len;
+      size_t u1 = u + A.len;
+      if (u1 > U) u1 = U;
       // ---- the ring: tiles issued and not yet consumed, oldest first; flags of tile (issued - 1 - k) in bits 2k+1:2k of hist
       unsigned hist = 0, slot_w = 0, slot_r = 0;
       int inflight = 0;
       auto consume = [&]() {  // the mixed addition of the oldest tile in flight
         const int p = inflight - 1;       // tiles issued after it
-        q_wait_tiles(p);
+        if (!(SP_Q_DIAG & 5)) q_wait_tiles(p);  // (bit 2: gathers issued, never waited for)
         const unsigned fl = (hist >> (2 * p)) & 3u;
-        const bool neg = fl & 1u, zero = (fl & 2u) != 0;
-        // chunk k of this lane's entry at e + k * 1024; a zero digit adds the neutral entry (the same point in other coordinates, so the
-        // canonical bytes of the sum do not change — and the addition runs outside any divergent branch)
-        const uint8_t* e = ring + slot_r * MSMQ_SLOT + lane * 16u;
-        const uint8_t* c0 = zero ? ident : e;
-        const unsigned cs = zero ? 16u : 1024u;
-        const unsigned a_off = neg ? 0u : 2u, b_off = neg ? 2u : 0u;  // p - n = p + (-n): -n swaps y+x with y-x and negates 2dxy
-        Fp Am = fp_mul(fp_sub(acc.Y, acc.X), q_lds_fp2(c0 + a_off * cs, c0 + (a_off + 1) * cs));
-        Fp Bm = fp_mul(fp_add(acc.Y, acc.X), q_lds_fp2(c0 + b_off * cs, c0 + (b_off + 1) * cs));
-        Fp t2 = q_lds_fp2(c0 + 4 * cs, c0 + 5 * cs);
+        const bool neg = fl & 1u, zero = (SP_Q_DIAG & 1) ? true : (fl & 2u) != 0;
+        if (SP_Q_DIAG & 2) { acc.X.v[0] ^= fl; slot_r = slot_r + 1 == (unsigned)D ? 0 : slot_r + 1; inflight--; return; }
+        // this lane's entry (y+x, y-x, 2dxy) at lane * 96 of the slot; a zero digit adds the neutral entry (the same point in other
+        // coordinates, so the canonical bytes of the sum do not change — and the addition runs outside any divergent branch)
+        const uint8_t* c0 = zero ? ident : ring + slot_r * MSMQ_SLOT + lane * 96u;
+        const unsigned a_off = neg ? 0u : 32u, b_off = neg ? 32u : 0u;  // p - n = p + (-n): -n swaps y+x with y-x and negates 2dxy
+        Fp Am = fp_mul(fp_sub(acc.Y, acc.X), q_lds_fp(c0 + a_off));
+        Fp Bm = fp_mul(fp_add(acc.Y, acc.X), q_lds_fp(c0 + b_off));
+        Fp t2 = q_lds_fp(c0 + 64);
         Fp Cm = fp_mul(acc.T, fp_select(t2, fp_neg(t2), neg));
         Fp Dd = fp_add(acc.Z, acc.Z);
         Fp E = fp_sub(Bm, Am), H = fp_add(Bm, Am);
@@ -188,7 +243,15 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
           d -= carry << c;
           const uint32_t m = (uint32_t)(d < 0 ? -d : d);
           shift();
-          q_gather_tile(cbase + (size_t)w * sub_bytes + (size_t)(m ? m - 1 : 0) * sizeof(Niels), ring_lds + slot_w * MSMQ_SLOT);
+          if (!(SP_Q_DIAG & 1)) {
+            const uint8_t* sub = cbase + (size_t)w * sub_bytes;  // the tile's (generator, window) sub-table (wave-uniform)
+            const int eidx = (int)(m ? m - 1 : 0);               // this lane's entry in it
+            const uint8_t* a[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+              a[i] = sub + (((size_t)(unsigned)__builtin_amdgcn_ds_bpermute(sel[i], eidx)) << 7) + poff[i];
+            q_gather_tile(a[0], a[1], a[2], a[3], a[4], a[5], ring_lds + slot_w * MSMQ_SLOT);
+          }
           slot_w = slot_w + 1 == (unsigned)D ? 0 : slot_w + 1;
           hist = (hist << 2) | (d < 0 ? 1u : 0u) | (m == 0 ? 2u : 0u);
           inflight++;
@@ -197,54 +260,80 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
       }
       while (inflight) consume();
     }
-    if (live) A.partial[row * A.nb + bk] = acc;
+    if (live) A.partial[row * A.S + slot] = acc;  // (the neutral element if another wavefront took the group's last run first)
   }
+#if SP_Q_DIAG & 8
+  if (blockIdx.x == 7 && tid == 0) {
+    const unsigned long long c = clock64() - dg_c0, w = wall_clock64() - dg_w0;
+    printf("k_msm_q clock: %llu shader cycles in %.1f us -> %.0f MHz\n", c, w * 0.01, c / (w * 0.01));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 // wavefronts per workgroup (4 / 8 / 12 = 1 / 2 / 3 per SIMD) and ring depth of a launch: 12 x 2 x 6 KB or 8 x 3 x 6 KB = 144 KB of the CU's
 // 160 KB, so a CU holds exactly one workgroup and a launch of n workgroups occupies n CUs — the partition a CU mask would give
-static void msm_q_shape(const sp_ctx* c, bool background, unsigned* waves, unsigned* depth) {
-  unsigned wv = (unsigned)c->opt.v[background ? OPT_MSM_Q_BG_WAVES : OPT_MSM_Q_WAVES], d = (unsigned)c->opt.v[OPT_MSM_Q_DEPTH];
+// role of a launch (MsmQRole, internal.hpp): ALONE — the chip to itself: msm.q_waves wavefronts per workgroup on every CU; SHARE — the
+// background launch on bg.eighths/8 of the CUs behind the register fence; CORESIDENT — msm.q_bg_waves wavefronts (8: two per SIMD, 96 KB of
+// LDS) on EVERY CU, leaving each CU half of its registers and 64 KB of LDS for the main stream's latency kernels, which outrank the MSM's
+// wavefronts in the issue arbitration (SP_FG_PRIO, internal.hpp) — no CU is held in reserve for them
+static void msm_q_shape(const sp_ctx* c, int role, unsigned* waves, unsigned* depth, size_t* wgs) {
+  unsigned wv = (unsigned)c->opt.v[role != MSMQ_ALONE ? OPT_MSM_Q_BG_WAVES : OPT_MSM_Q_WAVES], d = (unsigned)c->opt.v[OPT_MSM_Q_DEPTH];
+  *wgs = role == MSMQ_SHARE && c->bg_blocks > 0 ? (size_t)c->bg_blocks : (size_t)c->n_cus;
   if (wv * d * MSMQ_SLOT + 96 > 160 * 1024) d = 2;
   *waves = wv; *depth = d;
 }
-// runs per row: items of about msm.q_units units, at least two items per resident wavefront when the launch is large enough for that
-size_t msm_q_runs(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, bool background) {
+// The cut of a launch: runs of msm.q_units (column, window) units per row group, and S partial-sum slots per row — one for each wavefront that
+// can attach to a group: its share of the launch's resident wavefronts plus 64 for the ones that come stealing at the tail.
+MsmQRuns msm_q_cut(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, int role) {
   unsigned waves, depth;
-  msm_q_shape(c, background, &waves, &depth);
-  const size_t wgs = background && c->bg_blocks > 0 ? (size_t)c->bg_blocks : (size_t)c->n_cus;
+  size_t wgs;
+  msm_q_shape(c, role, &waves, &depth, &wgs);
   const size_t workers = wgs * waves, ngroups = (rows + 63) / 64;
   const size_t units = (cols + (has_blinds ? 1 : 0)) * (size_t)g->geom.nwin;
-  size_t nb = units / (size_t)c->opt.v[OPT_MSM_Q_UNITS];
-  const size_t fill = (2 * workers + ngroups - 1) / ngroups;
-  if (nb < fill) nb = fill;
-  if (nb > units / 4) nb = units / 4;  // at least four additions per item
-  if (nb < 1) nb = 1;
-  return nb;
+  size_t len = (size_t)c->opt.v[OPT_MSM_Q_UNITS];
+  const size_t share = (workers + ngroups - 1) / ngroups;  // wavefronts whose home is one group
+  if (len * share > units) len = (units + share - 1) / share;  // a small launch: at least one run per resident wavefront
+  if (len < 4) len = 4;
+  MsmQRuns r;
+  r.len = (unsigned)len;
+  r.nb = (unsigned)((units + len - 1) / len);
+  r.S = (unsigned)(share + 64);
+  if (r.S > workers) r.S = (unsigned)workers;
+  return r;
 }
 void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
-                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, size_t nb, bool background) {
+                   const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, const MsmQRuns& r, int role,
+                   const unsigned** counts_out) {
   MsmQArgs A;
   A.Z = dZ; A.z_row_stride = z_stride; A.rows = rows; A.cols = cols;
   A.table = g->table; A.g_off = g_off; A.idx = didx; A.blinds = dblinds; A.h_idx = h_idx;
   A.partial = partial;
-  A.nb = (unsigned)nb; A.ngroups = (unsigned)((rows + 63) / 64); A.n_items = A.nb * A.ngroups;
+  A.nb = r.nb; A.len = r.len; A.S = r.S;
+  A.ngroups = (unsigned)((rows + 63) / 64);
   A.wbits = g->geom.wbits; A.nwin = g->geom.nwin; A.tent = g->geom.tent;
-  // the queue head: one of a ring of device words owned by the launching context, zeroed in stream order in front of the launch
-  A.head = c->q_heads + 16 * (c->q_next++ % 64);
-  (void)hipMemsetAsync(A.head, 0, 4, st);
+  // the queues: one of a ring of counter blocks owned by the launching context (heads, then attachment counts), zeroed in stream order in
+  // front of the launch; *counts_out tells the reduction how many slots of each group hold a sum
+  A.heads = c->q_heads + (size_t)MSMQ_BLOCK_WORDS * (c->q_next++ % MSMQ_BLOCKS);
+  A.nslots = A.heads + MSMQ_MAX_GROUPS;
+  (void)hipMemsetAsync(A.heads, 0, 4 * (size_t)MSMQ_BLOCK_WORDS, st);
+  *counts_out = A.nslots;
   unsigned waves, depth;
-  msm_q_shape(c, background, &waves, &depth);
-  size_t wgs = background && c->bg_blocks > 0 ? (size_t)c->bg_blocks : (size_t)c->n_cus;
-  const size_t need = ((size_t)A.n_items + waves - 1) / waves;  // no more workgroups than there are items for
+  size_t wgs;
+  msm_q_shape(c, role, &waves, &depth, &wgs);
+  const size_t need = ((size_t)A.nb * A.ngroups + waves - 1) / waves;  // no more workgroups than there are items for
   if (wgs > need) wgs = need;
   size_t lds = (size_t)waves * depth * MSMQ_SLOT + 96;
-  if (lds < 81920 + 96) lds = 81920 + 96;  // more than half of a CU's LDS: one workgroup per CU whatever its size
+  if (lds < 81920 + 96) lds = 81920 + 96;  // more than half of a CU's LDS: one MSM workgroup per CU whatever its size
   auto launch = [&](auto kern) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), (unsigned)lds, st, A);
   };
-  if (depth >= 3) launch(k_msm_q<3>);
-  else launch(k_msm_q<2>);
+  // the register fence of the background launch: 3 wavefronts per SIMD x 168 or 2 x 256 VGPRs (4 / 8 wavefronts get the 256 form: the rest of
+  // the file then holds at most one more wavefront of their size, and the LDS claim keeps a second workgroup off the CU)
+  const bool fence = role == MSMQ_SHARE && c->bg_blocks > 0 && c->bg_blocks < c->n_cus;
+  if (!fence) { if (depth >= 3) launch(k_msm_q<3, 0>); else launch(k_msm_q<2, 0>); }
+  else if (waves == 12) launch(k_msm_q<2, 168>);
+  else if (depth >= 3) launch(k_msm_q<3, 256>);
+  else launch(k_msm_q<2, 256>);
 }

@@ -16,7 +16,7 @@
 // X(id, key, default, min, max, tier, doc)
 #define SP_OPTION_TABLE(X)                                                                                                                  \
   X(TESTING_UNLOCK, "testing.unlock", 0, 0, 1, 0, "1: accept tier-1 (A/B / test) options on this context")                                   \
-  X(MSM_FORM, "msm.form", 0, 0, 4, 0, "row MSM of many rows: 0 = per generator set (gathered wide-window tables; LDS-staged when the set's wide tables came out <= 10 bits), 3 = gathered always, 1 = LDS-staged small windows (needs msm.lds_bits at set creation), 2 = wide-window tables with loader wavefronts gathering each row's entry into an LDS ring, 4 = queue form: self-contained wavefronts with private LDS rings pulling items from a device-side queue") \
+  X(MSM_FORM, "msm.form", 0, 0, 3, 0, "row MSM of many rows: 0 = per launch and generator set (the queue form over the wide-window tables for commits of >= 256 rows; LDS-staged when the set's wide tables came out <= 10 bits; strip / balanced forms for the rest), 1 = LDS-staged small windows (needs msm.lds_bits at set creation), 2 = queue form also for sets that would take the LDS-staged form, 3 = strip / balanced forms always (the default before round 6)") \
   X(MSM_LDS_BITS, "msm.lds_bits", 0, 0, 10, 0, "window width of the LDS-staged form's tables built with a generator set (0 = not built; 10 = 48 KB sub-tables, double-buffered)") \
   X(MSM_WBITS, "msm.wbits", 0, 0, 15, 0, "force the wide tables' window width (4..15); 0 = chosen by the policy below")                       \
   X(MSM_TABLE_GB, "msm.table_gb", 170, 1, 100000, 0, "HBM budget of one generator set's wide tables, GB")                                    \
@@ -41,9 +41,10 @@
   X(MSM_FLAT_BG, "msm.flat_bg", 0, 0, 1, 1, "balanced form for the background launch too")                                                   \
   X(MSM_FLAT_ROUNDS, "msm.flat_rounds", 1, 1, 16, 1, "sets of resident workgroups a balanced launch is cut into")                            \
   X(MSM_Q_WAVES, "msm.q_waves", 12, 4, 12, 1, "queue form: wavefronts per workgroup (4 / 8 / 12 = 1 / 2 / 3 per SIMD; one workgroup per CU)")                      \
-  X(MSM_Q_BG_WAVES, "msm.q_bg_waves", 12, 4, 12, 1, "queue form: wavefronts per workgroup of the background launch")                                 \
+  X(MSM_Q_BG_WAVES, "msm.q_bg_waves", 8, 4, 12, 1, "queue form: wavefronts per workgroup of a launch that shares the chip (the background launch, a foreground launch next to one)")                                 \
+  X(MSM_Q_CORESIDENT, "msm.q_coresident", 1, 0, 1, 1, "queue form: the background launch runs on every CU next to the latency kernels (msm.q_bg_waves wavefronts per CU, no reserved CUs); 0 = on bg.eighths/8 of the CUs behind a register fence") \
   X(MSM_Q_DEPTH, "msm.q_depth", 2, 2, 3, 1, "queue form: ring slots per wavefront (depth - 1 tiles of gathers in flight; 3 only with <= 8 wavefronts)") \
-  X(MSM_Q_UNITS, "msm.q_units", 64, 4, 4096, 1, "queue form: (column, window) units per queue item")                                             \
+  X(MSM_Q_UNITS, "msm.q_units", 32, 4, 4096, 1, "queue form: (column, window) units per queue item")                                             \
   X(MSM_PREFETCH, "msm.prefetch", 2, 1, 2, 1, "table entries in flight in the strip form")                                                   \
   X(MSM_FUSED_TREE, "msm.fused_tree", 1, 0, 1, 1, "single-row commitments in one launch (0: lookups + tree, reduction, flag)")               \
   X(UPLOAD_OVERLAP, "upload.overlap", 1, 0, 1, 1, "witness commit issued in row chunks behind the upload")                                   \

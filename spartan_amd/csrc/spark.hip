@@ -3,14 +3,14 @@
 // All of it is F_q streaming work (no group operations), HBM/ALU-bound.
 #include "internal.hpp"
 
-__global__ void __launch_bounds__(256) k_from_index(const uint32_t* __restrict__ ix, size_t n, Fq* __restrict__ dst) {
+__global__ void __launch_bounds__(256) k_from_index(const uint32_t* __restrict__ ix, size_t n, Fq* __restrict__ dst) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(dst + i, fq_from_u64(ix[i]));
 }
-__global__ void __launch_bounds__(256) k_gather(const Fq* __restrict__ mem, const uint32_t* __restrict__ addr, size_t n, Fq* __restrict__ dst) {
+__global__ void __launch_bounds__(256) k_gather(const Fq* __restrict__ mem, const uint32_t* __restrict__ addr, size_t n, Fq* __restrict__ dst) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(dst + i, ld_fq(mem + addr[i]));
 }
 __global__ void __launch_bounds__(256) k_hash_layer(const Fq* __restrict__ addr, const Fq* __restrict__ val, const Fq* __restrict__ ts, int ts_inc,
-                                                    size_t n, Fq r_hash, Fq r_hash_sqr, Fq r_multiset, Fq* __restrict__ dst) {
+                                                    size_t n, Fq r_hash, Fq r_hash_sqr, Fq r_multiset, Fq* __restrict__ dst) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fq a = addr ? ld_fq(addr + i) : fq_from_u64((uint64_t)i);
     Fq t = ts ? ld_fq(ts + i) : fq_zero();
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_hash_layer(const Fq* __restrict__ addr,
 // one matrix differ by ts + 1 only (sparse_mlpoly.rs:572-598), i.e. by r_hash^2 per leaf: both circuits from one pass over addr, val, ts.
 template <bool PAIR>
 __global__ void __launch_bounds__(256) k_hash_layer_first(const Fq* __restrict__ addr, const Fq* __restrict__ val, const Fq* __restrict__ ts, int ts_inc,
-                                                          size_t n, Fq r_hash, Fq r_hash_sqr, Fq r_multiset, Fq* __restrict__ dst_a, Fq* __restrict__ dst_b) {
+                                                          size_t n, Fq r_hash, Fq r_hash_sqr, Fq r_multiset, Fq* __restrict__ dst_a, Fq* __restrict__ dst_b) { SP_FG_PRIO();
   const size_t half = n / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     Fq h[2];
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_hash_layer_first(const Fq* __restrict__
     }
   }
 }
-__global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, size_t half, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, size_t half, Fq* __restrict__ out) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
     st_fq(out + i, fq_mul(ld_fq(in + i), ld_fq(in + half + i)));
 }
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_prod_layer(const Fq* __restrict__ in, s
 struct Stores16 {
   Fq* p[16];
 };
-__global__ void __launch_bounds__(256) k_prod_layer_many(Stores16 st, size_t off, size_t half, size_t noff) {
+__global__ void __launch_bounds__(256) k_prod_layer_many(Stores16 st, size_t off, size_t half, size_t noff) { SP_FG_PRIO();
   const Fq* in = st.p[blockIdx.y] + off;
   Fq* out = st.p[blockIdx.y] + noff;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_prod_layer_many(Stores16 st, size_t off
 // TWO layers per launch for the middle of the tree (round 4): the layers between the streaming ones and the one-launch tail are a few
 // microseconds of work behind a launch each. Thread i reads the four entries i, i + q, i + 2q, i + 3q (q = len / 4) of layer k, writes
 // layer k+1 [i] = x0 x2 and [i + q] = x1 x3 (its pairs are (i, i + len/2)), and layer k+2 [i] = their product.
-__global__ void __launch_bounds__(256) k_prod_layer2_many(Stores16 st, size_t off, size_t len) {
+__global__ void __launch_bounds__(256) k_prod_layer2_many(Stores16 st, size_t off, size_t len) { SP_FG_PRIO();
   const size_t q = len / 4, off1 = off + len, off2 = off1 + len / 2;
   Fq* base = st.p[blockIdx.y];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_prod_layer2_many(Stores16 st, size_t of
 // The short layers of the same circuits in ONE launch: from a layer of `len` <= 2048 elements down to the two roots, one
 // workgroup per circuit, each layer kept in LDS for the next (a 2^20-leaf tree has 10 such layers: ten launches of a few
 // microseconds each on the path to the first product_circuits_evaluate).
-__global__ void __launch_bounds__(256) k_prod_layer_tail(Stores16 st, size_t off, size_t len) {
+__global__ void __launch_bounds__(256) k_prod_layer_tail(Stores16 st, size_t off, size_t len) { SP_FG_PRIO();
   __shared__ Fq cur[1024];
   Fq* base = st.p[blockIdx.x];
   size_t half = len / 2, noff = off + len;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void cubic_point(const Fq& a0, const Fq& a1, const Fq
   e[2] = fq_add(e[2], fq_mul(fq_mul(a3, b3), c3));
 }
 // grid (nblk, ninst): partials[(inst*nblk + blk)*3 + {0,1,2}]
-__global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __restrict__ T, TripleInline IN, size_t half, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __restrict__ T, TripleInline IN, size_t half, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_cubic_eval_batched(const Triple* __rest
     st_fq(p, e[0]); st_fq(p + 1, e[1]); st_fq(p + 2, e[2]);
   }
 }
-__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* __restrict__ T, TripleInline IN, size_t quarter, Fq r, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched(const Triple* __restrict__ T, TripleInline IN, size_t quarter, Fq r, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   Fq e[3] = {fq_zero(), fq_zero(), fq_zero()};
@@ -191,7 +191,7 @@ __device__ __forceinline__ void cubic_point4(const Fq& a0, const Fq& a1, const F
 // GEN selects the arithmetic at compile time (one launch for the product-circuit instances, one for the generic ones when there are any):
 // a kernel holding both bodies is allocated for the larger one (205 registers, two waves per SIMD instead of three)
 template <bool GEN>
-__global__ void __launch_bounds__(256) k_cubic_eval_batched_eq(TripleInline IN, unsigned inst0, size_t half, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_eval_batched_eq(TripleInline IN, unsigned inst0, size_t half, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const unsigned inst = inst0 + blockIdx.y;
   Triple t = IN.t[inst];
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_cubic_eval_batched_eq(TripleInline IN, 
   }
 }
 template <bool GEN>
-__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched_eq(TripleInline IN, unsigned inst0, size_t quarter, Fq r, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_batched_eq(TripleInline IN, unsigned inst0, size_t quarter, Fq r, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const unsigned inst = inst0 + blockIdx.y;
   Triple t = IN.t[inst];
@@ -256,13 +256,13 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_batched_eq(TripleInline
   }
 }
 // t[i] *= k for i < n (the hand-over from the factored rounds: the bound eq table the generic kernels continue with)
-__global__ void __launch_bounds__(256) k_scale_prefix(Fq* __restrict__ t, size_t n, Fq k) {
+__global__ void __launch_bounds__(256) k_scale_prefix(Fq* __restrict__ t, size_t n, Fq k) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(t + i, fq_mul(ld_fq(t + i), k));
 }
 // Latency form of the fused round for short tables (quarter <= a few hundred): the ~12 dependent field
 // multiplications of one index are spread over 8 lanes (six do one bind each, then three do one evaluation point
 // each), so a round costs ~3 multiplications of latency instead of 12. Block = 32 indices x 8 roles; grid (nblk, ninst).
-__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, TripleInline IN, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __restrict__ T, TripleInline IN, size_t quarter, Fq r, Fq* __restrict__ partials, DoneSig sig) { SP_FG_PRIO();
   __shared__ Fq bound[32][6];  // [index][table*2 + half]
   __shared__ Fq lv[32][3][3];  // [index][table][t = 0, 2, 3]: the bound pair's line
   __shared__ Fq red[3][32];
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_cubic_bind_eval_tiny(const Triple* __re
 }
 // Latency form of k_cubic_eval_batched (the first round of a layer's sum-check, half <= 8192): four lanes per index, lanes
 // 0..2 evaluate t = 0, 2, 3 with one instruction stream; block = 64 indices; grid (nblk, ninst).
-__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, TripleInline IN, size_t half, Fq* __restrict__ partials, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_cubic_eval_tiny(const Triple* __restrict__ T, TripleInline IN, size_t half, Fq* __restrict__ partials, DoneSig sig) { SP_FG_PRIO();
   __shared__ Fq red[3][64];
   Triple t = T ? T[blockIdx.y] : IN.t[blockIdx.y];
   int li = threadIdx.x >> 2, role = threadIdx.x & 3;
@@ -365,7 +365,7 @@ struct Bind2Inline {
   Fq w[24];
 };
 __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, Bind2Inline IN, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
-                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig) {
+                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig) { SP_FG_PRIO();
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
   __shared__ Fq red[18][8];
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
   SP_KT(kt, 7);
 }
 // partials[ninst][nblk][K] -> out[ninst][K]; one block per instance
-__global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __restrict__ partials, size_t nblk, int K, Fq* __restrict__ out, DoneSig sig) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const Fq* p = partials + (size_t)blockIdx.x * nblk * K;
   for (int k = 0; k < K; k++) {
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials_batched(const Fq* __res
   signal_done(sig);
 }
 // grid (nblk, nt): partials[t*nblk + blk] = partial <chi, T_t>
-__global__ void __launch_bounds__(256) k_dot_many(const Fq* __restrict__ chi, Fq* const* __restrict__ tabs, size_t n, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_dot_many(const Fq* __restrict__ chi, Fq* const* __restrict__ tabs, size_t n, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const Fq* t = tabs[blockIdx.y];
   Fq acc[1] = {fq_zero()};
@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(256) k_dot_many(const Fq* __restrict__ chi, Fq
   if (threadIdx.x == 0) st_fq(partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc[0]);
 }
 __global__ void __launch_bounds__(256) k_dot3(const Fq* __restrict__ l, const Fq* __restrict__ r, const Fq* __restrict__ w, size_t n,
-                                              Fq* __restrict__ partials) {
+                                              Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   Fq acc[1] = {fq_zero()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256) k_dot3(const Fq* __restrict__ l, const Fq
 }
 
 // grid (nblk, nt): partials[t*nblk + blk] = partial sum_i l_t[i] r_t[i] w_t[i]; ptrs = [l_0..l_{nt-1} | r_0.. | w_0..]
-__global__ void __launch_bounds__(256) k_dot3_many(const Fq* const* __restrict__ ptrs, size_t nt, size_t n, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_dot3_many(const Fq* const* __restrict__ ptrs, size_t nt, size_t n, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const Fq *l = ptrs[blockIdx.y], *r = ptrs[nt + blockIdx.y], *w = ptrs[2 * nt + blockIdx.y];
   Fq acc[1] = {fq_zero()};
@@ -869,7 +869,7 @@ int32_t sp_table_scale_prefix(sp_ctx* c, sp_table* t, size_t n, const uint64_t k
 }
 
 // partials[ninst][nblk][18] -> out[ninst][18], one block per instance: thread = (component k < 18 of 32, slice of blocks)
-__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out, DoneSig sig) {
+__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out, DoneSig sig) { SP_FG_PRIO();
   __shared__ Fq sm[8][18];
   const int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const Fq* p = partials + (size_t)blockIdx.x * nblk * 18;

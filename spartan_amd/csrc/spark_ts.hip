@@ -12,11 +12,11 @@
 
 #include "internal.hpp"
 
-__global__ void __launch_bounds__(256) k_ts_iota(uint32_t* __restrict__ pos, size_t n) {
+__global__ void __launch_bounds__(256) k_ts_iota(uint32_t* __restrict__ pos, size_t n) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) pos[i] = (uint32_t)i;
 }
 // start[q] = q where a run of equal keys begins, 0 elsewhere (an inclusive max-scan then carries the run start forward)
-__global__ void __launch_bounds__(256) k_ts_run_heads(const uint32_t* __restrict__ key, size_t n, uint32_t* __restrict__ start) {
+__global__ void __launch_bounds__(256) k_ts_run_heads(const uint32_t* __restrict__ key, size_t n, uint32_t* __restrict__ start) { SP_FG_PRIO();
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x)
     start[q] = (q == 0 || key[q] != key[q - 1]) ? (uint32_t)q : 0u;
 }
@@ -27,14 +27,14 @@ struct TsDst {
 };
 __global__ void __launch_bounds__(256) k_ts_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ pos,
                                                     const uint32_t* __restrict__ start, size_t n, size_t per_list, TsDst dst,
-                                                    Fq* __restrict__ audit) {
+                                                    Fq* __restrict__ audit) { SP_FG_PRIO();
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
     uint32_t rank = (uint32_t)q - start[q], p = pos[q];
     st_fq(dst.p[p / per_list] + p % per_list, fq_from_u64(rank));
     if (q + 1 == n || key[q + 1] != key[q]) st_fq(audit + key[q], fq_from_u64((uint64_t)rank + 1));
   }
 }
-__global__ void __launch_bounds__(256) k_ts_zero(Fq* __restrict__ t, size_t n) {
+__global__ void __launch_bounds__(256) k_ts_zero(Fq* __restrict__ t, size_t n) { SP_FG_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fq(t + i, fq_zero());
 }
 

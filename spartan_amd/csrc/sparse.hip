@@ -19,7 +19,7 @@ struct sp_sparse {
 
 // multiply_vec (sparse_mlpoly.rs:454-464)
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const Fq* __restrict__ val,
-                                              const Fq* __restrict__ z, size_t num_rows, Fq* __restrict__ out) {
+                                              const Fq* __restrict__ z, size_t num_rows, Fq* __restrict__ out) { SP_FG_PRIO();
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= num_rows) return;
   Fq acc = fq_zero();
@@ -34,7 +34,7 @@ struct Csc3 {
   int nm;
 };
 // compute_eval_table_sparse (sparse_mlpoly.rs:466-481) x nm, combined with weights (r1csproof.rs:275-283)
-__global__ void __launch_bounds__(256) k_eval_table(Csc3 M, const Fq* __restrict__ rx, size_t num_cols, Fq* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_eval_table(Csc3 M, const Fq* __restrict__ rx, size_t num_cols, Fq* __restrict__ out) { SP_FG_PRIO();
   size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= num_cols) return;
   Fq tot = fq_zero();
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_eval_table(Csc3 M, const Fq* __restrict
 }
 // evaluate_with_tables (sparse_mlpoly.rs:429-438)
 __global__ void __launch_bounds__(256) k_sparse_eval(const uint32_t* __restrict__ row, const uint32_t* __restrict__ col, const Fq* __restrict__ val,
-                                                     size_t nnz, const Fq* __restrict__ tx, const Fq* __restrict__ ty, Fq* __restrict__ partials) {
+                                                     size_t nnz, const Fq* __restrict__ tx, const Fq* __restrict__ ty, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   Fq acc[1] = {fq_zero()};
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (size_t)gridDim.x * blockDim.x)
@@ -62,7 +62,7 @@ struct SparseMany {
   const Fq* val[4];
   size_t nnz[4];
 };
-__global__ void __launch_bounds__(256) k_sparse_eval_many(SparseMany M, const Fq* __restrict__ tx, const Fq* __restrict__ ty, Fq* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_sparse_eval_many(SparseMany M, const Fq* __restrict__ tx, const Fq* __restrict__ ty, Fq* __restrict__ partials) { SP_FG_PRIO();
   __shared__ Fq sm[256];
   const int m = blockIdx.y;
   const uint32_t* __restrict__ row = M.row[m];
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) k_sparse_eval_many(SparseMany M, const Fq
   block_sum_fq<1>(acc, sm);
   if (threadIdx.x == 0) st_fq(partials + (size_t)m * gridDim.x + blockIdx.x, acc[0]);
 }
-__global__ void __launch_bounds__(256) k_sparse_sums(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out) {  // block per matrix
+__global__ void __launch_bounds__(256) k_sparse_sums(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out) { SP_FG_PRIO();  // block per matrix
   __shared__ Fq sm[256];
   Fq acc[1] = {fq_zero()};
   for (size_t b = threadIdx.x; b < nblk; b += 256) acc[0] = fq_add(acc[0], ld_fq(partials + (size_t)blockIdx.x * nblk + b));

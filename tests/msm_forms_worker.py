@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_kernels.py::test_row_msm_forms_match_oracle: the row MSM's launch form is chosen once per process
-(option msm.flat = 0 strip form / 1 balanced, rolled / 2 balanced, two entries in flight; msm.flat_bg = 1: the balanced background
+(msm.form = 0, the default: the queue form of msm_queue.hip for launches of >= 256 rows; msm.form = 3 with option msm.flat = 0 strip form / 1 balanced, rolled / 2 balanced, two entries in flight; msm.flat_bg = 1: the balanced background
 form; msm.form = 1 with msm.lds_bits = 10: the LDS-staged small-window form — all through SPARTAN_OPTIONS), so every form runs in a process of its own. Shapes that only these plans select, each against the oracle's orc_commit_rows:
 blinds (an extra column that starts or ends a run in the middle of a scalar), rows of zeros, short scalars (the early exit of the strip form
 and the ballot skip of the balanced form: SNARK::encode's addresses and timestamps, src/sparse_mlpoly.rs:483-503), scalars with only high
@@ -63,9 +63,9 @@ check(1024, 48, "mixed", True)           # four row-blocks
 check(2048, 40, "short", False)          # eight row-blocks: strip form in every mode (heterogeneous rows)
 check(768, 128, "uniform", False, background=True)
 check(768, 128, "zero_rows", False, background=True)
-if ctx.get_option("msm.form") >= 1:
-    # the LDS-staged small-window form (msm_lds.hip; msm.form = 1) takes every launch of >= 512 rows, the ring form (loader / consumer
-    # wavefronts over the wide tables; msm.form = 2) every launch of >= 256 rows: row-blocks that are not a multiple of a wavefront,
+if ctx.get_option("msm.form") != 3:
+    # the LDS-staged small-window form (msm_lds.hip; msm.form = 1) takes every launch of >= 512 rows, the queue form (msm_queue.hip: the
+    # default, msm.form = 0) every launch of >= 256 rows: row-blocks that are not a multiple of a wavefront,
     # two and three row-blocks, runs that start inside a scalar, the blind as the last column, every scalar kind, the persistent background form
     for kind in ("uniform", "short", "zero_rows", "high", "carry", "mixed"):
         check(576, 40, kind, True)
@@ -75,12 +75,12 @@ if ctx.get_option("msm.form") >= 1:
     check(2112, 10, "uniform", True)
     check(768, 128, "mixed", False, background=True)
     check(1536, 300, "uniform", False, background=True)
-if ctx.get_option("msm.form") == 4:
-    # the queue form (msm_queue.hip) takes every launch that is not lookup-sized: a last row group that is not a whole wavefront, fewer
-    # rows than a wavefront, items of four units (runs that start and end inside every scalar), whole wavefronts of zero rows in the background
-    check(100, 400, "mixed", True)
-    check(40, 900, "carry", False)
-    check(200, 300, "short", True)
+if ctx.get_option("msm.form") in (0, 2):
+    # the queue form: a last row group that is not a whole wavefront, the smallest launch it takes, items of four units (runs that start
+    # and end inside every scalar: msm.q_units = 4 in one of the settings), whole wavefronts of zero rows in the background
+    check(300, 200, "mixed", True)
+    check(256, 900, "carry", False)
+    check(420, 300, "short", True)
     check(832, 96, "zero_rows", False, background=True)
 print("MSM_FORMS_OK %d" % checked)
 ctx.close()

@@ -503,7 +503,8 @@ def test_every_ab_switch_gives_the_same_proof(orc):
                 {"sumcheck.double_round_max_len": 0, "sumcheck.host_tail": 0}, {"sumcheck.double_round_max_len": 512},
                 {"spark.prod_layer2": 0}, {"spark.prod_layer2_max_log2": 14}, {"upload.overlap": 0, "upload.thread": 0}, {"upload.chunks": 2},
                 {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"overlap.col_half": 1, "bg.eighths": 4}, {"bg.eighths": 0},
-                {"msm.flat": 0, "msm.prefetch": 1}, {"msm.flat": 1, "msm.flat_bg": 1, "msm.flat_rounds": 2}, {"msm.strip_threads": 131072, "msm.flat": 0},
+                {"msm.form": 3}, {"msm.form": 3, "msm.flat": 0, "msm.prefetch": 1}, {"msm.form": 3, "msm.flat": 1, "msm.flat_bg": 1, "msm.flat_rounds": 2}, {"msm.form": 3, "msm.strip_threads": 131072, "msm.flat": 0},
+                {"msm.q_coresident": 0, "msm.q_waves": 8, "msm.q_depth": 3, "msm.q_bg_waves": 12, "msm.q_units": 16}, {"msm.q_bg_waves": 4, "msm.q_units": 128, "bg.eighths": 0},
                 {"msm.lds_bits": 10, "msm.form": 1}, {"msm.lds_bits": 9, "msm.form": 1, "overlap.derefs": 0}, {"msm.wbits": 11}]
     covered = {k for st in settings for k in st}
     not_proof_shaping = {"ipa.rerun_exceptional", "ipa.dedicated_uploaded", "shard.residue_transport", "shard.cubic_min_len", "host.callstats", "debug.ktime"}  # their own tests (test_gpu_large, test_gpu_shard) / diagnostics
