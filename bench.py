@@ -175,6 +175,32 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
+def config_key(get_option, options_table, log2_cons):
+    """identifies the configuration a PMC traffic entry belongs to: kernel sources + instance size + every library option that is not at
+    its default (diagnostic switches excluded). profiles/pmc_traffic.json is keyed by it; a run whose key has no entry reports traffic null."""
+    skip = {"testing.unlock", "host.callstats", "debug.ktime"}
+    nd = sorted("%s=%d" % (k, get_option(k)) for k, d, _lo, _hi, _t, _doc in options_table() if k not in skip and get_option(k) != d)
+    return "%s|2^%d|%s" % (kernel_source_digest(), log2_cons, ",".join(nd) or "defaults")
+
+
+def union_ms(spans):
+    """measure of the union of [t0, t1) intervals"""
+    tot, end = 0.0, None
+    for t0, t1 in sorted(spans):
+        if end is None or t0 > end:
+            tot += t1 - t0; end = t1
+        elif t1 > end:
+            tot += t1 - end; end = t1
+    return tot
+
+
+def read_spans_raw(capi, raw, family, cap=4096):
+    """[(rows, cols, background, t0_ms, t1_ms, issued mixed additions)] of the family's launches since the last sp_prof_reset"""
+    sh = (ctypes.c_uint64 * cap)(); t0 = (ctypes.c_double * cap)(); t1 = (ctypes.c_double * cap)(); iss = (ctypes.c_double * cap)()
+    k = capi.lib.sp_prof_read_spans(raw, family.encode(), sh, t0, t1, iss, ctypes.c_int(cap))
+    return [((int(sh[i]) >> 32) & 0x7fffffff, int(sh[i]) & 0xffffffff, bool(int(sh[i]) >> 63), t0[i], t1[i], iss[i]) for i in range(max(0, min(k, cap)))]
+
+
 def concurrent_throughput(P, device, s, K, steps):
     """K independent SNARK::prove streams on ONE GPU (own context + host thread each; generator tables are shared). A
     single proof is a chain of latency-bound launches, so a second and a third proof fill the gaps of the first. Measured at 2^20
@@ -233,6 +259,28 @@ def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
         e = P.SNARK.encode(ctx, inst, gens); e.free()
     dt = (time.perf_counter() - t0) / 2
     out["snark_encode"] = {"ms": dt * 1e3, "note": "SNARK::encode: dense representation from the entry-order copies on the device, AddrTimestamps::new + two multi_commits on the device"}
+    # BASELINE config 5's report: the sparse_mlpoly commit path (SparseMatPolynomial::multi_commit, sparse_mlpoly.rs:483-503 — comb_ops and
+    # comb_mem: addresses, timestamps and values, most of them a few bits long) against the HBM roofline, from one instrumented encode
+    from spartan_amd import capi
+    raw = ctx.raw()
+    capi.lib.sp_prof_reset(raw); capi.lib.sp_prof_select(raw, b"msm_rows_fixed"); capi.lib.sp_prof_enable(raw, ctypes.c_int(1))
+    e = P.SNARK.encode(ctx, inst, gens); e.free()
+    capi.lib.sp_prof_enable(raw, ctypes.c_int(0))
+    sp_ = read_spans_raw(capi, raw, "msm_rows_fixed")
+    capi.lib.sp_prof_select(raw, None); capi.lib.sp_prof_reset(raw)
+    if sp_:
+        busy = union_ms([(a, b) for _r, _c, _bg, a, b, _i in sp_])
+        scal = sum(r * c for r, c, _bg, _a, _b, _i in sp_); rows = sum(r for r, _c, _bg, _a, _b, _i in sp_)
+        issued = sum(i for *_x, i in sp_)
+        nwin = -(-254 // gens.window_bits(1))
+        byts = 32.0 * scal + 32.0 * rows
+        out["snark_encode"]["roofline"] = {
+            "bound": "hbm", "kernel": "msm_rows_fixed (multi_commit of comb_ops and comb_mem)", "launches": [f"{r} x {c}" for r, c, *_x in sp_],
+            "committed_scalars": scal, "alg_bytes": byts, "busy_ms": round(busy, 4), "achieved": round(byts / busy / 1e6, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(byts / busy / 1e6 / HBM_PEAK_GBS, 6),
+            "additions_per_scalar_issued": round(issued / scal, 3) if issued else None, "additions_per_scalar_full_size": nwin,
+            "G_additions_issued_per_s": round(issued / busy / 1e6, 2) if issued else None,
+            "note": "32 B per committed scalar + 32 B per row (SURVEY 8d) over the union of the launches' intervals; addresses and timestamps are a few bits long, so the wavefronts leave a scalar after its first windows: additions_per_scalar_issued counts the mixed additions really performed (64 per issued tile)"}
     return out
 
 
@@ -386,6 +434,13 @@ def main():
         return [{"rows": (int(sh[i]) >> 32) & 0x7fffffff, "cols": int(sh[i]) & 0xffffffff, "background": bool(int(sh[i]) >> 63), "ms": ms[i],
                  "launches": int(nl[i]), "alg_bytes": by[i]} for i in range(min(k, cap))]
 
+    def read_spans(family):
+        cap = 4096
+        return read_spans_raw(capi, raw, family, cap)
+
+    def opt(key):
+        v = ctypes.c_int64(0); capi.lib.sp_ctx_get_option(raw, key.encode(), ctypes.byref(v)); return v.value
+
     proof = None
     raw = ctx.raw()
     ceil = measured_ceilings() if rank == 0 else None
@@ -448,6 +503,7 @@ def main():
     strong = None
     fam = read_prof() or {dom: breakdown[dom]}
     shapes = read_shapes(dom) if dom == "msm_rows_fixed" else []
+    spans = read_spans(dom) if dom == "msm_rows_fixed" else []
     capi.lib.sp_prof_select(raw, None)
 
     # dominant kernel (HIP events recorded inside the timed region) -> roofline
@@ -463,11 +519,12 @@ def main():
             per_proof = 32.0 * ((1 << s) + (1 << (s + 3))) + 32.0 * ((1 << (s // 2)) + (1 << ((s + 3) // 2)))
             alg_per_launch = per_proof / (f["launches"] / args.steps)
         ach = alg_per_launch / (avg_ms * 1e-3) / 1e9
-        pmc, pmc_note = None, "no PMC file for these kernel sources and this instance size: collect with profiles/collect_r3.sh + profiles/pmc_summarize.py"
+        key = config_key(opt, capi.options_table, s)
+        pmc, pmc_note = None, "no PMC entry for this configuration (kernel sources | size | non-default options = %s): collect with profiles/collect_r6.sh" % key
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj.get("kernel_source_digest") == kernel_source_digest() and pj.get("log2_cons", 20) == s and dom in pj:
-                pmc, pmc_note = pj[dom], "HBM bytes per launch from rocprofv3 --pmc (separate passes), same kernel sources: profiles/" + pj.get("source", "pmc_traffic.json")
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("entries", {}).get(key)
+            if pj and dom in pj:
+                pmc, pmc_note = pj[dom], "HBM bytes per launch from rocprofv3 --pmc (separate passes) for exactly this configuration (%s): profiles/%s" % (key, pj.get("source", "pmc_traffic.json"))
         except (OSError, ValueError):
             pass
         launched_per_launch = f["alg_bytes"] / f["launches"]   # the library's own count: 32 B per scalar of the rows it launched (the zero padding rows of `derefs` are not)
@@ -505,9 +562,13 @@ def main():
             madds = nm[1] * nwin
             e = {"shape": f'{sh["rows"]} x {sh["cols"]}', "what": nm[0], "launch_ms": round(lms, 4), "window_bits": wb_eval if nm[2] else wb_sat, "mixed_additions": madds,
                  "achieved_G_per_s": round(madds / lms / 1e6, 2)}
-            if sh["background"]:   # the persistent background MSM holds bg.eighths/8 of the CUs (one workgroup each; option of the context)
-                bg8 = ctypes.c_int64(5); capi.lib.sp_ctx_get_option(raw, b"bg.eighths", ctypes.byref(bg8))
-                e["cu_share"] = bg8.value / 8
+            if sh["background"]:
+                # queue form, co-resident (the default since round 6): the background launch runs on EVERY CU next to the latency kernels;
+                # otherwise the persistent background MSM holds bg.eighths/8 of the CUs (one workgroup each)
+                co = opt("msm.form") in (0, 2) and sh["rows"] >= 256
+                e["cu_share"] = 1.0 if co else opt("bg.eighths") / 8
+                if co:
+                    e["what"] = nm[0].replace("bg.eighths/8 of the CUs", "co-resident on every CU: msm.q_bg_waves wavefronts per CU, latency kernels prioritised")
             if ceil:
                 e["frac"] = round(madds / lms / 1e6 / ceil["pt_madd_G_per_s"], 3)
                 if sh["background"] and e["cu_share"] > 0:
@@ -529,9 +590,21 @@ def main():
                            "additions_per_scalar": {"gens_r1cs_sat": nwin_of[False], "gens_r1cs_eval": nwin_of[True]}, "shapes": alu_shapes,
                            # `frac` IS the family figure: every mixed addition of the step over the CU-time it was given (the best
                            # launch shape is reported beside it as frac_best_shape, never as the headline)
-                           "frac": (round(sum(e["mixed_additions"] for e in alu_shapes) / sum(e["launch_ms"] * e.get("cu_share", 1.0) for e in alu_shapes) / 1e6 / ceil["pt_madd_G_per_s"], 3)
-                                    if ceil and alu_shapes else None),
+                           "frac_sum_of_durations": (round(sum(e["mixed_additions"] for e in alu_shapes) / sum(e["launch_ms"] * e.get("cu_share", 1.0) for e in alu_shapes) / 1e6 / ceil["pt_madd_G_per_s"], 3)
+                                                     if ceil and alu_shapes else None),
                            "frac_best_shape": max([e.get("frac", 0) for e in alu_shapes if "background" not in e["what"]] or [None])}
+        # THE family figure: every mixed addition of the timed region over the time at least one row-MSM launch was in flight (the union of
+        # the launches' intervals on one clock, sp_prof_read_spans): launches overlap — the column half of `derefs` is queued while the row half
+        # still holds the CUs — so durations summed count the same milliseconds twice (kept beside it as frac_sum_of_durations)
+        fam_adds = 0.0
+        for r_, c_, bg_, _t0, _t1, _iss in spans:
+            nm = named.get((r_, c_, bg_))
+            if nm:
+                fam_adds += nm[1] * nwin_of[nm[2]]
+        busy = union_ms([(t0_, t1_) for _r, _c, _b, t0_, t1_, _i in spans])
+        roofline["alu"]["busy_ms_per_step"] = round(busy / args.steps, 4) if busy else None
+        roofline["alu"]["frac"] = round(fam_adds / busy / 1e6 / ceil["pt_madd_G_per_s"], 3) if ceil and busy else roofline["alu"]["frac_sum_of_durations"]
+        roofline["alu"]["frac_note"] = "mixed additions of every row-MSM launch of the timed region / union of the launches' intervals / the pt_madd ceiling; the latency chain of the proof runs on the same CUs meanwhile"
         roofline["alu"]["frac_family"] = roofline["alu"]["frac"]
         # F_q streaming kernels (the HBM-shaped part): multiplications/s against the fq_mul chain ceiling, bytes/s against HBM
         fq = {}

@@ -28,18 +28,6 @@ for name, label, rows, cols, blind in shapes:
     if blind:
         bz = rng.integers(0, 2**64, size=(rows, 4), dtype=np.uint64); bz[:, 3] &= np.uint64((1 << 60) - 1)
         bl = bz.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
-    if len(sys.argv) > 3 and sys.argv[3] == "diag":   # variant build -DSP_LDS_DIAG (SPARTAN_HIP_LIB=.../libspartan_hip_ldsdiag.so): what each stage of a tile costs
-        ctx.set_option("testing.unlock", 1); ctx.set_option("msm.form", 1)
-        for mask in (0, 1, 2, 4, 8, 3, 5, 6, 7, 12, 15):
-            ctx.set_option("msm.flat_rounds", mask + 1)
-            best = 1e9
-            for it in range(4):
-                t0 = time.time(); g.commit_rows(t, rows, cols, bl, 0, cols); best = min(best, time.time() - t0)
-            what = "+".join(n for b, n in ((1, "noDMA"), (2, "nobarrier"), (4, "nogather"), (8, "noadd")) if mask & b) or "full"
-            print("2^%d %-13s %5d x %5d  diag %-28s %.3f ms" % (s, name, rows, cols, what, best * 1e3), flush=True)
-        ctx.set_option("msm.flat_rounds", 1)
-        t.free(); g.free()
-        continue
     outs = {}
     for form in ("wide", "lds", "queue"):
         ctx.set_option("msm.form", {"wide": 3, "lds": 1, "queue": 2}[form])

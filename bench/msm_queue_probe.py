@@ -47,7 +47,7 @@ for key, name, label, rows, cols, blind in shapes:
     ctx.set_option("msm.form", 3); run("strip/balanced")
     ctx.set_option("msm.form", 0)
     for wv, dp, un in cfgs:
-        ctx.set_option("msm.q_waves", wv); ctx.set_option("msm.q_depth", dp); ctx.set_option("msm.q_units", un)
+        ctx.set_option("msm.q_waves", wv); ctx.set_option("msm.q_units", un)  # (the ring depth is fixed at 2 since the depth-3 variant was retired)
         run("queue %d/%d/%d" % (wv, dp, un))
     t.free(); g.free()
 print("MSM_QUEUE_PROBE_OK")

@@ -80,6 +80,12 @@ int32_t sp_prof_read_ops(sp_ctx* ctx, double* alg_ops, int cap);
  * background stream): returns the number of shapes seen, fills up to cap entries. */
 int32_t sp_prof_read_shapes(sp_ctx* ctx, const char* family, uint64_t* shape, double* total_ms, uint64_t* launches, double* alg_bytes,
                             double* alg_ops, int cap);
+/* The same launches as intervals [t0, t1) in ms on one clock (zero = the first sp_prof_enable of the context), in the order they were
+ * recorded: launches of one family overlap (a background launch under a foreground one, a launch queued while its predecessor still holds
+ * the CUs), so the family's busy time is the measure of the UNION of its intervals, not the sum of its durations. issued_adds: the mixed
+ * additions a queue-form launch really performed (its wavefronts skip the upper windows of short scalars; 0 for the other forms). Returns
+ * the number of intervals recorded since sp_prof_reset, fills up to cap. */
+int32_t sp_prof_read_spans(sp_ctx* ctx, const char* family, uint64_t* shape, double* t0_ms, double* t1_ms, double* issued_adds, int cap);
 /* default signed window width c (the width of a given set: sp_gens_window_bits): a committed scalar costs ceil(254 / c) mixed additions */
 int sp_msm_window_bits(void);
 

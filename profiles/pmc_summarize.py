@@ -3,12 +3,13 @@
 /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B
 requests at 64 B, i.e. reports half the bytes of a wide (16 B/lane) coalesced stream -> doubled. All kernels here load
 16 B per lane (ulonglong2). WRITE_SIZE is uncalibrated on gfx950 (reported as is).
-usage: python profiles/pmc_summarize.py <FETCH_SIZE pass>.csv <WRITE_SIZE pass>.csv [name of the committed text summary]
-Writes profiles/pmc_traffic.json with the digest of the kernel sources it was collected with (bench.kernel_source_digest):
-bench.py reports `roofline.traffic` only when that digest matches the sources it is running."""
+usage: python profiles/pmc_summarize.py <FETCH_SIZE pass>.csv <WRITE_SIZE pass>.csv <name of the committed text summary> <log2_cons> <SPARTAN_OPTIONS of the passes>
+Adds one entry to profiles/pmc_traffic.json, keyed by the configuration it was collected for (kernel sources | size | non-default
+options: bench.config_key): bench.py reports `roofline.traffic` only for a run whose own key has an entry.
+(An option given to the passes must not equal its default: the bench builds its key from the options that differ from theirs.)"""
 import csv, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_flat": "msm_rows_fixed", "k_msm_flat_bg": "msm_rows_fixed", "k_msm_lds": "msm_rows_fixed", "k_msm_ring": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed", "k_msm_windows_tree_fused": "msm_windows_fixed", "k_ipa_round": "ipa_round",
+FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_flat": "msm_rows_fixed", "k_msm_flat_bg": "msm_rows_fixed", "k_msm_lds": "msm_rows_fixed", "k_msm_q": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed", "k_msm_windows_tree_fused": "msm_windows_fixed", "k_ipa_round": "ipa_round",
           "k_msm_reduce": "msm_reduce_compress", "k_pt_encode": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
           "k_cubic_bind_eval_batched": "sumcheck_bind_eval", "k_sc_bind_eval": "sumcheck_bind_eval", "k_sc_eval": "sumcheck_eval",
           "k_cubic_eval_batched": "sumcheck_eval", "k_cubic_bind_eval_batched_eq": "sumcheck_bind_eval", "k_cubic_eval_batched_eq": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand",
@@ -32,12 +33,22 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
         fam_n[FAMILY[k]] += nf[k]
 out = {fam: fam_bytes[fam] / max(fam_n[fam], 1) for fam in fam_bytes}
 # msm_rows_fixed per launch SHAPE is what the bench line's dominant-kernel entry averages over: keep the two kernels apart too
-for k in ("k_msm_rows", "k_msm_rows_bg", "k_msm_flat", "k_msm_flat_bg", "k_msm_lds", "k_msm_ring"):
+for k in ("k_msm_rows", "k_msm_rows_bg", "k_msm_flat", "k_msm_flat_bg", "k_msm_lds", "k_msm_q"):
     if k in f:
         out[k] = (2.0 * f[k] * 1024 + w.get(k, 0.0) * 1024) / nf[k]
 from bench import kernel_source_digest
-out["kernel_source_digest"] = kernel_source_digest()
+# keyed by configuration (round 6): kernel sources | instance size | the non-default library options of the run — the same
+# string bench.config_key builds from its context. argv[4] = log2_cons, argv[5] = the SPARTAN_OPTIONS the passes ran with ("" = defaults)
+log2 = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+opts = sorted(o for o in (sys.argv[5] if len(sys.argv) > 5 else "").split(",") if o and not o.startswith(("testing.unlock", "host.callstats", "debug.ktime")))
+key = "%s|2^%d|%s" % (kernel_source_digest(), log2, ",".join(opts) or "defaults")
 out["source"] = sys.argv[3] if len(sys.argv) > 3 else "pmc_traffic.json"
-out["log2_cons"] = 20  # collected on bench.py's default workload (profiles/collect_r2.sh)
-json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
-print("\nper-family HBM bytes per launch (profiles/pmc_traffic.json):", json.dumps(out))
+path = "profiles/pmc_traffic.json"
+try:
+    allj = json.load(open(path))
+    if "entries" not in allj: allj = {"entries": {}}
+except (OSError, ValueError):
+    allj = {"entries": {}}
+allj["entries"][key] = out
+json.dump(allj, open(path, "w"), indent=1)
+print("\nper-family HBM bytes per launch (profiles/pmc_traffic.json, entry %s):" % key, json.dumps(out))

@@ -1,5 +1,6 @@
 // spartan_amd: context, generators (window tables), fixed-base MSM, device tables.
 #include "internal.hpp"
+#include <atomic>
 #include <list>
 #include <mutex>
 
@@ -87,6 +88,16 @@ void prof_drain(sp_ctx* c) {
     if (r.shape) {
       ProfShape& ps = c->prof_shapes[std::make_pair(r.fam, r.shape)];
       ps.ms += ms; ps.n += 1; ps.bytes += r.bytes; ps.ops += r.ops;
+      // where the launch lies on the context's clock (sp_prof_read_spans): launches of one family overlap — a background launch under a
+      // foreground one, a launch queued while its predecessor still holds the CUs' LDS — so their durations do not add up to busy time
+      float t0 = 0;
+      if (c->prof_epoch && hipEventElapsedTime(&t0, c->prof_epoch, r.e0) == hipSuccess && c->prof_spans.size() < 65536)
+      {
+        unsigned long long tiles = 0;
+        if (r.issued && hipMemcpy(&tiles, r.issued, 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); tiles = 0; }
+        c->prof_spans.push_back(ProfSpan{r.fam, r.shape, (double)t0, (double)t0 + (double)ms, 64.0 * (double)tiles});
+      }
+      else (void)hipGetLastError();
     }
     c->free_events.push_back(r.e0);
     c->free_events.push_back(r.e1);
@@ -134,7 +145,7 @@ int32_t sync_wait(sp_ctx* c, uint32_t seq) {
 }
 int32_t sync_spin(sp_ctx* c) { return sync_wait(c, sync_post(c)); }
 DoneSig sig_make(sp_ctx* c, size_t total_workgroups) {
-  if (!c->opt.v[OPT_SYNC_KERNEL_SIGNAL] || !c->done_counter) return sig_none();  // A/B switch: completion by a flag kernel behind the last kernel
+  if (!c->done_counter) return sig_none();
   return DoneSig{c->done_flag, c->done_counter, ++c->done_seq, (uint32_t)total_workgroups, c->ktime};
 }
 // wait for a trip whose last kernel was launched with `sig` (falls back to the flag kernel when the signal is off)
@@ -364,11 +375,9 @@ struct MsmDigitStream {
     w++; left--;
   }
 };
-// PIPE 2: two entries in flight, each for the time of two additions (the loop is unrolled twice so that the registers of an entry in
-// flight are never the source of a copy: the compiler's waits then allow the 12 most recent loads to stay outstanding); PIPE 1: rolled,
-// the second entry is copied each step (its load is waited for at the top of the next step: in flight for ONE addition); PIPE 0: one
-// entry in flight, 48 registers less (the 128-register background form)
-template <int PIPE, bool AHEAD>
+// Two entries in flight, each for the time of two additions: the loop is unrolled twice so that the registers of an entry in flight are never
+// the source of a copy — the compiler's waits then allow the 12 most recent loads to stay outstanding. (The rolled form with the second
+// entry copied each step, and the one-entry form of a 128-register background variant, were measured in round 4 and retired in round 6.)
 __device__ __forceinline__ void msm_flat_tile(const MsmFlatArgs& A, unsigned lb, unsigned tid) {
   const unsigned rb = lb % A.rb_count, bk = lb / A.rb_count;
   if (bk >= A.nb) return;
@@ -376,60 +385,31 @@ __device__ __forceinline__ void msm_flat_tile(const MsmFlatArgs& A, unsigned lb,
   const size_t U = (A.cols + (A.blinds ? 1 : 0)) * (size_t)A.geom.nwin;
   const size_t u0 = U * bk / A.nb, u1 = U * (bk + 1) / A.nb;
   Pt acc = pt_identity();
-  MsmDigitStream<AHEAD> ds(A, row);
+  MsmDigitStream<true> ds(A, row);
   ds.open(u0, u1);
   MsmUnit a;
   ds.next(a);
   MsmEntry X = msm_load(a.p);
-  if (PIPE == 0) {
+  MsmUnit b;
+  ds.next(b);
+  MsmEntry Y = msm_load(b.p);
 #pragma unroll 1
-    while (a.valid) {
-      MsmEntry cur = X;
-      MsmUnit ca = a;
-      ds.next(a);
-      X = msm_load(a.p);
-      if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
-    }
-  } else {
-    MsmUnit b;
+  while (a.valid) {
+    MsmEntry cur = X;
+    MsmUnit ca = a;
+    ds.next(a);
+    X = msm_load(a.p);
+    if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
+    if (!b.valid) break;
+    cur = Y;
+    ca = b;
     ds.next(b);
-    MsmEntry Y = msm_load(b.p);
-    if (PIPE == 2) {
-#pragma unroll 1
-      while (a.valid) {
-        MsmEntry cur = X;
-        MsmUnit ca = a;
-        ds.next(a);
-        X = msm_load(a.p);
-        if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
-        if (!b.valid) break;
-        cur = Y;
-        ca = b;
-        ds.next(b);
-        Y = msm_load(b.p);
-        if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
-      }
-    } else {
-#pragma unroll 1
-      while (a.valid) {
-        MsmEntry cur = X;
-        MsmUnit ca = a;
-        a = b; X = Y;
-        ds.next(b);
-        Y = msm_load(b.p);
-        if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
-      }
-    }
+    Y = msm_load(b.p);
+    if (ca.nz) acc = pt_madd(acc, msm_entry_niels(cur), ca.neg);
   }
   A.partial[row * A.nb + bk] = acc;
 }
-template <int PIPE>
-__global__ void __launch_bounds__(256) k_msm_flat(MsmFlatArgs A) { msm_flat_tile<PIPE, true>(A, blockIdx.x, threadIdx.x); }
-// background form: persistent 1024-thread workgroups on a share of the CUs (see k_msm_rows_bg)
-__global__ void __launch_bounds__(1024) k_msm_flat_bg(MsmFlatArgs A, unsigned ntiles) {
-  extern __shared__ uint8_t occupancy_fence[];
-  for (unsigned lb = blockIdx.x * 4 + threadIdx.x / 256; lb < ntiles; lb += gridDim.x * 4) msm_flat_tile<0, false>(A, lb, threadIdx.x % 256);
-}
+__global__ void __launch_bounds__(256) k_msm_flat(MsmFlatArgs A) { msm_flat_tile(A, blockIdx.x, threadIdx.x); }
 
 // Latency-bound shapes (Sigma-protocol commits, IPA rounds, single-row commits): one thread per (row, column,
 // window) performs a single table lookup, so the serial chain per thread is one mixed addition instead of 32.
@@ -1133,6 +1113,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
+  if (c->prof_epoch) (void)hipEventDestroy(c->prof_epoch);
   if (c->q_heads) (void)hipFree(c->q_heads);
   if (c->ktime) (void)hipFree(c->ktime);
   if (c->vm_pinned) (void)hipHostFree(c->vm_pinned);
@@ -1167,6 +1148,12 @@ int32_t sp_ctx_sync(sp_ctx* c) {
 int32_t sp_prof_enable(sp_ctx* c, int on) {
   if (!c) return SP_EINVAL;
   prof_drain(c);
+  if (on && !c->prof_epoch) {  // the zero of the spans' clock: recorded once, on the main stream
+    HIPCHK(hipSetDevice(c->dev));
+    HIPCHK(hipEventCreate(&c->prof_epoch));
+    HIPCHK(hipEventRecord(c->prof_epoch, c->stream));
+    HIPCHK(hipEventSynchronize(c->prof_epoch));
+  }
   c->prof_on = on;
   return SP_OK;
 }
@@ -1186,7 +1173,28 @@ int32_t sp_prof_reset(sp_ctx* c) {
   memset(c->prof_bytes, 0, sizeof c->prof_bytes);
   memset(c->prof_ops, 0, sizeof c->prof_ops);
   c->prof_shapes.clear();
+  c->prof_spans.clear();
   return SP_OK;
+}
+int32_t sp_prof_read_spans(sp_ctx* c, const char* family, uint64_t* shape, double* t0_ms, double* t1_ms, double* issued_adds, int cap) {
+  if (!c || !family) return SP_EINVAL;
+  prof_drain(c);
+  int fam = -1;
+  for (int i = 0; i < PF_COUNT; i++)
+    if (strcmp(kProfNames[i], family) == 0) fam = i;
+  if (fam < 0) return SP_EINVAL;
+  int k = 0;
+  for (auto& sp : c->prof_spans) {
+    if (sp.fam != fam) continue;
+    if (k < cap) {
+      if (shape) shape[k] = sp.shape;
+      if (t0_ms) t0_ms[k] = sp.t0;
+      if (t1_ms) t1_ms[k] = sp.t1;
+      if (issued_adds) issued_adds[k] = sp.issued;
+    }
+    k++;
+  }
+  return k;
 }
 int32_t sp_prof_read_ops(sp_ctx* c, double* alg_ops, int cap) {
   if (!c || !alg_ops) return SP_EINVAL;
@@ -1315,13 +1323,14 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     Niels* table = nullptr;
     HIPCHK(hipMalloc((void**)&table, n * geom.pt_entries * sizeof(Niels)));
     NielsP* table_lds = nullptr;
-    int lds_bits = c->opt.v[OPT_MSM_LDS_BITS] >= 5 ? (int)c->opt.v[OPT_MSM_LDS_BITS] : 0;  // 10 bits: 512 x 96 B = 48 KB per sub-table, double-buffered in 96 of a CU's 160 KB of LDS
+    int lds_bits = (int)c->opt.v[OPT_MSM_LDS_BITS];   // 0 or 6..10 (options.hip refuses the rest)  // 10 bits: 512 x 96 B = 48 KB per sub-table, double-buffered in 96 of a CU's 160 KB of LDS
     // THE DEFAULT PER GENERATOR SET (measured: profiles/r5_ab_msm_forms.txt). While the wide tables keep >= 12 bits (17-22 additions per scalar)
     // the gathered forms win at every size measured (2^20, 2^22, 2^24). When HBM is short and the policy above lands on 10 or 8 bits (26-32
     // additions, at 0.68 of the addition ceiling), the LDS-staged form does the same 26 additions at 0.83 from tables that are SMALLER (96-byte
     // packed entries instead of 128-byte lines): the set then gets the packed tables too and its row commits take that form unless msm.form says otherwise.
     bool prefer_lds = false;
-    if (!lds_bits && wbits <= 10 && n >= 512) { lds_bits = 10; prefer_lds = true; }
+    // (not when msm.wbits forces the width: a caller that asks for 8- or 10-bit gathered tables gets them, and nothing outside its budget: ADVICE r5)
+    if (!lds_bits && wbits <= 10 && n >= 512 && c->opt.v[OPT_MSM_WBITS] < 4) { lds_bits = 10; prefer_lds = true; }
     if (lds_bits && hipMalloc((void**)&table_lds, n * msm_geom(lds_bits).pt_entries * sizeof(NielsP)) != hipSuccess) {
       (void)hipGetLastError();
       table_lds = nullptr;
@@ -1353,6 +1362,29 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     }
     g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table, table_lds, lds_bits, prefer_lds});
     hit = &g_gens_cache.back();
+  }
+  // a resident entry serves every later handle on the same points — but a context that asks for the LDS-staged form's tables must get them:
+  // built for the cached entry now if it has none (msm.form = 1 silently took the gathered form otherwise); another width than
+  // the one already there is reported and the resident tables kept
+  if (const int want_lds = (int)c->opt.v[OPT_MSM_LDS_BITS]) {
+    if (hit->table_lds && hit->wbits_lds != want_lds)
+      fprintf(stderr, "spartan_hip: generator set of %zu points is resident with %d-bit LDS-form tables; msm.lds_bits = %d ignored for it\n", n, hit->wbits_lds, want_lds);
+    if (!hit->table_lds) {
+      MsmGeom gl = msm_geom(want_lds);
+      NielsP* tl = nullptr;
+      HIPCHK(hipStreamSynchronize(c->stream));
+      size_t off_pts = (in_bytes + 255) & ~(size_t)255, off_bad = off_pts + n * sizeof(Pt) + ((32 * n + 255) & ~(size_t)255);
+      SPCHK(ensure(&c->scratch, &c->scratch_cap, off_bad + 256));
+      uint8_t* base = (uint8_t*)c->scratch;
+      if (hipMalloc((void**)&tl, n * gl.pt_entries * sizeof(NielsP)) != hipSuccess) { (void)hipGetLastError(); return SP_ENOMEM; }
+      HIPCHK(hipMemcpyAsync(base, hit->in.data(), in_bytes, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemsetAsync(base + off_bad, 0, 4, c->stream));
+      hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts), (uint8_t*)nullptr, (int*)(base + off_bad));
+      size_t ntl = n * gl.nwin * (size_t)(gl.tent < 128 ? 1 : gl.tent / 128);
+      hipLaunchKernelGGL(k_table_build<NielsP>, dim3((unsigned)((ntl + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, tl, gl);
+      if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) { (void)hipFree(tl); return SP_EHIP; }
+      hit->table_lds = tl; hit->wbits_lds = want_lds;
+    }
   }
   sp_gens* g = new (std::nothrow) sp_gens();
   if (!g) {
@@ -1413,11 +1445,12 @@ struct MsmPlan {
   bool queue = false; // the queue form (msm_queue.hip, k_msm_q): P = runs per row
   MsmQRuns qruns{0, 0, 0};
   int qrole = MSMQ_ALONE;
-  int flat;  // 0: strip form; 1 / 2: balanced form (k_msm_flat<0> / <1>), P = runs per row
+  int flat;  // 0: strip form; 2: balanced form (k_msm_flat), P = runs per row
   size_t strip, nstrips, P, chunk, nchunks, part_bytes, part2_bytes;
 };
 // workgroups of 256 threads the chip holds at once for the balanced row MSM (occupancy of the kernel x CUs), per device
-static size_t msm_flat_slots(int pipe) {
+static size_t msm_flat_slots() {
+  const int pipe = 1;
   static std::mutex mu;
   static std::map<std::pair<int, int>, size_t> slots;  // (device, pipe) -> resident workgroups
   int dev = 0;
@@ -1428,7 +1461,7 @@ static size_t msm_flat_slots(int pipe) {
   int per_cu = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 768;
-  hipError_t e = pipe ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat<1>, 256, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_flat, 256, 0);
   if (e != hipSuccess || per_cu < 1) per_cu = 3;
   return slots[{dev, pipe}] = (size_t)per_cu * (size_t)prop.multiProcessorCount;
 }
@@ -1446,33 +1479,28 @@ static MsmPlan msm_plan(const sp_ctx* c, const sp_gens* g, size_t rows, size_t c
     m.P = ncol * NWIN;
   } else {
     const SpOptions& opt = c->opt;
-    const size_t target_threads = (size_t)opt.v[OPT_MSM_STRIP_THREADS];
+    const size_t target_threads = 524288;  // (256 k and 1 M threads measured in round 3: both slower)
     m.strip = total / target_threads;  // enough threads for >= 4 waves per SIMD on 256 CUs
     if (m.strip < 1) m.strip = 1;
     if (m.strip > cols) m.strip = cols;
     m.nstrips = (cols + m.strip - 1) / m.strip;
     m.P = m.nstrips;
-    // balanced form (A/B switch SPARTAN_MSM_FLAT: 0 = strip form, 1 = one entry in flight, 2 = two, the default)
-    const int flat_mode = (int)opt.v[OPT_MSM_FLAT];
     if (launch_rows == 0) launch_rows = rows;
-    // the background launch keeps the strip form by default: its balanced form finishes a 768 x 4096 commit in 4.7 instead of 5.8 ms on 5/8 of
-    // the chip, and the latency-bound kernels next to it (second sum-check, witness opening) then run 2x slower instead of 1.3x — the
-    // proof loses more than the commit gains (profiles/r4_ab_msm_forms.txt); SPARTAN_MSM_FLAT_BG=1 selects it
-    const bool flat_bg = opt.v[OPT_MSM_FLAT_BG] != 0;
-    // a foreground commit that shares the chip with a background one also keeps the strip form: the balanced form is exactly as many
-    // workgroups as an EMPTY chip holds, each as long as the launch — with 5/8 of the CUs taken it would run in three uneven waves of
-    // them (commit_nondet_witness 4.1 -> 4.55 ms), where the strip form's two thousand short workgroups fill whatever is free
-    // and so does a commit of many row-blocks (SNARK::encode's 4096 x 4096 multi_commit: 16 of them): the balanced form gives every
-    // workgroup the same NUMBER of additions, which is the same TIME only when the scalars are alike — the three row-blocks of `val` are
-    // full-size, the twelve of addresses and timestamps a few bits long, so 144 of the 768 workgroups would do all the work (encode 54 ->
-    // 65 ms); the strip form's two thousand workgroups are handed out as CUs free up
-    if (flat_mode && rows % 256 == 0 && launch_rows % 256 == 0 && launch_rows / 256 <= 4 && (bg_subblocks ? flat_bg : !shares_chip)) {
+    // balanced form: a launch of at most four row-blocks that has the chip to itself (the witness commitment and its upload chunks,
+    // stand-alone commits of few rows). Everything else that is not queue-sized keeps the strip form: the background launch (its
+    // balanced form finished a 768 x 4096 commit in 4.7 instead of 5.8 ms on 5/8 of the chip and the latency-bound kernels next to it then
+    // ran 2x slower instead of 1.3x: profiles/r4_ab_msm_forms.txt), a foreground commit that shares the chip with a background one (the
+    // balanced form is exactly as many workgroups as an EMPTY chip holds, each as long as the launch), and a commit of many row-blocks
+    // whose rows carry unlike scalars (equal additions per workgroup are equal time only when the scalars are alike)
+    if (rows % 256 == 0 && launch_rows % 256 == 0 && launch_rows / 256 <= 4 && !bg_subblocks && !shares_chip) {
       const size_t rb = launch_rows / 256, units = ncol * NWIN;
-      size_t slots = bg_subblocks ? bg_subblocks : msm_flat_slots(flat_mode == 2 ? 1 : 0);
-      const size_t rounds = (size_t)opt.v[OPT_MSM_FLAT_ROUNDS];
-      size_t nb = slots * rounds / rb;          // runs per row: the launch is `rounds` full sets of resident workgroups
+      size_t nb = msm_flat_slots() / rb;        // runs per row: the launch is one full set of resident workgroups
       if (nb > units / 4) nb = units / 4;       // at least four additions per thread
-      if (nb >= 1) { m.flat = bg_subblocks ? 1 : flat_mode; m.P = nb; }
+      if (nb >= 1) { m.flat = 2; m.P = nb; }
+    }
+    if (opt.v[OPT_MSM_FORM] == 1 && !g->table_lds) {  // asked for, not possible: say so once instead of silently measuring another form
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true)) fprintf(stderr, "spartan_hip: msm.form = 1 but the generator set was built without LDS-form tables (set msm.lds_bits before creating it): its row commitments take the default forms\n");
     }
     // LDS-staged small-window form: a workgroup is up to 1024 rows, so it needs rows to fill a CU with (>= 768 for 3 waves per SIMD)
     if (g->table_lds && (opt.v[OPT_MSM_FORM] == 1 || (opt.v[OPT_MSM_FORM] == 0 && g->prefer_lds)) && launch_rows >= 512) {
@@ -1488,8 +1516,7 @@ static MsmPlan msm_plan(const sp_ctx* c, const sp_gens* g, size_t rows, size_t c
       // (a commit issued in row chunks behind its upload has the chip to itself and rows that are alike: the balanced form's case)
       m.queue = true; m.flat = 0;
       // the background launch and a foreground launch that meets one in flight share the chip with each other and with the latency kernels
-      const bool co = opt.v[OPT_MSM_Q_CORESIDENT] != 0;
-      m.qrole = bg_subblocks ? (co ? MSMQ_CORESIDENT : MSMQ_SHARE) : (shares_chip && co ? MSMQ_CORESIDENT : MSMQ_ALONE);
+      m.qrole = bg_subblocks || shares_chip ? MSMQ_CORESIDENT : MSMQ_ALONE;
       m.qruns = msm_q_cut(c, g, launch_rows, cols, has_blinds, m.qrole);
       m.P = m.qruns.S;
     }
@@ -1531,29 +1558,19 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
     int xcd_map = rows % 256 == 0;
     size_t nblocks = xcd_map ? ((m.nstrips + 7) / 8) * 8 * (rows / 256) : (rows * m.nstrips + 255) / 256;
     if (m.queue) {
-      msm_q_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.qruns, m.qrole, &qcounts);
+      msm_q_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.qruns, m.qrole, &qcounts, &ps.issued);
     } else if (m.lds) {
       msm_lds_enqueue(c, st, g, dZ, z_stride, rows, cols, g_off, didx, dblinds, h_idx, partial, m.P, st != c->stream && c->bg_blocks > 0 ? (unsigned)c->bg_blocks : 0u);
     } else if (m.flat) {
       MsmFlatArgs A{dZ, z_stride, rows, cols, (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, (unsigned)m.P, (unsigned)(rows / 256), g->geom};
       const unsigned ntiles = A.nb * A.rb_count;
-      if (st != c->stream && c->bg_blocks > 0)
-        hipLaunchKernelGGL(k_msm_flat_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, A, ntiles);
-      else if (m.flat == 2)
-        hipLaunchKernelGGL(k_msm_flat<2>, dim3(ntiles), dim3(256), 0, st, A);
-      else
-        hipLaunchKernelGGL(k_msm_flat<1>, dim3(ntiles), dim3(256), 0, st, A);
+      hipLaunchKernelGGL(k_msm_flat, dim3(ntiles), dim3(256), 0, st, A);
     } else if (st != c->stream && !didx && !dblinds && c->bg_blocks > 0) {
       hipLaunchKernelGGL(k_msm_rows_bg, dim3((unsigned)c->bg_blocks), dim3(1024), (unsigned)c->bg_lds, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
                          (const Niels*)g->table, g_off, partial, xcd_map, nblocks, g->geom);
     } else {
-      const bool pf2 = c->opt.v[OPT_MSM_PREFETCH] == 2;  // A/B switch: one table entry in flight instead of two
-      if (pf2)
-        hipLaunchKernelGGL(k_msm_rows<true>, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
-                           (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
-      else
-        hipLaunchKernelGGL(k_msm_rows<false>, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
-                           (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
+      hipLaunchKernelGGL(k_msm_rows<true>, dim3((unsigned)nblocks), dim3(256), 0, st, dZ, z_stride, rows, cols, m.strip, m.nstrips,
+                         (const Niels*)g->table, g_off, didx, dblinds, h_idx, partial, xcd_map, g->geom);
     }
   }
   if (!do_reduce) return;
@@ -1591,8 +1608,7 @@ int32_t msm_launch(sp_ctx* c, const sp_gens* g, const Fq* dZ, size_t z_stride, s
     if (m.windowed) {
       size_t nblk = (m.P + 255) / 256;
       Pt10* part = (Pt10*)c->scratch;  // nblk * rows * 160 B <= part_bytes
-      const bool fused = c->opt.v[OPT_MSM_FUSED_TREE] != 0;  // A/B switch: lookups + tree, reduction and flag as three launches
-      if (fused && nblk > 1 && !c->device_encode && c->done_counter) {
+      if (nblk > 1 && !c->device_encode && c->done_counter) {
         DoneSig sig = sig_make(c, nblk * rows);
         {
           ProfScope ps(c, PF_MSM_WINDOWS, 32.0 * (double)(rows * cols) + 160.0 * (double)(rows * nblk));

@@ -42,9 +42,11 @@ extern const char* kProfNames[PF_COUNT];
 struct ProfRec {
   hipEvent_t e0, e1;
   int fam;
+  const unsigned long long* issued;  // queue-form row MSM: device counter of the tiles (64 mixed additions each) the launch issued, or null
   uint64_t shape;  // launch shape inside the family (0 = not tracked): the MSM families key (rows, cols, background)
   double bytes, ops;
 };
+struct ProfSpan { int fam; uint64_t shape; double t0, t1, issued; };  // one tracked launch on the context's clock (ms since prof_epoch)
 struct ProfShape {
   double ms = 0, bytes = 0, ops = 0;
   uint64_t n = 0;
@@ -113,6 +115,8 @@ struct sp_ctx {
   double prof_bytes[PF_COUNT];
   double prof_ops[PF_COUNT];  // algorithmic field multiplications (F_q kernels) / mixed point additions (MSM kernels)
   std::map<std::pair<int, uint64_t>, ProfShape> prof_shapes;
+  std::vector<ProfSpan> prof_spans;  // launches of the shape-tracked families (the row MSMs) as intervals: sp_prof_read_spans
+  hipEvent_t prof_epoch = nullptr;
 };
 struct sp_gens {
   sp_ctx* ctx;
@@ -168,6 +172,7 @@ struct ProfScope {
   hipStream_t st;  // the stream the timed kernels are launched on
   uint64_t shape;
   double bytes, ops;
+  const unsigned long long* issued = nullptr;
   ProfScope(sp_ctx* c_, int fam_, double bytes_, hipStream_t st_ = nullptr, double ops_ = 0.0, uint64_t shape_ = 0)
       : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)), st(st_ ? st_ : c_->stream), shape(shape_), bytes(bytes_), ops(ops_) {
     if (!on) return;
@@ -190,7 +195,7 @@ struct ProfScope {
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, st);
-    c->pending.push_back(ProfRec{e0, e1, fam, shape, bytes, ops});
+    c->pending.push_back(ProfRec{e0, e1, fam, issued, shape, bytes, ops});
   }
 };
 
@@ -273,12 +278,13 @@ void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, 
 // queue form (msm_queue.hip, k_msm_q): self-contained wavefronts with private LDS rings, items pulled from a device-side queue; the options and
 // the queue heads are those of the LAUNCHING context c (a virtual shard launches its parent's generator set on its own streams)
 struct MsmQRuns { unsigned nb, len, S; };  // queue form (msm_queue.hip): runs per row, units per run, partial-sum slots per row
-constexpr unsigned MSMQ_MAX_GROUPS = 1024, MSMQ_BLOCK_WORDS = 2 * MSMQ_MAX_GROUPS, MSMQ_BLOCKS = 64;  // counter blocks of sp_ctx::q_heads
-enum MsmQRole { MSMQ_ALONE = 0, MSMQ_SHARE = 1, MSMQ_CORESIDENT = 2 };  // what else runs on the chip next to a launch (msm_queue.hip, msm_q_shape)
+constexpr unsigned MSMQ_MAX_GROUPS = 1024, MSMQ_BLOCK_WORDS = 2 * MSMQ_MAX_GROUPS + 2 /* + a 64-bit tile counter */, MSMQ_BLOCKS = 256;  // counter blocks of sp_ctx::q_heads
+enum MsmQRole { MSMQ_ALONE = 0, MSMQ_CORESIDENT = 2 };  // what else runs on the chip next to a launch (msm_queue.hip, msm_q_shape)
 MsmQRuns msm_q_cut(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, bool has_blinds, int role);
 void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, const MsmQRuns& r, int role,
-                   const unsigned** counts_out /* per 64-row group: partial sums written (take min with r.S) */);
+                   const unsigned** counts_out /* per 64-row group: partial sums written (take min with r.S) */,
+                   const unsigned long long** issued_out /* profiling runs: device counter of the tiles issued, else null */);
 
 static inline size_t grid_for(size_t work, size_t maxblocks = 2048) {
   size_t b = (work + 255) / 256;

@@ -40,7 +40,7 @@ struct MsmLdsArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// DIAG (timing experiments of `make variant NAME=ldsdiag FLAGS=-DSP_LDS_DIAG` only; WRONG RESULTS unless 0): bit 0 no DMA, bit 1 no barrier,
+// DIAG (timing experiments of `make variant NAME=ldsdiagN FLAGS=-DSP_LDS_DIAG=N` only; WRONG RESULTS unless 0): bit 0 no DMA, bit 1 no barrier,
 // bit 2 no LDS gather (one fixed entry), bit 3 no addition — what each stage of a tile costs (bench/msm_lds_probe.py ... diag).
 // First measurement (profiles/r5_lds_diag_v1.txt, 1536 x 4096): the additions alone 7.1 of 8.1 ms; the DMA costs 0.8 ms although it has a
 // whole addition to land in — its ISSUE does: right after the barrier every wave of the CU queues its 3-4 LDS-DMA pieces (~100 cycles of
@@ -243,12 +243,9 @@ void msm_lds_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, 
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  // more than the default 64 KB of dynamic LDS
     hipLaunchKernelGGL(kern, dim3(grid), dim3(thr), (unsigned)lds, st, A);
   };
-#ifdef SP_LDS_DIAG
-  switch ((int)c->opt.v[OPT_MSM_FLAT_ROUNDS] - 1) {  // variant build only: the stage mask rides on msm.flat_rounds - 1 (1..16 -> 0..15)
-    case 1: launch(k_msm_lds<1>); return; case 2: launch(k_msm_lds<2>); return; case 3: launch(k_msm_lds<3>); return; case 4: launch(k_msm_lds<4>); return;
-    case 5: launch(k_msm_lds<5>); return; case 6: launch(k_msm_lds<6>); return; case 7: launch(k_msm_lds<7>); return; case 8: launch(k_msm_lds<8>); return;
-    case 12: launch(k_msm_lds<12>); return; case 15: launch(k_msm_lds<15>); return; default: break;
-  }
+#ifdef SP_LDS_DIAG   // variant build only (make variant NAME=ldsdiagN FLAGS=-DSP_LDS_DIAG=N): the stage mask is compiled in
+  launch(k_msm_lds<SP_LDS_DIAG>);
+  return;
 #endif
   launch(k_msm_lds<0>);
 }

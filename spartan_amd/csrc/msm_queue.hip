@@ -37,6 +37,8 @@ struct MsmQArgs {
   unsigned* heads;          // [ngroups] next run of each row group (zero when the launch starts)
   unsigned* nslots;         // [ngroups] attachments so far (may run past S: refused ones count too; the reduction takes min(nslots, S))
   unsigned nb, ngroups, len, S;  // runs per row; 64-row groups; units per run; partial-sum slots per row
+  unsigned long long* issued;     // profiling runs: tiles issued by all wavefronts (x 64 = mixed additions actually performed: the ballot skips
+                                  // the upper windows of short scalars), or null
   int wbits, nwin, tent;
 };
 
@@ -99,23 +101,20 @@ __device__ __forceinline__ void q_wait_tiles(int tiles) {
   }
 }
 
-// D: ring depth, D - 1 tiles of gathers in flight per wavefront (LDS: D x 6 KB per wavefront).
-// FENCE (the background launch): the wavefronts claim the SIMD's whole register file between them — 168 VGPRs each at 3 per SIMD, 256 at 2 —
-// although the code needs ~120. A CU that runs a background workgroup then has no room for a wavefront of any other kernel, and the launch
-// on bg.eighths/8 of the CUs is the partition a CU mask would give (not honoured on this platform). Without it the main stream's latency
-// kernels are dispatched onto the background CUs as well and lose every issue arbitration against three older, ALU-saturating wavefronts
-// per SIMD: measured, second sum-check 1.2 -> 4.1 ms at 2^20, 2.9 -> 9.4 ms at 2^22 (profiles/r6_ab_queue_form.txt).
+// D = 2 ring slots per wavefront: one tile of gathers in flight under the addition of the previous one. (Three slots with two wavefronts
+// per SIMD measured no better — the gathers are not waited for: profiles/r6_queue_diag.txt — and were retired with the variant that ran the
+// background launch on a fenced share of the CUs: without the fence the latency kernels were dispatched onto the background CUs and lost
+// every issue arbitration there, second sum-check 1.2 -> 4.1 ms; with it the reserved CUs idled. The co-resident form replaced both.)
+constexpr int MSMQ_D = 2;
 // SP_Q_DIAG (timing experiments of `make variant NAME=qdiagN FLAGS=-DSP_Q_DIAG=N` only; WRONG RESULTS unless 0): bit 0 no gathers (every
 // addition takes the neutral entry), bit 1 no additions (the gathers and their waits alone), bit 2 gathers issued but not waited for (the
 // additions read whatever the slot holds: the cost of ISSUING the gathers without their latency) — what each side of a tile costs in this loop
 #ifndef SP_Q_DIAG
 #define SP_Q_DIAG 0
 #endif
-template <int D, int FENCE>
-__global__ void __launch_bounds__(FENCE == 256 ? 512 : 768) k_msm_q(MsmQArgs A) {
+__global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
+  constexpr int D = MSMQ_D;
   extern __shared__ __attribute__((aligned(16))) uint8_t q_lds[];
-  if (FENCE == 168) asm volatile("v_mov_b32 v167, 0" ::: "v167");
-  if (FENCE == 256) asm volatile("v_mov_b32 v255, 0" ::: "v255");
   const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 #if SP_Q_DIAG & 8   // bit 3: the shader clock this kernel runs at (shader cycles over the 100 MHz wall clock), printed by one wavefront
   const unsigned long long dg_c0 = clock64(), dg_w0 = wall_clock64();
@@ -147,6 +146,7 @@ __global__ void __launch_bounds__(FENCE == 256 ? 512 : 768) k_msm_q(MsmQArgs A) 
   // this wavefront's walk over the row groups: position 0 is its home group (wavefronts are dealt to the groups round-robin), positions only
   // ever advance — a group it has left is exhausted, a group that had no slot for it is left to the wavefronts attached there
   const unsigned home = (blockIdx.x * nwaves + wave) % A.ngroups;
+  unsigned long long n_issued = 0;
   for (unsigned pos = 0; pos < A.ngroups;) {
     {  // the next position whose group still has runs (lanes look at 64 heads at a time)
       unsigned found = A.ngroups;
@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(FENCE == 256 ? 512 : 768) k_msm_q(MsmQArgs A) 
           slot_w = slot_w + 1 == (unsigned)D ? 0 : slot_w + 1;
           hist = (hist << 2) | (d < 0 ? 1u : 0u) | (m == 0 ? 2u : 0u);
           inflight++;
+          n_issued++;
           if (inflight == D) consume();  // (the tile just issued went into the slot the previous addition has finished reading)
         }
       }
@@ -262,6 +263,7 @@ __global__ void __launch_bounds__(FENCE == 256 ? 512 : 768) k_msm_q(MsmQArgs A) 
     }
     if (live) A.partial[row * A.S + slot] = acc;  // (the neutral element if another wavefront took the group's last run first)
   }
+  if (A.issued && lane == 0 && n_issued) atomicAdd(A.issued, n_issued);
 #if SP_Q_DIAG & 8
   if (blockIdx.x == 7 && tid == 0) {
     const unsigned long long c = clock64() - dg_c0, w = wall_clock64() - dg_w0;
@@ -273,13 +275,13 @@ __global__ void __launch_bounds__(FENCE == 256 ? 512 : 768) k_msm_q(MsmQArgs A) 
 // ------------------------------------------------------------------------------------------------ host side
 // wavefronts per workgroup (4 / 8 / 12 = 1 / 2 / 3 per SIMD) and ring depth of a launch: 12 x 2 x 6 KB or 8 x 3 x 6 KB = 144 KB of the CU's
 // 160 KB, so a CU holds exactly one workgroup and a launch of n workgroups occupies n CUs — the partition a CU mask would give
-// role of a launch (MsmQRole, internal.hpp): ALONE — the chip to itself: msm.q_waves wavefronts per workgroup on every CU; SHARE — the
-// background launch on bg.eighths/8 of the CUs behind the register fence; CORESIDENT — msm.q_bg_waves wavefronts (8: two per SIMD, 96 KB of
+// role of a launch (MsmQRole, internal.hpp): ALONE — the chip to itself: msm.q_waves wavefronts per workgroup on every CU;
+// CORESIDENT — the background launch, and a foreground launch that meets one in flight: msm.q_bg_waves wavefronts (8: two per SIMD, 96 KB of
 // LDS) on EVERY CU, leaving each CU half of its registers and 64 KB of LDS for the main stream's latency kernels, which outrank the MSM's
 // wavefronts in the issue arbitration (SP_FG_PRIO, internal.hpp) — no CU is held in reserve for them
 static void msm_q_shape(const sp_ctx* c, int role, unsigned* waves, unsigned* depth, size_t* wgs) {
-  unsigned wv = (unsigned)c->opt.v[role != MSMQ_ALONE ? OPT_MSM_Q_BG_WAVES : OPT_MSM_Q_WAVES], d = (unsigned)c->opt.v[OPT_MSM_Q_DEPTH];
-  *wgs = role == MSMQ_SHARE && c->bg_blocks > 0 ? (size_t)c->bg_blocks : (size_t)c->n_cus;
+  unsigned wv = (unsigned)c->opt.v[role != MSMQ_ALONE ? OPT_MSM_Q_BG_WAVES : OPT_MSM_Q_WAVES], d = MSMQ_D;
+  *wgs = (size_t)c->n_cus;
   if (wv * d * MSMQ_SLOT + 96 > 160 * 1024) d = 2;
   *waves = wv; *depth = d;
 }
@@ -304,7 +306,7 @@ MsmQRuns msm_q_cut(const sp_ctx* c, const sp_gens* g, size_t rows, size_t cols, 
 }
 void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, size_t z_stride, size_t rows, size_t cols, size_t g_off,
                    const uint32_t* didx, const Fq* dblinds, size_t h_idx, Pt* partial, const MsmQRuns& r, int role,
-                   const unsigned** counts_out) {
+                   const unsigned** counts_out, const unsigned long long** issued_out) {
   MsmQArgs A;
   A.Z = dZ; A.z_row_stride = z_stride; A.rows = rows; A.cols = cols;
   A.table = g->table; A.g_off = g_off; A.idx = didx; A.blinds = dblinds; A.h_idx = h_idx;
@@ -318,6 +320,10 @@ void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, si
   A.nslots = A.heads + MSMQ_MAX_GROUPS;
   (void)hipMemsetAsync(A.heads, 0, 4 * (size_t)MSMQ_BLOCK_WORDS, st);
   *counts_out = A.nslots;
+  A.issued = c->prof_on ? reinterpret_cast<unsigned long long*>(A.heads + 2 * MSMQ_MAX_GROUPS) : nullptr;  // (zeroed with the block)
+  if (issued_out) *issued_out = A.issued;
+  // profiling runs read the counter at the next drain: drain before the ring of blocks wraps onto a block that has not been read
+  if (c->prof_on && c->q_next % MSMQ_BLOCKS == 0) prof_drain(c);
   unsigned waves, depth;
   size_t wgs;
   msm_q_shape(c, role, &waves, &depth, &wgs);
@@ -329,11 +335,5 @@ void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, si
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(64 * waves), (unsigned)lds, st, A);
   };
-  // the register fence of the background launch: 3 wavefronts per SIMD x 168 or 2 x 256 VGPRs (4 / 8 wavefronts get the 256 form: the rest of
-  // the file then holds at most one more wavefront of their size, and the LDS claim keeps a second workgroup off the CU)
-  const bool fence = role == MSMQ_SHARE && c->bg_blocks > 0 && c->bg_blocks < c->n_cus;
-  if (!fence) { if (depth >= 3) launch(k_msm_q<3, 0>); else launch(k_msm_q<2, 0>); }
-  else if (waves == 12) launch(k_msm_q<2, 168>);
-  else if (depth >= 3) launch(k_msm_q<3, 256>);
-  else launch(k_msm_q<2, 256>);
+  launch(k_msm_q);
 }

@@ -32,6 +32,12 @@ static int32_t opt_apply(SpOptions& o, const char* key, const char* value, bool 
     if (!quiet) fprintf(stderr, "spartan_hip: option %s = \"%s\" is outside %lld..%lld\n", key, value, kOptDesc[i].lo, kOptDesc[i].hi);
     return SP_EINVAL;
   }
+  // values inside the range that no kernel supports: 1..5-bit LDS-form tables (a sub-table must be whole KB pieces of LDS-DMA: ADVICE r5 — 5
+  // bits gave silently wrong commitments), queue-form workgroups that are not 1, 2 or 3 wavefronts per SIMD
+  if ((i == OPT_MSM_LDS_BITS && v != 0 && v < 6) || ((i == OPT_MSM_Q_WAVES || i == OPT_MSM_Q_BG_WAVES) && v != 4 && v != 8 && v != 12)) {
+    if (!quiet) fprintf(stderr, "spartan_hip: option %s = %lld is not a supported value\n", key, v);
+    return SP_EINVAL;
+  }
   if (kOptDesc[i].tier > 0 && !o.v[OPT_TESTING_UNLOCK]) {
     if (!quiet) fprintf(stderr, "spartan_hip: option %s is an A/B / test switch: set testing.unlock = 1 first\n", key);
     return SP_EINVAL;
@@ -73,6 +79,13 @@ int32_t sp_ctx_set_option(sp_ctx* c, const char* key, const char* value) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     defaults_init_locked();
     return opt_apply(g_defaults, key, value, false);
+  }
+  {  // options that are process-wide by nature live in the process-wide table only: set on a context they would be accepted and ignored
+    const int i = opt_find(key ? key : "");
+    if (i == OPT_HOST_KECCAK || i == OPT_HOST_PROOF_GATE || i == OPT_HOST_CALLSTATS) {
+      fprintf(stderr, "spartan_hip: option %s is process-wide: set it with a NULL context (before the first proof)\n", key);
+      return SP_EINVAL;
+    }
   }
   int32_t rc = opt_apply(c->opt, key, value, false);
   if (rc == SP_OK) ctx_options_changed(c, opt_find(key));

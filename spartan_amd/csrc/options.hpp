@@ -28,28 +28,19 @@
   X(SHARD_RESIDUE_MIN_LOG2, "shard.residue_min_log2", 22, 0, 64, 0, "over multi-process transports: shard a sum-check when its tables have >= 2^this entries (0 = always, 64 = never)") \
   X(HOST_KECCAK, "host.keccak", 0, 0, 3, 0, "PROC. Keccak-f[1600] form of the host transcript: 0 = fastest by calibration, 1 = plain, 2 = BMI2, 3 = AVX-512") \
   X(HOST_PROOF_GATE, "host.proof_gate", 0, 0, 1, 0, "PROC. several proofs in flight on one device: admit one at a time to the throughput-bound part") \
-  X(SYNC_KERNEL_SIGNAL, "sync.kernel_signal", 1, 0, 1, 1, "completion raised by the last kernel of a trip (0: a flag kernel behind it)")     \
   X(IPA_UNIFIED_TREE, "ipa.unified_tree", 0, 0, 1, 1, "inner-product rounds always with the unified (complete) addition tree")               \
   X(IPA_DEDICATED_UPLOADED, "ipa.dedicated_uploaded", 0, 0, 1, 1, "dedicated (incomplete, two-multiplication) addition tree also for caller-supplied generator lists (default: only for sets the library derived by hash-to-curve)") \
-  X(IPA_FUSED, "ipa.fused", 1, 0, 1, 1, "one launch per inner-product round (0: prepare + lookups + reduce)")                                \
+  X(IPA_FUSED, "ipa.fused", 1, 0, 1, 1, "one launch per inner-product round (0: prepare + lookups + reduce, the form vectors longer than 16384 fall back to - its test hook)")                                \
   X(IPA_RERUN_EXCEPTIONAL, "ipa.rerun_exceptional", 1, 0, 1, 1, "re-run a round with the unified tree when the dedicated tree met an exceptional sum") \
   X(IPA_FINISH_DEVICE, "ipa.finish_device", 0, 0, 1, 1, "the end of an inner-product argument on the device instead of the proving core")     \
   X(ENCODE_DEVICE, "encode.device", 0, 0, 1, 1, "every RFC 9496 encode on the device (few-row commitments are encoded by the proving core by default)") \
   X(COMMIT_SMALL_DEVICE, "commit.small_device", 0, 0, 1, 1, "the 2..5-term Sigma-protocol commitments on the device instead of the proving core") \
-  X(MSM_STRIP_THREADS, "msm.strip_threads", 524288, 65536, 16777216, 1, "threads a strip-form row MSM launch aims for")                      \
-  X(MSM_FLAT, "msm.flat", 2, 0, 2, 1, "balanced (column, window) form of the wide row MSM: 0 = strip form only, 1 = one entry in flight, 2 = two") \
-  X(MSM_FLAT_BG, "msm.flat_bg", 0, 0, 1, 1, "balanced form for the background launch too")                                                   \
-  X(MSM_FLAT_ROUNDS, "msm.flat_rounds", 1, 1, 16, 1, "sets of resident workgroups a balanced launch is cut into")                            \
   X(MSM_Q_WAVES, "msm.q_waves", 12, 4, 12, 1, "queue form: wavefronts per workgroup (4 / 8 / 12 = 1 / 2 / 3 per SIMD; one workgroup per CU)")                      \
   X(MSM_Q_BG_WAVES, "msm.q_bg_waves", 8, 4, 12, 1, "queue form: wavefronts per workgroup of a launch that shares the chip (the background launch, a foreground launch next to one)")                                 \
-  X(MSM_Q_CORESIDENT, "msm.q_coresident", 1, 0, 1, 1, "queue form: the background launch runs on every CU next to the latency kernels (msm.q_bg_waves wavefronts per CU, no reserved CUs); 0 = on bg.eighths/8 of the CUs behind a register fence") \
-  X(MSM_Q_DEPTH, "msm.q_depth", 2, 2, 3, 1, "queue form: ring slots per wavefront (depth - 1 tiles of gathers in flight; 3 only with <= 8 wavefronts)") \
   X(MSM_Q_UNITS, "msm.q_units", 32, 4, 4096, 1, "queue form: (column, window) units per queue item")                                             \
-  X(MSM_PREFETCH, "msm.prefetch", 2, 1, 2, 1, "table entries in flight in the strip form")                                                   \
-  X(MSM_FUSED_TREE, "msm.fused_tree", 1, 0, 1, 1, "single-row commitments in one launch (0: lookups + tree, reduction, flag)")               \
   X(UPLOAD_OVERLAP, "upload.overlap", 1, 0, 1, 1, "witness commit issued in row chunks behind the upload")                                   \
   X(UPLOAD_THREAD, "upload.thread", 1, 0, 1, 1, "witness upload + commit issued by a helper thread while the proving thread hashes the transcript prefix") \
-  X(SUMCHECK_INLINE_ARGS, "sumcheck.inline_args", 1, 0, 1, 1, "table pointers of the batched sum-check kernels in the kernel arguments")      \
+  X(SUMCHECK_INLINE_ARGS, "sumcheck.inline_args", 1, 0, 1, 1, "table pointers of the batched sum-check kernels in the kernel arguments (0: the staged form that more than 24 instances or 13 variables fall back to - its test hook)")      \
   X(SUMCHECK_DOUBLE_ROUND_MAX_LEN, "sumcheck.double_round_max_len", 4096, 0, 1073741824, 1, "two rounds per trip while the tables have at most this many entries") \
   X(SUMCHECK_HOST_TAIL, "sumcheck.host_tail", 1, 0, 1, 1, "last <= 3 rounds of a batched sum-check on the proving core")                     \
   X(SPARK_PROD_LAYER2, "spark.prod_layer2", 1, 0, 1, 1, "two product-circuit layers per launch in the launch-sized middle of the tree")       \
@@ -58,10 +49,8 @@
   X(SPARK_HASH_FUSE, "spark.hash_fuse", 1, 0, 1, 1, "hash layer + first product layer in one pass")                                          \
   X(OVERLAP_DEREFS, "overlap.derefs", 1, 0, 1, 1, "row half of the derefs commitment on the background stream under the second sum-check")    \
   X(OVERLAP_EVAL_AHEAD, "overlap.eval_ahead", 1, 0, 1, 1, "R1CSInstance::evaluate queued on a low-priority stream as soon as ry is known")    \
-  X(OVERLAP_COL_HALF, "overlap.col_half", 0, 0, 1, 1, "column half of derefs queued behind the row half on the background stream")           \
   X(SHARD_RESIDUE_TRANSPORT, "shard.residue_transport", 0, 0, 1, 1, "residue-shard every sum-check over multi-process transports (= shard.residue_min_log2 0)") \
   X(SHARD_CUBIC_MIN_LEN, "shard.cubic_min_len", 0, 0, 1073741824, 1, "batched cubic sum-checks stay sharded while a bind leaves at least this many entries (a power of two >= 32; 0 = twice sumcheck.double_round_max_len)") \
-  X(HOST_INVERT_CHAIN, "host.invert_chain", 0, 0, 1, 1, "challenge inversion by the addition chain instead of division steps")               \
   X(HOST_CALLSTATS, "host.callstats", 0, 0, 1, 1, "PROC. per-entry-point wall time on stderr at exit")                                        \
   X(DEBUG_KTIME, "debug.ktime", 0, 0, 1, 1, "SP_KTIME builds: in-kernel time stamps")
 

@@ -393,6 +393,20 @@ void spz_merlin_challenge_from_state(uint8_t state[203], const char* label, uint
   t.challenge_bytes(label, out, n);
   t.export_state(state);
 }
+// The probe of the coarse Rust binding (rust_shim/src/gpu_tail.rs.in, transcript_state / set_transcript_state): that binding reads and writes
+// merlin::Transcript's private state through the struct's memory, which `repr(Rust)` does not pin. Before its first use the Rust side runs
+// this fixed script on its own merlin transcript — Transcript::new(b"spartan_amd binding probe"), append_message(b"probe-message", 0..63) —
+// exports it through the raw copy and compares the 203 bytes with out_state; then it imports out_state into a fresh merlin transcript
+// through the raw write and compares challenge_bytes(b"probe-challenge", 32) with out_challenge. A field order or padding that differs
+// from {state[200], pos, pos_begin, cur_flags} fails one of the two, in release builds too.
+void spz_transcript_probe(uint8_t out_state[203], uint8_t out_challenge[32]) {
+  Transcript t("spartan_amd binding probe");
+  uint8_t msg[64];
+  for (int i = 0; i < 64; i++) msg[i] = (uint8_t)i;
+  t.append_message("probe-message", msg, 64);
+  t.export_state(out_state);
+  t.challenge_bytes("probe-challenge", out_challenge, 32);
+}
 void spz_tape_draws(const uint64_t seed[4], const char* label, size_t n, uint64_t* out) {
   Fq s;
   memcpy(s.l, seed, 32);

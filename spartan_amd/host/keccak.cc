@@ -147,7 +147,7 @@ static double keccak_time(keccak_fn f) {  // ns per permutation, best of three s
   return best + (st[0] == 1 ? 1e-9 : 0);  // keep the result alive
 }
 struct sp_ctx;
-extern "C" int sp_ctx_get_option(const sp_ctx* ctx, const char* key, long long* value);  // include/spartan_hip.h (int32_t / int64_t there)
+#include "../../include/spartan_hip.h"  // sp_ctx_get_option
 static KeccakChoice keccak_pick() {
   KeccakChoice cands[3];
   int n = 0;
@@ -157,7 +157,7 @@ static KeccakChoice keccak_pick() {
   if (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) cands[n++] = {keccak_f1600_bmi, "bmi2"};
   if (__builtin_cpu_supports("avx512f")) cands[n++] = {keccak_f1600_avx512, "avx512"};
 #endif
-  long long want = 0;  // process-wide library option host.keccak: 0 = by calibration, 1 plain, 2 bmi2, 3 avx512 (ignored if this CPU cannot run it)
+  int64_t want = 0;  // process-wide library option host.keccak: 0 = by calibration, 1 plain, 2 bmi2, 3 avx512 (ignored if this CPU cannot run it)
   if (sp_ctx_get_option(nullptr, "host.keccak", &want) == 0 && want >= 1 && want <= 3) {
     static const char* names[4] = {"", "plain", "bmi2", "avx512"};
     for (int i = 0; i < n; i++) if (!strcmp(names[want], cands[i].name)) return cands[i];

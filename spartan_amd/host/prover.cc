@@ -875,7 +875,6 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
   DotProductProofLog p;
   Fq blind_hat, r;
   CP Cy;
-  const bool invert_chain = ctx_opt(c, "host.invert_chain") != 0;
   try {
     t.append_point("Cx", Cx.data());
     Cy = commit_scalar(c, y, blind_y, g1);
@@ -893,9 +892,9 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
       t.append_point("R", R.data());
       u = t.challenge_scalar("u"); }
       { HSPAN("ipa_invert");
-      // u is a public challenge: division steps (fq_inv.hpp, ~1 us) instead of the a^(q-2) chain (~6 us), same value
-      const bool chain = invert_chain;  // A/B switch (option host.invert_chain, read once per argument)
-      u_inv = chain ? fq_invert(u) : fq_invert_vartime(u); }
+      // u is a public challenge: division steps (fq_inv.hpp, ~1 us) instead of the a^(q-2) chain (~6 us), same value (checked against
+      // the chain in tests/test_host_arith.py)
+      u_inv = fq_invert_vartime(u); }
       SPX(sp_ipa_round_fold(ipa, U(u), U(u_inv)));
       blind_hat = blind_hat + v1[k] * u * u + v2[k] * u_inv * u_inv;
       p.bullet.L_vec.push_back(L);

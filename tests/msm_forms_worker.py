@@ -1,6 +1,5 @@
 """Worker of tests/test_gpu_kernels.py::test_row_msm_forms_match_oracle: the row MSM's launch form is chosen once per process
-(msm.form = 0, the default: the queue form of msm_queue.hip for launches of >= 256 rows; msm.form = 3 with option msm.flat = 0 strip form / 1 balanced, rolled / 2 balanced, two entries in flight; msm.flat_bg = 1: the balanced background
-form; msm.form = 1 with msm.lds_bits = 10: the LDS-staged small-window form — all through SPARTAN_OPTIONS), so every form runs in a process of its own. Shapes that only these plans select, each against the oracle's orc_commit_rows:
+(msm.form = 0, the default: the queue form of msm_queue.hip for launches of >= 256 rows; msm.form = 3: the strip form and the balanced form with two entries in flight, chosen per launch; msm.form = 1 with msm.lds_bits = 10: the LDS-staged small-window form — all through SPARTAN_OPTIONS), so every form runs in a process of its own. Shapes that only these plans select, each against the oracle's orc_commit_rows:
 blinds (an extra column that starts or ends a run in the middle of a scalar), rows of zeros, short scalars (the early exit of the strip form
 and the ballot skip of the balanced form: SNARK::encode's addresses and timestamps, src/sparse_mlpoly.rs:483-503), scalars with only high
 bits set (carries into the top window), a run boundary inside the signed recoding's carry chain, and the background kernel."""

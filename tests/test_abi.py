@@ -132,7 +132,7 @@ def test_option_table_and_tiers():
     import subprocess, sys
     from spartan_amd import capi
     table = capi.options_table()
-    assert len(table) >= 40 and len({k for k, *_ in table}) == len(table)
+    assert 30 <= len(table) <= 40 and len({k for k, *_ in table}) == len(table)   # (51 at the start of round 6: the A/B switches of paths that lost every comparison since round 3 went with their kernels)
     for key, default, lo, hi, tier, doc in table:
         assert lo <= default <= hi and tier in (0, 1) and len(doc) > 10, key
     code = r"""
@@ -148,6 +148,11 @@ assert L.sp_ctx_get_option(None, b"spark.eq_factor", ctypes.byref(v)) == 0 and v
 assert L.sp_ctx_set_option(None, b"testing.unlock", b"1") == 0 and L.sp_ctx_set_option(None, b"spark.eq_factor", b"0") == 0
 assert L.sp_ctx_get_option(None, b"spark.eq_factor", ctypes.byref(v)) == 0 and v.value == 0
 assert L.sp_ctx_get_option(None, b"bg.eighths", ctypes.byref(v)) == 0 and v.value == 6      # from SPARTAN_OPTIONS
+# values inside the range that no kernel supports are refused, not silently accepted (ADVICE r5: msm.lds_bits = 5 gave wrong commitments)
+for bad in (b"1", b"4", b"5"):
+    assert L.sp_ctx_set_option(None, b"msm.lds_bits", bad) == -1
+assert L.sp_ctx_set_option(None, b"msm.lds_bits", b"6") == 0 and L.sp_ctx_set_option(None, b"msm.lds_bits", b"0") == 0
+assert L.sp_ctx_set_option(None, b"msm.q_waves", b"5") == -1 and L.sp_ctx_set_option(None, b"msm.q_waves", b"8") == 0
 print("OPTIONS_OK")
 """ % ROOT
     env = dict(os.environ, SPARTAN_OPTIONS="bg.eighths=6")

@@ -452,16 +452,16 @@ def test_dot3_many_matches_reference_arithmetic(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opts,count", [({"msm__form": 3, "msm__flat": 0}, 11), ({"msm__form": 3, "msm__flat": 1}, 11), ({"msm__form": 3, "msm__flat": 2}, 11),
-                                        ({"msm__form": 3, "msm__flat": 2, "msm__flat_bg": 1}, 11), ({"msm__form": 3, "msm__flat": 2, "msm__wbits": 13, "msm__flat_rounds": 3}, 11),
+@pytest.mark.parametrize("opts,count", [({"msm__form": 3}, 11), ({"msm__form": 3, "msm__wbits": 13, "bg__eighths": 3}, 11),
                                         ({"msm__lds_bits": 10, "msm__form": 1}, 23), ({"msm__lds_bits": 8, "msm__form": 1, "bg__eighths": 3}, 23),
-                                        ({}, 27), ({"msm__form": 2, "msm__q_coresident": 0, "msm__q_depth": 3, "msm__q_waves": 8, "msm__q_bg_waves": 4, "msm__q_units": 4, "msm__wbits": 12, "bg__eighths": 6}, 27),
+                                        ({"msm__lds_bits": 6, "msm__form": 1}, 23), ({"msm__lds_bits": 7, "msm__form": 1, "msm__wbits": 12}, 23),
+                                        ({}, 27), ({"msm__form": 2, "msm__q_waves": 8, "msm__q_bg_waves": 4, "msm__q_units": 4, "msm__wbits": 12, "bg__eighths": 6}, 27),
                                         ({"msm__q_waves": 4, "msm__q_bg_waves": 12, "msm__q_units": 100, "msm__wbits": 15}, 27)])
 def test_row_msm_forms_match_oracle(opts, count):
     """Every launch form of the fixed-base row MSM (DensePolynomial::commit_inner, src/dense_mlpoly.rs:164-177) against the oracle: the strip
-    form with its short-scalar early exit, the balanced (column, window) form rolled and with two entries in flight, its background
-    variant, another window width with three rounds of workgroups, and the LDS-staged small-window form (msm_lds.hip: 10-bit sub-tables
-    double-buffered in LDS; 8-bit ones on another background share) with shapes of its own — row-blocks that are not a multiple of a
+    form with its short-scalar early exit (many row-blocks, the persistent background launch), the balanced (column, window) form with two
+    entries in flight, another window width and background share, and the LDS-staged small-window form (msm_lds.hip: 10-bit sub-tables
+    double-buffered in LDS; 8-, 7- and 6-bit ones — every width the option accepts since ADVICE r5) with shapes of its own — row-blocks that are not a multiple of a
     wavefront, two and three row-blocks, runs that start inside a scalar, the persistent background form — and the queue form (k_msm_q, the
     default since round 6: self-contained wavefronts with private LDS rings pulling runs from per-row-group queues) on the same shapes plus four
     of its own, co-resident and on a fenced share of the CUs, with items of 4, 32 and 100 units. The form is an option of the

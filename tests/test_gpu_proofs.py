@@ -479,9 +479,9 @@ def test_every_ab_switch_gives_the_same_proof(orc):
     move a piece of work between the proving core and the device) must give the oracle's bytes, and so must the tier-0 ones that change
     launch plans: the eq table as a factor vs bound like any table, hash layers fused with the first multiplication layer vs separate,
     dedicated vs unified addition in the inner-product trees, the end of the inner-product arguments on the proving core vs on the device,
-    challenge inversion by division steps vs the a^(q-2) chain, each Keccak-f form, the proof gate, one- vs two-round trips, the host tail,
-    the kernel-raised completion flag, inline kernel arguments, the upload thread and chunks, the overlap placements, every row-MSM form
-    including the LDS-staged one. One process per setting (tests/switch_worker.py, SPARTAN_OPTIONS) at 2^17 — the smallest size with
+    each Keccak-f form, the proof gate, one- vs two-round trips, the host tail, inline kernel arguments, the upload thread and chunks,
+    the overlap placements, every row-MSM form: the queue form (the default) in three shapes, the strip / balanced forms it replaced for
+    large commits, the LDS-staged one. One process per setting (tests/switch_worker.py, SPARTAN_OPTIONS) at 2^17 — the smallest size with
     throughput-sized batched rounds — against the oracle's proof of the same instance and tape. The test also checks that no tier-1 option
     of the table is left out of the list."""
     import hashlib, os, subprocess, sys
@@ -496,15 +496,15 @@ def test_every_ab_switch_gives_the_same_proof(orc):
     want = hashlib.sha256(oracle_bytes(orc, op)).hexdigest()
     from tests.helpers import options_env
     from spartan_amd import capi
-    settings = [{}, {"spark.eq_factor": 0}, {"spark.hash_fuse": 0}, {"ipa.unified_tree": 1}, {"ipa.finish_device": 1}, {"host.invert_chain": 1},
+    settings = [{}, {"spark.eq_factor": 0}, {"spark.hash_fuse": 0}, {"ipa.unified_tree": 1}, {"ipa.finish_device": 1},
                 {"host.keccak": 1}, {"host.keccak": 2}, {"host.keccak": 3}, {"host.proof_gate": 1},
-                {"spark.eq_factor": 0, "spark.hash_fuse": 0, "ipa.unified_tree": 1, "ipa.finish_device": 1, "host.invert_chain": 1},
-                {"sync.kernel_signal": 0, "sumcheck.inline_args": 0, "msm.fused_tree": 0}, {"ipa.fused": 0}, {"encode.device": 1}, {"commit.small_device": 1},
+                {"spark.eq_factor": 0, "spark.hash_fuse": 0, "ipa.unified_tree": 1, "ipa.finish_device": 1},
+                {"sumcheck.inline_args": 0}, {"ipa.fused": 0}, {"encode.device": 1}, {"commit.small_device": 1},
                 {"sumcheck.double_round_max_len": 0, "sumcheck.host_tail": 0}, {"sumcheck.double_round_max_len": 512},
                 {"spark.prod_layer2": 0}, {"spark.prod_layer2_max_log2": 14}, {"upload.overlap": 0, "upload.thread": 0}, {"upload.chunks": 2},
-                {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"overlap.col_half": 1, "bg.eighths": 4}, {"bg.eighths": 0},
-                {"msm.form": 3}, {"msm.form": 3, "msm.flat": 0, "msm.prefetch": 1}, {"msm.form": 3, "msm.flat": 1, "msm.flat_bg": 1, "msm.flat_rounds": 2}, {"msm.form": 3, "msm.strip_threads": 131072, "msm.flat": 0},
-                {"msm.q_coresident": 0, "msm.q_waves": 8, "msm.q_depth": 3, "msm.q_bg_waves": 12, "msm.q_units": 16}, {"msm.q_bg_waves": 4, "msm.q_units": 128, "bg.eighths": 0},
+                {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"bg.eighths": 4}, {"bg.eighths": 0},
+                {"msm.form": 3}, {"msm.form": 3, "bg.eighths": 3, "upload.chunks": 1},
+                {"msm.q_waves": 8, "msm.q_bg_waves": 12, "msm.q_units": 16}, {"msm.q_bg_waves": 4, "msm.q_units": 128, "bg.eighths": 0},
                 {"msm.lds_bits": 10, "msm.form": 1}, {"msm.lds_bits": 9, "msm.form": 1, "overlap.derefs": 0}, {"msm.wbits": 11}]
     covered = {k for st in settings for k in st}
     not_proof_shaping = {"ipa.rerun_exceptional", "ipa.dedicated_uploaded", "shard.residue_transport", "shard.cubic_min_len", "host.callstats", "debug.ktime"}  # their own tests (test_gpu_large, test_gpu_shard) / diagnostics

@@ -117,6 +117,25 @@ def test_transcript_state_export_import_matches_oracle(H, orc):
         assert bytes(oa) == tail and bytes(ob) == tail and bytes(a) == bytes(b)  # the states after the draw agree too
 
 
+def test_coarse_binding_probe_is_the_script_it_says(H, orc):
+    """spz_transcript_probe (host_capi.cc) is the C half of the coarse Rust binding's layout self-check (rust_shim/src/gpu_tail.rs.in,
+    `layout_checked`: the binding reads merlin::Transcript's private state through the struct's memory and must not trust `repr(Rust)`):
+    the state it returns is the state of Transcript::new(b"spartan_amd binding probe") + append_message(b"probe-message", 0..63) — equal to
+    the oracle's independent transcript on the same script — and the challenge is what that transcript draws next. The Rust side panics,
+    in release builds too, unless merlin gives the same 203 bytes through the raw copy and the same challenge through the raw write."""
+    st, ch = (ctypes.c_uint8 * 203)(), (ctypes.c_uint8 * 32)()
+    H.spz_transcript_probe(st, ch)
+    ops = [(0, b"probe-message", bytes(range(64)))]
+    want = _state(orc, "orc_merlin_state", b"spartan_amd binding probe", ops)
+    assert bytes(st) == bytes(want) and bytes(st) == bytes(_state(H, "spz_merlin_state", b"spartan_amd binding probe", ops))
+    oc = (ctypes.c_uint8 * 32)()
+    orc.orc_merlin_challenge_from_state(want, b"probe-challenge", oc, sz(32))
+    assert bytes(ch) == bytes(oc)
+    assert st[200] != 0 or st[201] != 0 or st[202] != 0   # the three position / flag bytes are live in this state: a reordered struct cannot pass
+    src = open(os.path.join(ROOT, "rust_shim", "src", "gpu_tail.rs.in")).read()
+    assert "spz_transcript_probe" in src and "debug_assert" not in src and src.count("layout_checked();") == 2
+
+
 def _zlib6(H, data, old=0):
     H.spz_zlib_level6.restype = sz
     cap = 2 * len(data) + 1024
