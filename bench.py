@@ -272,7 +272,7 @@ def side_metrics(P, ctx, inst, gens, N, s, tape_seed, steps):
         busy = union_ms([(a, b) for _r, _c, _bg, a, b, _i in sp_])
         scal = sum(r * c for r, c, _bg, _a, _b, _i in sp_); rows = sum(r for r, _c, _bg, _a, _b, _i in sp_)
         issued = sum(i for *_x, i in sp_)
-        nwin = -(-254 // gens.window_bits(1))
+        nwin = gens.windows(1)
         byts = 32.0 * scal + 32.0 * rows
         out["snark_encode"]["roofline"] = {
             "bound": "hbm", "kernel": "msm_rows_fixed (multi_commit of comb_ops and comb_mem)", "launches": [f"{r} x {c}" for r, c, *_x in sp_],
@@ -432,7 +432,7 @@ def main():
         sh = (ctypes.c_uint64 * cap)(); ms = (ctypes.c_double * cap)(); nl = (ctypes.c_uint64 * cap)(); by = (ctypes.c_double * cap)(); ops = (ctypes.c_double * cap)()
         k = capi.lib.sp_prof_read_shapes(raw, family.encode(), sh, ms, nl, by, ops, ctypes.c_int(cap))
         return [{"rows": (int(sh[i]) >> 32) & 0x7fffffff, "cols": int(sh[i]) & 0xffffffff, "background": bool(int(sh[i]) >> 63), "ms": ms[i],
-                 "launches": int(nl[i]), "alg_bytes": by[i]} for i in range(min(k, cap))]
+                 "launches": int(nl[i]), "alg_bytes": by[i], "alg_ops": ops[i]} for i in range(min(k, cap))]
 
     def read_spans(family):
         cap = 4096
@@ -466,6 +466,12 @@ def main():
     proof = step()
     capi.lib.sp_prof_enable(raw, ctypes.c_int(0))
     breakdown = read_prof()
+    fq_big = {}   # throughput-sized launches (>= 64 MB of algorithmic bytes) of the F_q families, from the same instrumented step
+    for name in breakdown:
+        if name != "msm_rows_fixed":
+            for e_ in read_shapes(name):
+                if e_["rows"] == 0x40000000 and e_["cols"] == 1:   # the pseudo-shape 0x4000000000000001 (include/spartan_hip.h)
+                    fq_big[name] = e_
     dom = max(breakdown, key=lambda n: breakdown[n]["ms"])
     capi.lib.sp_prof_reset(raw)
     if not os.environ.get("BENCH_NO_PROF"):
@@ -539,7 +545,7 @@ def main():
                     "note": "255-bit EC / 253-bit field integer work: VALU-bound by construction, the HBM fraction is reported as the contract asks; `alu` below is the roofline that can approach 1 (DESIGN.md, roofline)"}
         # ---- ALU roofline: mixed additions/s of each MSM launch shape against the pt_madd chain measured on this GPU
         wb_sat, wb_eval = gens.window_bits(0), gens.window_bits(1)
-        nwin_of = {False: -(-254 // wb_sat), True: -(-254 // wb_eval)}  # witness commit: gens_r1cs_sat stream; derefs: gens_r1cs_eval
+        nwin_of = {False: gens.windows(0), True: gens.windows(1)}  # witness commit: gens_r1cs_sat stream; derefs: gens_r1cs_eval (windows = additions per scalar; mixed widths since round 6)
         R = 1 << ((s + 3) - (s + 3) // 2)   # columns of the derefs commitment (2^(s+3) entries, dense_mlpoly.rs:188-191)
         named = {}
         if s >= 6:
@@ -608,17 +614,21 @@ def main():
         roofline["alu"]["frac_family"] = roofline["alu"]["frac"]
         # F_q streaming kernels (the HBM-shaped part): multiplications/s against the fq_mul chain ceiling, bytes/s against HBM
         fq = {}
-        for name in ("sumcheck_eval", "sumcheck_bind_eval", "vecmat", "dot"):
+        for name in ("sumcheck_eval", "sumcheck_bind_eval", "vecmat", "dot", "spark", "sparse", "eq_expand"):
             if name in breakdown and breakdown[name]["ms"] > 0:
                 b_ = breakdown[name]
-                e = {"ms_per_step": round(b_["ms"], 4), "launches": b_["launches"], "GB_per_s": round(b_["alg_bytes"] / b_["ms"] / 1e6, 1),
-                     "G_fq_mul_per_s": round(b_["alg_ops"] / b_["ms"] / 1e6, 2)}
-                if ceil:
-                    e["frac_of_fq_mul_ceiling"] = round(e["G_fq_mul_per_s"] / ceil["fq_mul_G_per_s"], 3)
-                e["frac_of_hbm_peak"] = round(e["GB_per_s"] / HBM_PEAK_GBS, 4)
-                fq[name] = e
+                def part(ms, n, by, ops):
+                    if not n or ms <= 0: return None
+                    e_ = {"ms_per_step": round(ms, 4), "launches": int(n), "GB_per_s": round(by / ms / 1e6, 1), "frac_of_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                    if ops:
+                        e_["G_fq_mul_per_s"] = round(ops / ms / 1e6, 2)
+                        if ceil: e_["frac_of_fq_mul_ceiling"] = round(e_["G_fq_mul_per_s"] / ceil["fq_mul_G_per_s"], 3)
+                    return e_
+                big = fq_big.get(name)
+                bm, bn, bb, bo = (big["ms"], big["launches"], big["alg_bytes"], big.get("alg_ops", 0.0)) if big else (0.0, 0, 0.0, 0.0)
+                fq[name] = {"throughput_sized": part(bm, bn, bb, bo), "launch_sized": part(b_["ms"] - bm, b_["launches"] - bn, b_["alg_bytes"] - bb, b_["alg_ops"] - bo)}
         roofline["fq_kernels"] = {"ceiling_G_fq_mul_per_s": ceil["fq_mul_G_per_s"] if ceil else None, "families": fq,
-                                  "note": "whole families, launch-sized rounds included (most launches of a proof are latency-bound: ~400 rounds on tables that halve every round)"}
+                                  "note": "each family split into its throughput-sized launches (>= 64 MB of algorithmic bytes: the first rounds of the large layers) and the launch-sized rest (most of a proof's ~400 rounds run on tables that halve every round: latency-bound, their GB/s says nothing); per kernel and launch size with PMC bytes: profiles/r6_fq_bandwidth_2p20.txt / _2p22.txt"}
 
     if rank == 0:
         gpu_ms_total = sum(v["ms"] for v in breakdown.values())
@@ -645,7 +655,7 @@ def main():
                        "bit_exact_against": "the in-repo oracle (oracle/: CPU restatement of the reference prover, pinned to RFC 9496 / Merlin / reference F_q vectors; no libspartan run exists here)",
                        "fs_trips_per_proof": fs_trips,
                        "table_GB": {"gens_r1cs_sat": round(gens.table_bytes(0) / 1e9, 2), "gens_r1cs_eval": round(gens.table_bytes(1) / 1e9, 2),
-                                    "window_bits": [gens.window_bits(0), gens.window_bits(1)]},
+                                    "window_bits": [gens.window_bits(0), gens.window_bits(1)], "windows": [gens.windows(0), gens.windows(1)]},
                        "host_cores_busy": world, "host_note": "each proving thread spins on its completion flag and runs Merlin, the 2..5-term Sigma-protocol commitments, ~150 point encodes (in pairs), the challenge inversions and the end of every inner-product argument: one host core per GPU, flat out; a helper thread computes the tape-only halves of the ZK sum-checks' commitments ahead of the rounds (~0.5 ms of a second core per proof), another issues the witness upload",
                        "host_keccak": P.keccak_variant()},
             "roofline": roofline,

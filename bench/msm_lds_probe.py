@@ -37,7 +37,7 @@ for name, label, rows, cols, blind in shapes:
             out = g.commit_rows(t, rows, cols, bl, 0, cols)
             best = min(best, time.time() - t0)
         outs[form] = out
-        nwin = -(-254 // (LB if form == "lds" else g.window_bits()))
+        nwin = -(-254 // LB) if form == "lds" else g.windows()
         madds = rows * (cols + (1 if blind else 0)) * nwin
         print("2^%d %-13s %5d x %5d  %-4s  %2d adds/scalar  %.3f ms  %.2f G madd/s  (set built in %.2f s, wide %d bits)" %
               (s, name, rows, cols, form, nwin, best * 1e3, madds / best / 1e9, t_build, g.window_bits()), flush=True)

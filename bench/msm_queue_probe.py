@@ -30,7 +30,7 @@ for key, name, label, rows, cols, blind in shapes:
     if blind:
         bz = rng.integers(0, 2**64, size=(rows, 4), dtype=np.uint64); bz[:, 3] &= np.uint64((1 << 60) - 1)
         bl = bz.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
-    nwin = -(-254 // g.window_bits())
+    nwin = g.windows()
     madds = rows * (cols + (1 if blind else 0)) * nwin
     ref = None
     def run(tag):

@@ -77,7 +77,8 @@ int32_t sp_prof_read(sp_ctx* ctx, const char** names, double* total_ms, uint64_t
  * additions of the MSM kernels assuming non-zero scalars): the numerators of the ALU roofline. */
 int32_t sp_prof_read_ops(sp_ctx* ctx, double* alg_ops, int cap);
 /* Per-launch-shape totals inside one family (msm_rows_fixed: shape = rows << 32 | cols, bit 63 set for launches on the
- * background stream): returns the number of shapes seen, fills up to cap entries. */
+ * background stream; every other family: one pseudo-shape 0x4000000000000001 that sums its THROUGHPUT-SIZED launches, those with >= 64 MB
+ * of algorithmic bytes, so that they can be reported apart from the launch-sized ones): returns the number of shapes seen, fills up to cap. */
 int32_t sp_prof_read_shapes(sp_ctx* ctx, const char* family, uint64_t* shape, double* total_ms, uint64_t* launches, double* alg_bytes,
                             double* alg_ops, int cap);
 /* The same launches as intervals [t0, t1) in ms on one clock (zero = the first sp_prof_enable of the context), in the order they were
@@ -115,7 +116,8 @@ int32_t sp_gens_upload(sp_ctx* ctx, const uint8_t* compressed /*32*n*/, size_t n
 int32_t sp_gens_from_uniform(sp_ctx* ctx, const uint8_t* uniform /*64*n*/, size_t n, uint8_t* compressed_out, sp_gens** out);
 size_t sp_gens_len(const sp_gens* g);
 size_t sp_gens_table_bytes(const sp_gens* g); /* HBM held by the window tables of this set */
-int sp_gens_window_bits(const sp_gens* g); /* the width c the tables of this set were built with */
+int sp_gens_window_bits(const sp_gens* g); /* the width c of the (narrow) windows the tables of this set were built with */
+int sp_gens_windows(const sp_gens* g);     /* windows per scalar = mixed additions per committed scalar (17 .. 32; the top windows may be one bit wider than c) */
 void sp_gens_free(sp_gens* g);
 
 /* ---- Pedersen commitments (src/commitments.rs:73-92, src/dense_mlpoly.rs:164-177, src/group.rs:98-117) --

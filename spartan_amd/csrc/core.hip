@@ -99,6 +99,10 @@ void prof_drain(sp_ctx* c) {
       }
       else (void)hipGetLastError();
     }
+    else if (r.bytes >= 64e6) {  // the throughput-sized launches of the other families (>= 64 MB of algorithmic traffic) as one "shape" of their own:
+      ProfShape& ps = c->prof_shapes[std::make_pair(r.fam, PROF_SHAPE_BIG)];  // bench.py reports them apart from the launch-sized ones
+      ps.ms += ms; ps.n += 1; ps.bytes += r.bytes; ps.ops += r.ops;
+    }
     c->free_events.push_back(r.e0);
     c->free_events.push_back(r.e1);
   }
@@ -198,15 +202,17 @@ __global__ void k_points_load(const uint8_t* __restrict__ in, int mode, size_t n
 // stage 2: one thread per (point, window, chunk of up to 128 magnitudes): entries k * 2^(c w) * P in affine Niels form.
 template <class E>  // E = Niels (one entry per 128-byte line: the gathered wide-window tables) or NielsP (packed: the streamed LDS-form tables)
 __global__ void k_table_build(const Pt* __restrict__ pts, size_t n, E* __restrict__ table, MsmGeom geom) {
+  // chunks of a point run over its windows in order; a wide window (msm.hpp, mixed widths) is two narrow windows' worth of chunks
   const int chunk = geom.tent < 128 ? geom.tent : 128, nchunk = geom.tent / chunk;
+  const size_t per_pt = (size_t)(geom.nwin + geom.nwide) * nchunk;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * geom.nwin * nchunk) return;
-  int ck = (int)(t % nchunk);
-  size_t pw = t / nchunk;
-  size_t pt = pw / geom.nwin;
-  int w = (int)(pw % geom.nwin);
+  if (t >= n * per_pt) return;
+  size_t pt = t / per_pt;
+  const int slot = (int)((t % per_pt) / nchunk), n0 = msm_n0(geom);   // slot: narrow-window-sized piece of the point's table
+  const int w = slot < n0 ? slot : n0 + (slot - n0) / 2;
+  int ck = (int)(t % nchunk) + (slot >= n0 && ((slot - n0) & 1) ? nchunk : 0);
   Pt base = pts[pt];
-  for (int k = 0; k < geom.wbits * w; k++) base = pt_dbl(base);
+  for (int k = 0; k < msm_bitpos(geom, w); k++) base = pt_dbl(base);
   // first multiple of this chunk: (ck * chunk + 1) * base by double-and-add
   int m0 = ck * chunk + 1;
   Pt acc = pt_identity();
@@ -318,8 +324,7 @@ struct MsmDigitStream {
     s0 = s.l[0]; s1 = s.l[1]; s2 = s.l[2]; s3 = s.l[3];
     carry = 0;
   }
-  __device__ __forceinline__ void shift() {
-    const int c = A.geom.wbits;
+  __device__ __forceinline__ void shift(int c) {
     s0 = (s0 >> c) | (s1 << (64 - c));
     s1 = (s1 >> c) | (s2 << (64 - c));
     s2 = (s2 >> c) | (s3 << (64 - c));
@@ -336,13 +341,14 @@ struct MsmDigitStream {
     set_base(j);
     if (AHEAD) raw_next = j + 1 < ncol ? ld_fq(scalar_ptr(j + 1)) : fq_zero();
     for (int k = 0; k < w; k++) {  // the carry into window w depends on all lower windows
-      int d = (int)(s0 & ((1u << A.geom.wbits) - 1)) + carry;
-      carry = d >= A.geom.tent;
-      shift();
+      const int c = msm_wbits_of(A.geom, k);
+      int d = (int)(s0 & ((1u << c) - 1)) + carry;
+      carry = d >= (1 << (c - 1));
+      shift(c);
     }
   }
   __device__ __forceinline__ void next(MsmUnit& u) {
-    const int nwin = A.geom.nwin, c = A.geom.wbits;
+    const int nwin = A.geom.nwin;
     for (;;) {
       if (left == 0) { u.p = base; u.neg = false; u.nz = false; u.valid = false; return; }
       if (w == nwin) {
@@ -365,13 +371,14 @@ struct MsmDigitStream {
       }
       break;
     }
+    const int c = msm_wbits_of(A.geom, w);
     int d = (int)(s0 & ((1u << c) - 1)) + carry;
-    carry = d >= A.geom.tent;
+    carry = d >= (1 << (c - 1));
     d -= carry << c;
     uint32_t m = (uint32_t)(d < 0 ? -d : d);
-    u.p = base + (size_t)w * A.geom.tent + (m ? m - 1 : 0);
+    u.p = base + msm_woff(A.geom, w) + (m ? m - 1 : 0);
     u.neg = d < 0; u.nz = m != 0; u.valid = true;
-    shift();
+    shift(c);
     w++; left--;
   }
 };
@@ -1225,6 +1232,7 @@ int32_t sp_prof_read_shapes(sp_ctx* c, const char* family, uint64_t* shape, doub
 }
 int sp_msm_window_bits(void) { return MSM_WBITS; }
 int sp_gens_window_bits(const sp_gens* g) { return g ? g->geom.wbits : 0; }
+int sp_gens_windows(const sp_gens* g) { return g ? g->geom.nwin : 0; }
 int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap) {
   if (!c) return SP_EINVAL;
   prof_drain(c);
@@ -1242,7 +1250,8 @@ int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* 
 // they are built once per (device, generator bytes) and shared by every context of the process — concurrent proving
 // contexts on one GPU hold one copy, and re-creating a SNARKGens is free. Reference-counted; freed with the last handle.
 struct GensCacheEntry {
-  int dev, mode, wbits;
+  int dev, mode;
+  MsmGeom geom;
   size_t n, refs;
   std::vector<uint8_t> in, comp;
   Niels* table;
@@ -1253,42 +1262,43 @@ struct GensCacheEntry {
 static std::mutex g_gens_mu;
 static std::list<GensCacheEntry> g_gens_cache;
 
-// Window width of a generator set. The table of a set is n points x ceil(254/c) windows x 2^(c-1) entries x 128 B (96 bytes of values
-// per 128-byte line, curve.hpp); wider windows mean fewer mixed additions per committed scalar (17 at 15 bits, 19 at 14, 20 at 13) and
-// every LAUNCH is shortest at the widest width — the PROOF is not necessarily: swept at 2^20 (profiles/r2_window_width_sweep.txt, and
-// again in round 4 with line-aligned entries) 15 bits for the 1025-point stream and 14 bits for the 4098-point one tie with 15 / 15 and
-// hold 65 GB less. So the width is chosen by proof time, not by launch time:
-//   * 15 bits while the set's table stays under SPARTAN_MSM_WIDE_GB (default 80: the 2049-point stream of a 2^22 instance, 73 GB, keeps
-//     them, the 4098-point one of 2^20, 146 GB, does not),
-//   * otherwise the widest of 14/13/12/10/8 that fits the budget SPARTAN_MSM_TABLE_GB (default 170 per set: the 8194-point stream of a 2^22
-//     instance at 14 bits is 163 GB),
-//   * and never more than the free device memory less a reserve for the proof's own tables (24 GB, applied only to
-//     tables that are themselves large: a 1.5 MB table set must not be refused because another process holds the HBM).
-// 2^20: 15 / 14 bits (36.5 + 81.6 GB); 2^22: 15 / 14 (73 + 163 GB of the 288); 2^24: 14 / 12. SPARTAN_MSM_WBITS forces a width (the tests
-// use it to cover several). A width below the first choice is reported on stderr (once per set): a silent narrowing would be a
-// performance cliff nobody sees. Returns 0 when not even 8-bit tables fit in free memory.
-static int choose_wbits(const sp_ctx* c, size_t n) {
-  if (c->opt.v[OPT_MSM_WBITS] >= 4) return (int)c->opt.v[OPT_MSM_WBITS];
+// Window geometry of a generator set. A committed scalar costs one mixed addition (and one 128-byte gather) per window, so the policy
+// minimises the NUMBER of windows under a memory budget; for each number of windows the table is as small as 254 bits allow (mixed
+// widths, msm.hpp): per generator 17 windows = 34.6 MB, 18 = 21.0, 19 = 13.6, 20 = 8.9, 21 = 6.0, 22 = 4.5, 24 = 2.5, 26 = 1.5, 32 = 0.5.
+//   * 17 windows only while the set's tables stay under msm.wide_gb (default 80: the 1025- and 2049-point streams of a 2^20 / 2^22
+//     instance keep them; the proof time of 17 against 18 windows for the larger stream was a tie in rounds 2-4 and costs 56 GB);
+//   * otherwise the fewest windows that fit msm.table_gb (default 180 per set: the 8194-point stream of a 2^22 instance at 18 windows is
+//     172 GB) and the free device memory less a reserve for the proof's own tables: 24 GB, or 2.2e-7 GB x n^2 when that is more — the
+//     working set of a proof grows with the square of its larger generator stream (59 GB for the 16386 points of a 2^24 instance); applied
+//     only to tables that are themselves large (a 1.5 MB table set must not be refused because another process holds the HBM).
+// 2^20: 17 / 18 windows (35.5 + 86.1 GB; rounds 2-5: uniform 15 / 14 bits = 17 / 19 windows, 36.6 + 81.6 GB); 2^22: 17 / 18 (70.9 + 172 GB;
+// before 17 / 19, 73 + 163); 2^24: 18 / 21 (86 + 99 GB; before 14 / 12 bits = 19 / 22 windows, 82 + 95). Option msm.windows forces a
+// number of windows, msm.wbits a uniform width (the tests use both). Fewer windows than the first choice are reported on stderr (once per
+// set): a silent narrowing would be a performance cliff nobody sees. Returns false when not even 32 windows fit in free memory.
+static bool choose_geom(const sp_ctx* c, size_t n, MsmGeom* out) {
+  if (c->opt.v[OPT_MSM_WBITS] >= 4) { *out = msm_geom((int)c->opt.v[OPT_MSM_WBITS]); return true; }
+  if (c->opt.v[OPT_MSM_WINDOWS] >= 17) { *out = msm_geom_windows((int)c->opt.v[OPT_MSM_WINDOWS]); return true; }
   const double budget = (double)c->opt.v[OPT_MSM_TABLE_GB], wide = (double)c->opt.v[OPT_MSM_WIDE_GB];
   size_t free_b = 0, total_b = 0;
   double free_gb = 1e9;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) free_gb = (double)free_b / 1e9;
   int first_choice = 0;  // what the policy picks when memory is no object
-  for (int cbits : {15, 14, 13, 12, 10, 8}) {
-    MsmGeom g = msm_geom(cbits);
+  for (int nw : {17, 18, 19, 20, 21, 22, 24, 26, 32}) {
+    MsmGeom g = msm_geom_windows(nw);
     double gb = (double)n * (double)g.pt_entries * sizeof(Niels) / 1e9;
-    if (cbits == 15 && gb > wide) continue;
+    if (nw == 17 && gb > wide) continue;
     if (gb > budget) continue;
-    if (!first_choice) first_choice = cbits;
-    double reserve = gb >= 1.0 ? 24.0 : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
-    if (gb + reserve <= free_gb || (cbits == 8 && gb * 1.05 <= free_gb)) {
-      if (cbits < first_choice)
-        fprintf(stderr, "spartan_hip: window tables of %zu generators narrowed from %d to %d bits (%.1f GB of device memory free): %d instead of %d additions per scalar\n",
-                n, first_choice, cbits, free_gb, msm_geom(cbits).nwin, msm_geom(first_choice).nwin);
-      return cbits;
+    if (!first_choice) first_choice = nw;
+    double reserve = gb >= 1.0 ? std::max(24.0, 2.2e-7 * (double)n * (double)n) : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
+    if (gb + reserve <= free_gb || (nw == 32 && gb * 1.05 <= free_gb)) {
+      if (nw > first_choice)
+        fprintf(stderr, "spartan_hip: window tables of %zu generators cut from %d to %d windows (%.1f GB of device memory free): %d instead of %d additions per scalar\n",
+                n, first_choice, nw, free_gb, nw, first_choice);
+      *out = g;
+      return true;
     }
   }
-  return 0;
+  return false;
 }
 const uint8_t* gens_compressed_bytes(const sp_gens* g, size_t* n) {
   const GensCacheEntry* e = (const GensCacheEntry*)g->cache_entry;
@@ -1304,13 +1314,13 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   for (auto& e : g_gens_cache)  // a resident table set serves every later handle on the same points, whatever width it was built with
     if (e.dev == c->dev && e.mode == mode && e.n == n && memcmp(e.in.data(), in, in_bytes) == 0) { hit = &e; break; }
   if (!hit) {
-    int wbits = choose_wbits(c, n);
-    if (wbits == 0) {
-      fprintf(stderr, "spartan_hip: no window-table width fits: %zu generators need at least %.2f GB of free device memory (8-bit windows)\n", n,
-              (double)n * (double)msm_geom(8).pt_entries * sizeof(Niels) / 1e9);
+    MsmGeom geom;
+    if (!choose_geom(c, n, &geom)) {
+      fprintf(stderr, "spartan_hip: no window tables fit: %zu generators need at least %.2f GB of free device memory (32 windows)\n", n,
+              (double)n * (double)msm_geom_windows(32).pt_entries * sizeof(Niels) / 1e9);
       return SP_ENOMEM;
     }
-    MsmGeom geom = msm_geom(wbits);
+    const int wbits = geom.wbits;
     // scratch layout: [in bytes][pad][Pt n][comp 32n][bad int]
     size_t off_pts = (in_bytes + 255) & ~(size_t)255;
     size_t off_comp = off_pts + n * sizeof(Pt);
@@ -1330,19 +1340,19 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
     // packed entries instead of 128-byte lines): the set then gets the packed tables too and its row commits take that form unless msm.form says otherwise.
     bool prefer_lds = false;
     // (not when msm.wbits forces the width: a caller that asks for 8- or 10-bit gathered tables gets them, and nothing outside its budget: ADVICE r5)
-    if (!lds_bits && wbits <= 10 && n >= 512 && c->opt.v[OPT_MSM_WBITS] < 4) { lds_bits = 10; prefer_lds = true; }
+    if (!lds_bits && geom.nwin >= 26 && n >= 512 && c->opt.v[OPT_MSM_WBITS] < 4 && c->opt.v[OPT_MSM_WINDOWS] < 17) { lds_bits = 10; prefer_lds = true; }
     if (lds_bits && hipMalloc((void**)&table_lds, n * msm_geom(lds_bits).pt_entries * sizeof(NielsP)) != hipSuccess) {
       (void)hipGetLastError();
       table_lds = nullptr;
       if (!prefer_lds) { (void)hipFree(table); return SP_ENOMEM; }   // asked for by option: an error; chosen by the policy: do without
       lds_bits = 0; prefer_lds = false;
     }
-    if (prefer_lds) fprintf(stderr, "spartan_hip: %zu generators with %d-bit gathered tables: row commitments of this set take the LDS-staged form (10-bit windows streamed through LDS)\n", n, wbits);
+    if (prefer_lds) fprintf(stderr, "spartan_hip: %zu generators with %d-window gathered tables: row commitments of this set take the LDS-staged form (10-bit windows streamed through LDS: the same 26 additions at a higher rate)\n", n, geom.nwin);
     {
       ProfScope ps(c, PF_GENS_TABLE, (double)n * geom.pt_entries * sizeof(Niels));
       hipLaunchKernelGGL(k_points_load, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, base, mode, n, (Pt*)(base + off_pts),
                          mode == 1 ? base + off_comp : (uint8_t*)nullptr, (int*)(base + off_bad));
-      size_t nt = n * geom.nwin * (size_t)(geom.tent < 128 ? 1 : geom.tent / 128);
+      size_t nt = n * (size_t)(geom.nwin + geom.nwide) * (size_t)(geom.tent < 128 ? 1 : geom.tent / 128);
       hipLaunchKernelGGL(k_table_build<Niels>, dim3((unsigned)((nt + 63) / 64)), dim3(64), 0, c->stream, (const Pt*)(base + off_pts), n, table, geom);
       if (lds_bits) {
         MsmGeom gl = msm_geom(lds_bits);
@@ -1360,7 +1370,8 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
       if (table_lds) (void)hipFree(table_lds);
       return rc != SP_OK ? rc : SP_EPOINT;
     }
-    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, wbits, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table, table_lds, lds_bits, prefer_lds});
+    (void)wbits;
+    g_gens_cache.push_back(GensCacheEntry{c->dev, mode, geom, n, 0, std::vector<uint8_t>(in, in + in_bytes), std::move(comp), table, table_lds, lds_bits, prefer_lds});
     hit = &g_gens_cache.back();
   }
   // a resident entry serves every later handle on the same points — but a context that asks for the LDS-staged form's tables must get them:
@@ -1400,7 +1411,7 @@ static int32_t gens_build(sp_ctx* c, const uint8_t* in, int mode, size_t n, uint
   g->ctx = c;
   g->n = n;
   g->table = hit->table;
-  g->geom = msm_geom(hit->wbits);
+  g->geom = hit->geom;
   g->derived = hit->mode == 1;
   g->prefer_lds = hit->prefer_lds;
   g->table_lds = hit->table_lds;

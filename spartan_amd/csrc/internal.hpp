@@ -46,6 +46,7 @@ struct ProfRec {
   uint64_t shape;  // launch shape inside the family (0 = not tracked): the MSM families key (rows, cols, background)
   double bytes, ops;
 };
+constexpr uint64_t PROF_SHAPE_BIG = 0x4000000000000001ULL;  // pseudo-shape: launches of an untracked family with >= 64 MB of algorithmic bytes
 struct ProfSpan { int fam; uint64_t shape; double t0, t1, issued; };  // one tracked launch on the context's clock (ms since prof_epoch)
 struct ProfShape {
   double ms = 0, bytes = 0, ops = 0;

@@ -39,7 +39,7 @@ struct MsmQArgs {
   unsigned nb, ngroups, len, S;  // runs per row; 64-row groups; units per run; partial-sum slots per row
   unsigned long long* issued;     // profiling runs: tiles issued by all wavefronts (x 64 = mixed additions actually performed: the ballot skips
                                   // the upper windows of short scalars), or null
-  int wbits, nwin, tent;
+  MsmGeom geom;   // window geometry of the set's tables (mixed widths: msm.hpp)
 };
 
 typedef __attribute__((address_space(3))) void* q_lds_ptr_t;
@@ -138,11 +138,9 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
     sel[i] = (int)((t / 6u) * 4u);
     poff[i] = (t % 6u) * 16u;
   }
-  const int nwin = A.nwin, c = A.wbits;
+  const int nwin = A.geom.nwin, n0 = msm_n0(A.geom);
   const size_t ncol = A.cols + (A.blinds ? 1 : 0);
   const size_t U = ncol * (size_t)nwin;
-  const uint32_t mask = (1u << c) - 1;
-  const size_t sub_bytes = (size_t)A.tent * sizeof(Niels);
   // this wavefront's walk over the row groups: position 0 is its home group (wavefronts are dealt to the groups round-robin), positions only
   // ever advance — a group it has left is exhausted, a group that had no slot for it is left to the wavefronts attached there
   const unsigned home = (blockIdx.x * nwaves + wave) % A.ngroups;
@@ -174,7 +172,7 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
     };
     auto col_base = [&](size_t jj) {  // the window tables of column jj's generator (wave-uniform)
       const size_t pt = jj < A.cols ? (A.idx ? (size_t)A.idx[jj] : A.g_off + jj) : A.h_idx;
-      return reinterpret_cast<const uint8_t*>(A.table + pt * (size_t)nwin * (size_t)A.tent);
+      return reinterpret_cast<const uint8_t*>(A.table + pt * A.geom.pt_entries);
     };
     Pt acc = pt_identity();
     for (;;) {
@@ -220,7 +218,7 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
         uint64_t s0 = s.l[0], s1 = s.l[1], s2 = s.l[2], s3 = s.l[3];
         int carry = 0;
         raw = j + 1 < ncol ? ld_scalar(j + 1) : fq_zero();
-        auto shift = [&]() {
+        auto shift = [&](int c) {
           s0 = (s0 >> c) | (s1 << (64 - c));
           s1 = (s1 >> c) | (s2 << (64 - c));
           s2 = (s2 >> c) | (s3 << (64 - c));
@@ -229,22 +227,24 @@ __global__ void __launch_bounds__(768) k_msm_q(MsmQArgs A) {
         int w = 0;
         if (j == j0)
           for (; w < w_first; w++) {  // a run may start inside a scalar: the carry into window w depends on all lower windows
-            int d = (int)(s0 & mask) + carry;
-            carry = d >= A.tent;
-            shift();
+            const int c = A.geom.wbits + (w >= n0 ? 1 : 0);
+            int d = (int)(s0 & ((1u << c) - 1)) + carry;
+            carry = d >= (1 << (c - 1));
+            shift(c);
           }
         const int w_end = j == j1 ? w_last : nwin;
         const uint8_t* cbase = col_base(j);
         for (; w < w_end; w++) {
           // nothing left in this scalar on any lane of the wavefront: no gathers for its upper windows (short scalars)
           if (__all((s0 | s1 | s2 | s3) == 0 && carry == 0)) break;
-          int d = (int)(s0 & mask) + carry;
-          carry = d >= A.tent;
+          const int c = A.geom.wbits + (w >= n0 ? 1 : 0);   // the top windows are one bit wider (mixed widths)
+          int d = (int)(s0 & ((1u << c) - 1)) + carry;
+          carry = d >= (1 << (c - 1));
           d -= carry << c;
           const uint32_t m = (uint32_t)(d < 0 ? -d : d);
-          shift();
+          shift(c);
           if (!(SP_Q_DIAG & 1)) {
-            const uint8_t* sub = cbase + (size_t)w * sub_bytes;  // the tile's (generator, window) sub-table (wave-uniform)
+            const uint8_t* sub = cbase + msm_woff(A.geom, w) * sizeof(Niels);  // the tile's (generator, window) sub-table (wave-uniform)
             const int eidx = (int)(m ? m - 1 : 0);               // this lane's entry in it
             const uint8_t* a[6];
 #pragma unroll
@@ -313,7 +313,7 @@ void msm_q_enqueue(sp_ctx* c, hipStream_t st, const sp_gens* g, const Fq* dZ, si
   A.partial = partial;
   A.nb = r.nb; A.len = r.len; A.S = r.S;
   A.ngroups = (unsigned)((rows + 63) / 64);
-  A.wbits = g->geom.wbits; A.nwin = g->geom.nwin; A.tent = g->geom.tent;
+  A.geom = g->geom;
   // the queues: one of a ring of counter blocks owned by the launching context (heads, then attachment counts), zeroed in stream order in
   // front of the launch; *counts_out tells the reduction how many slots of each group hold a sum
   A.heads = c->q_heads + (size_t)MSMQ_BLOCK_WORDS * (c->q_next++ % MSMQ_BLOCKS);

@@ -34,7 +34,7 @@ static int32_t opt_apply(SpOptions& o, const char* key, const char* value, bool 
   }
   // values inside the range that no kernel supports: 1..5-bit LDS-form tables (a sub-table must be whole KB pieces of LDS-DMA: ADVICE r5 — 5
   // bits gave silently wrong commitments), queue-form workgroups that are not 1, 2 or 3 wavefronts per SIMD
-  if ((i == OPT_MSM_LDS_BITS && v != 0 && v < 6) || ((i == OPT_MSM_Q_WAVES || i == OPT_MSM_Q_BG_WAVES) && v != 4 && v != 8 && v != 12)) {
+  if ((i == OPT_MSM_LDS_BITS && v != 0 && v < 6) || (i == OPT_MSM_WINDOWS && v != 0 && v < 17) || (i == OPT_MSM_WBITS && v != 0 && v < 4) || ((i == OPT_MSM_Q_WAVES || i == OPT_MSM_Q_BG_WAVES) && v != 4 && v != 8 && v != 12)) {
     if (!quiet) fprintf(stderr, "spartan_hip: option %s = %lld is not a supported value\n", key, v);
     return SP_EINVAL;
   }

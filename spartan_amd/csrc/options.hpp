@@ -18,9 +18,10 @@
   X(TESTING_UNLOCK, "testing.unlock", 0, 0, 1, 0, "1: accept tier-1 (A/B / test) options on this context")                                   \
   X(MSM_FORM, "msm.form", 0, 0, 3, 0, "row MSM of many rows: 0 = per launch and generator set (the queue form over the wide-window tables for commits of >= 256 rows; LDS-staged when the set's wide tables came out <= 10 bits; strip / balanced forms for the rest), 1 = LDS-staged small windows (needs msm.lds_bits at set creation), 2 = queue form also for sets that would take the LDS-staged form, 3 = strip / balanced forms always (the default before round 6)") \
   X(MSM_LDS_BITS, "msm.lds_bits", 0, 0, 10, 0, "window width of the LDS-staged form's tables built with a generator set (0 = not built; 10 = 48 KB sub-tables, double-buffered)") \
-  X(MSM_WBITS, "msm.wbits", 0, 0, 15, 0, "force the wide tables' window width (4..15); 0 = chosen by the policy below")                       \
-  X(MSM_TABLE_GB, "msm.table_gb", 170, 1, 100000, 0, "HBM budget of one generator set's wide tables, GB")                                    \
-  X(MSM_WIDE_GB, "msm.wide_gb", 80, 1, 100000, 0, "15-bit windows only while the set's tables stay under this many GB")                      \
+  X(MSM_WBITS, "msm.wbits", 0, 0, 15, 0, "force UNIFORM windows of this width (4..15: ceil(254 / width) additions per scalar); 0 = chosen by the policy below") \
+  X(MSM_WINDOWS, "msm.windows", 0, 0, 32, 0, "force this many windows = additions per committed scalar (17..32; mixed widths, as narrow as 254 bits allow); 0 = the fewest that fit the budgets below") \
+  X(MSM_TABLE_GB, "msm.table_gb", 180, 1, 100000, 0, "HBM budget of one generator set's wide tables, GB")                                    \
+  X(MSM_WIDE_GB, "msm.wide_gb", 80, 1, 100000, 0, "17 windows only while the set's tables stay under this many GB")                          \
   X(BG_EIGHTHS, "bg.eighths", 5, 0, 8, 0, "share of the CUs (in eighths) the background half of the derefs commitment runs on; 0 = plain low-priority launches") \
   X(UPLOAD_CHUNKS, "upload.chunks", 4, 1, 16, 0, "row chunks the witness upload + commit is issued in (each chunk's additions behind its PCIe copy)") \
   X(SHARD_COLS, "shard.cols", 1, 0, 1, 0, "column-sharded commitments for commits with fewer rows than shards")                              \

@@ -199,6 +199,7 @@ size_t spz_snark_gens_stream(void* g, int which, uint8_t* out, size_t cap) {
 int spz_ctx_set_option(void* ctx, const char* key, const char* value) { return sp_ctx_set_option(ctx ? ((Ctx*)ctx)->h : nullptr, key, value); }
 // window width of the fixed-base tables of a generator stream (0: gens_r1cs_sat, 1: gens_r1cs_eval)
 int spz_snark_gens_window_bits(void* g, int which) { return sp_gens_window_bits(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
+int spz_snark_gens_windows(void* g, int which) { return sp_gens_windows(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
 size_t spz_snark_gens_table_bytes(void* g, int which) { return sp_gens_table_bytes(which == 0 ? ((SNARKGens*)g)->stream_sat.g : ((SNARKGens*)g)->stream_eval.g); }
 // bincode of SNARKGens / ComputationCommitment (wire formats)
 size_t spz_snark_gens_bincode(void* g, uint8_t* out, size_t cap) {

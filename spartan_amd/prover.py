@@ -126,6 +126,10 @@ class SNARKGens:
         """signed window width of the fixed-base tables of generator stream `which` (0: gens_r1cs_sat, 1: gens_r1cs_eval)"""
         return int(H.spz_snark_gens_window_bits(self.h, ctypes.c_int(which)))
 
+    def windows(self, which):
+        """windows per scalar (= mixed additions per committed scalar) of the tables of generator stream `which`"""
+        return int(H.spz_snark_gens_windows(self.h, ctypes.c_int(which)))
+
     def table_bytes(self, which):
         """HBM held by the window tables of generator stream `which`"""
         H.spz_snark_gens_table_bytes.restype = sz

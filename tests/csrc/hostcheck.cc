@@ -87,4 +87,39 @@ int hc_msm_fixed(const uint8_t* pts_comp, size_t n, const uint64_t* scalars, uin
   pt_compress(acc, out);
   return 1;
 }
+// The same over a MIXED-width geometry (msm.hpp, msm_geom_windows: nwin windows over exactly 254 bits, the top ones one bit wider), two ways:
+// out_stream = the shifting digit stream of the strip form (msm_accumulate_t, one and two entries in flight), out_digit = one lookup per
+// (generator, window) with msm_digit / msm_tidx as the latency kernels do it. nwin = 0: uniform `wbits`-bit windows.
+int hc_msm_fixed_geom(const uint8_t* pts_comp, size_t n, const uint64_t* scalars, int nwin, int wbits, uint8_t* out_stream, uint8_t* out_stream2, uint8_t* out_digit) {
+  const MsmGeom g = nwin ? msm_geom_windows(nwin) : msm_geom(wbits);
+  if (nwin && ((g.nwin - g.nwide) * g.wbits + g.nwide * (g.wbits + 1) != 254 || msm_bitpos(g, g.nwin - 1) + msm_wbits_of(g, g.nwin - 1) != 254)) return 0;
+  std::vector<Niels> table(n * g.pt_entries);
+  for (size_t i = 0; i < n; i++) {
+    Pt P;
+    if (!pt_decompress(pts_comp + 32 * i, &P)) return 0;
+    for (int w = 0; w < g.nwin; w++) {
+      Pt base = P;
+      for (int k = 0; k < msm_bitpos(g, w); k++) base = pt_dbl(base);
+      Pt acc = base;
+      const int tent_w = 1 << (msm_wbits_of(g, w) - 1);
+      for (int m = 1; m <= tent_w; m++) {
+        table[msm_tidx(g, i, w, m)] = pt_to_niels(acc, fp_invert(acc.Z));
+        acc = pt_add(acc, base);
+      }
+    }
+  }
+  Pt a1 = pt_identity(), a2 = pt_identity(), a3 = pt_identity();
+  for (size_t i = 0; i < n; i++) {
+    const Fq sm = L(scalars + 4 * i);
+    msm_accumulate_t<false>(a1, sm, table.data(), i, g);
+    msm_accumulate_t<true>(a2, sm, table.data(), i, g);
+    const Fq s = fq_from_mont(sm);
+    for (int w = 0; w < g.nwin; w++) {
+      int d = msm_digit(s, w, g);
+      if (d != 0) a3 = pt_madd(a3, table[msm_tidx(g, i, w, d < 0 ? -d : d)], d < 0);
+    }
+  }
+  pt_compress(a1, out_stream); pt_compress(a2, out_stream2); pt_compress(a3, out_digit);
+  return 1;
+}
 }

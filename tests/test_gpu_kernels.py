@@ -108,19 +108,29 @@ def test_commit_rows_launch_plans_match_oracle(ctx, orc, gens301, rows, cols, bl
     assert got == bytes(want)
 
 
-@pytest.mark.parametrize("wbits", [5, 6, 8, 10, 12, 13, 14, 15])
+@pytest.mark.parametrize("wbits", [5, 6, 8, 10, 12, 13, 14, 15, -17, -18, -19, -20, -21, -22, -24, -26, -32])
 def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
-    """the window width is a property of the generator set, chosen at upload (core.hip choose_wbits; option msm.wbits forces
-    it): every width gives the same commitments through every launch plan (one-launch small, windowed trees, row strips, the
-    indexed lookups of the inner-product argument)"""
+    """the window geometry is a property of the generator set, chosen at upload (core.hip choose_geom): every uniform width (option
+    msm.wbits) and every number of MIXED-width windows (option msm.windows, the negative parameters: 17 = 1 x 14 + 16 x 15 bits, 18 = 16 x
+    14 + 2 x 15, ... 32 = 2 x 7 + 30 x 8: msm.hpp) gives the same commitments through every launch plan (one-launch small, windowed trees,
+    row strips, the queue form, the indexed lookups of the inner-product argument)"""
     from spartan_amd import capi
-    ctx.set_option("msm.wbits", wbits)   # read when a generator set is built
-    label = b"gens_width_%d" % wbits      # fresh points per width: a resident table set would be reused whatever its width
+    if wbits > 0:
+        ctx.set_option("msm.wbits", wbits)   # read when a generator set is built
+    else:
+        ctx.set_option("msm.wbits", 0); ctx.set_option("msm.windows", -wbits)
+    label = b"gens_width_%d" % (wbits & 0xff)      # fresh points per geometry: a resident table set would be reused whatever its width
     g = capi.Gens(ctx, compressed=gens_bytes(orc, 130, label))
-    assert g.window_bits() == wbits
+    if wbits > 0:
+        assert g.window_bits() == wbits and g.windows() == -(-254 // wbits)
+    else:
+        nw = -wbits
+        assert g.windows() == nw and g.window_bits() == 254 // nw
+        assert capi.lib.sp_gens_table_bytes(g.h) == 131 * (nw + 254 - nw * (254 // nw)) * (1 << (254 // nw - 1)) * 128
     gb = g.compressed
     rng = random.Random(wbits)
-    for rows, cols, blind, kind in [(1, 130, True, "uniform"), (6, 3, False, "edge"), (40, 128, True, "uniform"), (300, 64, True, "uniform"), (9, 17, False, "sparse")]:
+    for rows, cols, blind, kind in [(1, 130, True, "uniform"), (6, 3, False, "edge"), (40, 128, True, "uniform"), (300, 64, True, "uniform"), (9, 17, False, "sparse"),
+                                    (256, 128, True, "edge"), (2304, 20, False, "uniform")]:   # (the balanced form; nine row-blocks: the strip form / the queue form)
         Z = rand_scalars(rng, rows * cols, kind)
         bl = rand_scalars(rng, rows, "uniform") if blind else None
         got = g.commit_rows(mont_array(Z), rows, cols, mont_array(bl) if blind else None, g_off=0, h_idx=130)
@@ -136,20 +146,25 @@ def test_commit_rows_at_every_window_width(ctx, orc, wbits, monkeypatch):
         assert orc.orc_pt_msm(mont_array(S[r * 5:(r + 1) * 5]), pts, sz(5), out) == 1
         assert got[32 * r:32 * r + 32] == bytes(out)
     g.free()
-    ctx.set_option("msm.wbits", 0)
+    ctx.set_option("msm.wbits", 0); ctx.set_option("msm.windows", 0)
 
 
 def test_narrow_wide_tables_switch_the_set_to_the_lds_staged_form(ctx, orc):
     """The default per generator set (core.hip gens_build; profiles/r5_ab_msm_forms.txt): a set whose gathered tables come out at <= 10 bits — HBM
-    was short, or the width was forced — also gets the packed 10-bit tables and its row commitments of >= 512 rows run the LDS-staged form
-    (msm_lds.hip); msm.form = 3 keeps the gathered forms. Same commitments either way, equal to the oracle's."""
+    was short (here: a 1 GB table budget) — also gets the packed 10-bit tables and its row commitments of >= 512 rows run the LDS-staged form
+    (msm_lds.hip); msm.form = 3 keeps the gathered forms. Same commitments either way, equal to the oracle's. A width FORCED with msm.wbits
+    gets exactly the tables it asks for and no second set."""
     from spartan_amd import capi
     ctx.set_option("msm.wbits", 10)
+    gf = capi.Gens(ctx, compressed=gens_bytes(orc, 513, b"gens_forced_10"))
+    assert capi.lib.sp_gens_table_bytes(gf.h) == 514 * 26 * 512 * 128 and gf.window_bits() == 10
+    gf.free()
+    ctx.set_option("msm.wbits", 0); ctx.set_option("msm.table_gb", 1); ctx.set_option("msm.wide_gb", 1)
     try:
         n = 520
         g = capi.Gens(ctx, compressed=gens_bytes(orc, n, b"gens_auto_lds"))
-        per_point = 26 * 512
-        assert capi.lib.sp_gens_table_bytes(g.h) == (n + 1) * per_point * (128 + 96)    # both table kinds were built
+        # 26 windows is what 1 GB holds for 521 points (6 x 9 + 20 x 10 bits: 46 x 256 entries); the packed tables are uniform 10-bit ones
+        assert g.windows() == 26 and capi.lib.sp_gens_table_bytes(g.h) == (n + 1) * (46 * 256 * 128 + 26 * 512 * 96)    # both table kinds were built
         rows, cols = 640, n
         rng = random.Random(77)
         Z = rand_scalars(rng, rows * cols, "uniform")
@@ -163,7 +178,7 @@ def test_narrow_wide_tables_switch_the_set_to_the_lds_staged_form(ctx, orc):
         assert got_auto == got_gathered == bytes(want)
         g.free()
     finally:
-        ctx.set_option("msm.form", 0); ctx.set_option("msm.wbits", 0)
+        ctx.set_option("msm.form", 0); ctx.set_option("msm.wbits", 0); ctx.set_option("msm.table_gb", 180); ctx.set_option("msm.wide_gb", 80)
 
 
 def test_commit_rows_dev_and_offset(ctx, orc, gens40):

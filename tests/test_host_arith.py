@@ -88,6 +88,26 @@ def test_fixed_base_table_msm_matches_oracle(hc, orc, kind):
     assert bytes(o1) == bytes(o2)
 
 
+@pytest.mark.parametrize("nwin,wbits", [(32, 0), (26, 0), (43, 0), (0, 6), (0, 7)])
+def test_mixed_width_window_geometry_matches_oracle(hc, orc, nwin, wbits):
+    """The window geometries of round 6 (spartan_amd/csrc/msm.hpp: nwin windows over exactly 254 bits, the top ones one bit wider; the
+    policy uses 17 .. 32, here the cheap-to-build end and one past it) on the host build of the device arithmetic: tables laid out by
+    msm_tidx / msm_woff, the strip form's shifting digit stream with one and with two entries in flight, and the per-window msm_digit
+    lookups of the latency kernels all give the oracle's multi-scalar multiplication — edge scalars (0, 1, q - 1, all-ones runs that carry
+    through every window, values just below 2^252 that fill the top window) included."""
+    rng = random.Random(90 + nwin + wbits)
+    n = 6
+    g = gens_bytes(orc, n - 1)
+    for kind in ("uniform", "edge", "sparse"):
+        sc = rand_scalars(rng, n, kind)
+        if kind == "edge":
+            sc = [0, 1, Q - 1, (1 << 252) - 1, (1 << 252) + 27742317777372353535851937790883648492, (1 << 200) - 1][:n]
+        o1, o2, o3, want = u8x32(), u8x32(), u8x32(), u8x32()
+        assert hc.hc_msm_fixed_geom(g, sz(n), mont_array(sc), ctypes.c_int(nwin), ctypes.c_int(wbits), o1, o2, o3) == 1
+        assert orc.orc_pt_msm(mont_array(sc), g, sz(n), want) == 1
+        assert bytes(o1) == bytes(o2) == bytes(o3) == bytes(want), (nwin, wbits, kind)
+
+
 def test_fe10_serial_chain_matches_python(hc):
     """radix-2^25.5 arithmetic used by the lone-wave exponentiation ladder (spartan_amd/csrc/fe10.hpp)."""
     rng = random.Random(16)
