@@ -174,6 +174,17 @@ impl PolyEvalProof {
     poly: &DensePolynomial, blinds_opt: Option<&PolyCommitmentBlinds>, r: &[Scalar], Zr: &Scalar, blind_Zr_opt: Option<&Scalar>,
     gens: &PolyCommitmentGens, transcript: &mut Transcript, random_tape: &mut RandomTape,
   ) -> (PolyEvalProof, CompressedGroup) {
+    let (proof, c, _zr) = PolyEvalProof::prove_eval(poly, blinds_opt, r, Some(Zr), blind_Zr_opt, gens, transcript, random_tape);
+    (proof, c)
+  }
+  /// The same with the evaluation itself optional: `Zr = None` computes it here as <LZ, R> — the field element
+  /// DensePolynomial::evaluate(r) = L^T Z R — from the vector-matrix product the opening needs anyway (sp_eq_expand + sp_dot: one
+  /// launch-sized trip instead of a pass over the polynomial), and returns it. Used by R1CSProof::prove for `eval_vars_at_ry` (:299).
+  #[cfg(feature = "gpu")]
+  pub fn prove_eval(
+    poly: &DensePolynomial, blinds_opt: Option<&PolyCommitmentBlinds>, r: &[Scalar], Zr: Option<&Scalar>, blind_Zr_opt: Option<&Scalar>,
+    gens: &PolyCommitmentGens, transcript: &mut Transcript, random_tape: &mut RandomTape,
+  ) -> (PolyEvalProof, CompressedGroup, Scalar) {
     transcript.append_protocol_name(PolyEvalProof::protocol_name());
     assert_eq!(poly.get_num_vars(), r.len());
     let (left_num_vars, right_num_vars) = EqPolynomial::compute_factored_lens(r.len());
@@ -191,7 +202,18 @@ impl PolyEvalProof {
         (gpu::Table(lz), Vec::new())
       }
     };
+    let Rt = if Zr.is_none() { Some(gpu::Table::eq(&r[left_num_vars..])) } else { None };  // queued behind the product
     let R = EqPolynomial::new(r[left_num_vars..].to_vec()).evals();
+    let Zr_val: Scalar = match (Zr, &Rt) {
+      (Some(z), _) => *z,
+      (None, Some(rt)) => {
+        let mut out = Scalar::zero();
+        gpu::ok(unsafe { gpu::sp_dot(gpu::ctx(), LZ.0, 0, rt.0, 0, R.len(), &mut out as *mut Scalar as *mut u64) });
+        out
+      }
+      (None, None) => unreachable!(),
+    };
+    let Zr = &Zr_val;
     let LZ_blind: Scalar = match blinds_opt {
       Some(b) => { assert_eq!(b.blinds.len(), L_size); (0..L.len()).map(|i| b.blinds[i] * L[i]).sum() }
       None => Scalar::zero(),
@@ -199,6 +221,6 @@ impl PolyEvalProof {
     let zero = Scalar::zero();
     let blind_Zr = blind_Zr_opt.map_or(&zero, |p| p);
     let (proof, _C_LR, C_Zr_prime) = DotProductProofLog::prove_dev(&gens.gens, transcript, random_tape, &LZ, &LZ_blind, &R, Zr, blind_Zr);
-    (PolyEvalProof { proof }, C_Zr_prime)
+    (PolyEvalProof { proof }, C_Zr_prime, Zr_val)
   }
 }

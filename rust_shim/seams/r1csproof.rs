@@ -112,10 +112,14 @@ impl R1CSProof {
       &gens.gens_sc.gens_1, &gens.gens_sc.gens_3, transcript, random_tape);
     if let Some(f) = hooks.on_ry { f(&ry); }
 
-    let eval_vars_at_ry = poly_vars.evaluate(&ry[1..]); // sp_evaluate
+    // eval_vars_at_ry (:299): unsharded, it comes out of the opening's own vector-matrix product (<LZ, R>, PolyEvalProof::prove_eval);
+    // sharded (or with option polyeval.eval_from_opening = 0), a pass of its own (sp_evaluate, chunked over the shards)
+    let from_opening = gpu::shard_ctxs().len() < 2 && gpu::opt("polyeval.eval_from_opening") != 0;
+    let eval_first = if from_opening { None } else { Some(poly_vars.evaluate(&ry[1..])) };
     let blind_eval = random_tape.random_scalar(b"blind_eval");
-    let (proof_eval_vars_at_ry, comm_vars_at_ry) = PolyEvalProof::prove(&poly_vars, Some(&blinds_vars), &ry[1..], &eval_vars_at_ry,
-      Some(&blind_eval), &gens.gens_pc, transcript, random_tape);
+    let (proof_eval_vars_at_ry, comm_vars_at_ry, eval_vars_at_ry) = PolyEvalProof::prove_eval(&poly_vars, Some(&blinds_vars), &ry[1..],
+      eval_first.as_ref(), Some(&blind_eval), &gens.gens_pc, transcript, random_tape);
+    let _ = eval_vars_at_ry;
     let blind_eval_Z_at_ry = (Scalar::one() - ry[0]) * blind_eval;
     let blind_expected_claim_postsc2 = claims_phase2[1] * blind_eval_Z_at_ry;
     let claim_post_phase2 = claims_phase2[0] * claims_phase2[1];

@@ -48,6 +48,7 @@
   X(SPARK_PROD_LAYER2_MAX_LOG2, "spark.prod_layer2_max_log2", 18, 0, 40, 1, "... for layers of at most 2^this entries")                      \
   X(SPARK_EQ_FACTOR, "spark.eq_factor", 1, 0, 1, 1, "the eq table as a factor in the throughput-sized batched rounds")                       \
   X(SPARK_HASH_FUSE, "spark.hash_fuse", 1, 0, 1, 1, "hash layer + first product layer in one pass")                                          \
+  X(POLYEVAL_EVAL_FROM_OPENING, "polyeval.eval_from_opening", 1, 0, 1, 1, "R1CSProof::prove: the witness evaluation at ry as <LZ, R> from the opening's own vector-matrix product (0: a separate DensePolynomial::evaluate pass)") \
   X(OVERLAP_DEREFS, "overlap.derefs", 1, 0, 1, 1, "row half of the derefs commitment on the background stream under the second sum-check")    \
   X(OVERLAP_EVAL_AHEAD, "overlap.eval_ahead", 1, 0, 1, 1, "R1CSInstance::evaluate queued on a low-priority stream as soon as ry is known")    \
   X(SHARD_RESIDUE_TRANSPORT, "shard.residue_transport", 0, 0, 1, 1, "residue-shard every sum-check over multi-process transports (= shard.residue_min_log2 0)") \

@@ -921,8 +921,12 @@ static DotProductProofLog dotproductlog_prove(sp_ctx* c, const DotProductProofGe
 }
 
 // PolyEvalProof::prove (dense_mlpoly.rs:312-365)
+// Zr_from_LZ != nullptr: the evaluation itself is not known yet and is computed HERE, as <LZ, R> — the same field element as
+// DensePolynomial::evaluate(r) = sum_i Z_i chi_i(r) = L^T Z R, from the vector-matrix product the opening needs anyway — and returned through
+// it (round 6: R1CSProof::prove's `poly_vars.evaluate(&ry[1..])`, r1csproof.rs:299, was a pass of its own over the witness, 0.13 ms at 2^20
+// and 0.6 ms at 2^22 on the critical path; the dot product of two sqrt(N) vectors is one launch-sized trip). `Zr` is ignored then.
 static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec* blinds_opt, const FqVec& r, const Fq& Zr, const Fq* blind_Zr_opt,
-                                    const PolyCommitmentGens& gens, Transcript& t, RandomTape& tape, CP* C_Zr) { HSPAN("polyeval_prove");
+                                    const PolyCommitmentGens& gens, Transcript& t, RandomTape& tape, CP* C_Zr, Fq* Zr_from_LZ = nullptr) { HSPAN("polyeval_prove");
   t.append_protocol_name("polynomial evaluation proof");
   size_t Ls = pow2(r.size() / 2), Rs = pow2(r.size() - r.size() / 2);
   REQUIRE(poly.len() == Ls * Rs);
@@ -957,7 +961,14 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
     SPX(sp_vecmat_dev(c, U(Lv), Ls, poly.h, &lz));  // DensePolynomial::bound :349, kept on the device; queued, not waited for
   }
   DevTable LZ(c, lz);
+  Fq Zr_val = Zr;
+  DevTable Rt;
+  if (Zr_from_LZ) Rt = tab_eq(c, FqVec(r.begin() + r.size() / 2, r.end()));  // queued behind the product; the host computes its own copy meanwhile
   FqVec Rv = eq_evals_host(FqVec(r.begin() + r.size() / 2, r.end()));  // while the device multiplies
+  if (Zr_from_LZ) {
+    SPX(sp_dot(c, LZ.h, 0, Rt.h, 0, Rs, Zr_val.l));
+    *Zr_from_LZ = Zr_val;
+  }
   Fq LZ_blind = fq_zero();
   if (blinds_opt) {
     REQUIRE(blinds_opt->size() == Ls);
@@ -965,7 +976,7 @@ static PolyEvalProof polyeval_prove(sp_ctx* c, const DevTable& poly, const FqVec
   }
   Fq blind_Zr = blind_Zr_opt ? *blind_Zr_opt : fq_zero();
   PolyEvalProof p;
-  p.proof = dotproductlog_prove(c, gens.gens, t, tape, LZ, LZ_blind, Rv, Zr, blind_Zr, C_Zr);
+  p.proof = dotproductlog_prove(c, gens.gens, t, tape, LZ, LZ_blind, Rv, Zr_val, blind_Zr, C_Zr);
   return p;
 }
 
@@ -1100,10 +1111,13 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
   double t3 = now_s();
   FqVec ry1(ry.begin() + 1, ry.end());
   Fq eval_vars_at_ry;
+  bool eval_from_opening = false;  // unsharded: the evaluation comes out of the opening's own vector-matrix product (polyeval_prove)
   {
     std::vector<sp_ctx*> shards = residue_shard_ctxs(c);
     size_t W = shards.size(), lw = W >= 2 ? log_2(W) : 0;
-    if (W >= 2 && ry1.size() > lw + 1 && !commit_shard_residue_off(c)) {
+    if (W < 2 && ctx_opt(c, "polyeval.eval_from_opening") != 0) {
+      eval_from_opening = true;
+    } else if (W >= 2 && ry1.size() > lw + 1 && !commit_shard_residue_off(c)) {
       // DensePolynomial::evaluate as W partial dot products over contiguous chunks (chunk g = the top log2 W index
       // bits): <Z, chi(r)> = sum_g chi_g(r[..lw]) <Z_g, chi(r[lw..])>, one scalar per shard gathered and combined here
       SPX(sp_ctx_sync(c));
@@ -1123,7 +1137,8 @@ static R1CSProof r1cs_prove(sp_ctx* c, const Instance& inst, const Fq* vars, siz
     }
   }
   Fq blind_eval = tape.random_scalar("blind_eval");
-  P.proof_eval_vars_at_ry = polyeval_prove(c, poly_vars, &blinds_vars, ry1, eval_vars_at_ry, &blind_eval, gens.gens_pc, t, tape, &P.comm_vars_at_ry);
+  P.proof_eval_vars_at_ry = polyeval_prove(c, poly_vars, &blinds_vars, ry1, eval_vars_at_ry, &blind_eval, gens.gens_pc, t, tape, &P.comm_vars_at_ry,
+                                           eval_from_opening ? &eval_vars_at_ry : nullptr);
   if (tm) tm->polyeval = now_s() - t3;
 
   Fq blind_eval_Z_at_ry = (fq_one() - ry[0]) * blind_eval;

@@ -501,7 +501,7 @@ def test_every_ab_switch_gives_the_same_proof(orc):
                 {"sumcheck.inline_args": 0}, {"ipa.fused": 0}, {"encode.device": 1}, {"commit.small_device": 1},
                 {"sumcheck.double_round_max_len": 0, "sumcheck.host_tail": 0}, {"sumcheck.double_round_max_len": 512},
                 {"spark.prod_layer2": 0}, {"spark.prod_layer2_max_log2": 14}, {"upload.overlap": 0, "upload.thread": 0}, {"upload.chunks": 2},
-                {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"bg.eighths": 4}, {"bg.eighths": 0},
+                {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"polyeval.eval_from_opening": 0}, {"bg.eighths": 4}, {"bg.eighths": 0},
                 {"msm.form": 3}, {"msm.form": 3, "bg.eighths": 3, "upload.chunks": 1},
                 {"msm.q_waves": 8, "msm.q_bg_waves": 12, "msm.q_units": 16}, {"msm.q_bg_waves": 4, "msm.q_units": 128, "bg.eighths": 0},
                 {"msm.lds_bits": 10, "msm.form": 1}, {"msm.lds_bits": 9, "msm.form": 1, "overlap.derefs": 0}, {"msm.wbits": 11}]
