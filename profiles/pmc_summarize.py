@@ -10,7 +10,7 @@ options: bench.config_key): bench.py reports `roofline.traffic` only for a run w
 import csv, json, os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAMILY = {"k_msm_rows": "msm_rows_fixed", "k_msm_rows_bg": "msm_rows_fixed", "k_msm_flat": "msm_rows_fixed", "k_msm_flat_bg": "msm_rows_fixed", "k_msm_lds": "msm_rows_fixed", "k_msm_q": "msm_rows_fixed", "k_msm_windows": "msm_windows_fixed", "k_msm_windows_tree": "msm_windows_fixed", "k_msm_windows_tree_fused": "msm_windows_fixed", "k_ipa_round": "ipa_round",
-          "k_msm_reduce": "msm_reduce_compress", "k_pt_encode": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
+          "k_msm_reduce": "msm_reduce_compress", "k_pt_encode": "msm_reduce_compress", "k_pt_encode_lean": "msm_reduce_compress", "k_pt_reduce_pass": "msm_reduce_pass",
           "k_cubic_bind_eval_batched": "sumcheck_bind_eval", "k_sc_bind_eval": "sumcheck_bind_eval", "k_sc_eval": "sumcheck_eval",
           "k_cubic_eval_batched": "sumcheck_eval", "k_cubic_bind_eval_batched_eq": "sumcheck_bind_eval", "k_cubic_eval_batched_eq": "sumcheck_eval", "k_bind_top": "table_bind", "k_eq_expand": "eq_expand",
           "k_cubic_bind2_eval": "sumcheck_bind_eval", "k_cubic_bind_eval_tiny": "sumcheck_bind_eval", "k_sc_bind_eval_tiny": "sumcheck_bind_eval",

@@ -993,12 +993,22 @@ __global__ void __launch_bounds__(256) k_msm_reduce(const void* __restrict__ par
 // RFC 9496 encode of many row sums at once: one LANE per row. (With the encode inside k_msm_reduce one lane per BLOCK runs
 // the ~100 us inverse-square-root chain while 255 wait: a 1024-row commit spent 0.6 ms there; this way the 1024 chains
 // run side by side in 16 wavefronts.)
-__global__ void __launch_bounds__(64) k_pt_encode(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) { SP_FG_PRIO();
+__device__ __forceinline__ void pt_encode_rows(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) {
   size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (row >= rows) return;
   uint8_t c[32];
   pt10_compress(pt10_load(in[row]), c);
   for (int k = 0; k < 32; k++) out[32 * row + k] = c[k];
+}
+__global__ void __launch_bounds__(64) k_pt_encode(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) { SP_FG_PRIO();
+  pt_encode_rows(in, rows, out);
+}
+// The same in at most 168 VGPRs (the compiler takes all 256 for its schedule of the chain above; here it spills ~100 dwords): the encode of
+// the ROW half of `derefs` runs while the column half's queue-form MSM holds two wavefronts per SIMD on every CU — 272 of a lane's 512
+// registers — and a 256-register wavefront could not be placed until that launch had ended (first round-6 traces: k_pt_encode 0.13 -> 3 ms
+// on average at 2^22, the row half's shares absorbed after the MSM instead of under it).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_pt_encode_lean(const Pt* __restrict__ in, size_t rows, uint8_t* __restrict__ out) { SP_FG_PRIO();
+  pt_encode_rows(in, rows, out);
 }
 
 extern "C" {
@@ -1602,7 +1612,11 @@ static void msm_enqueue(sp_ctx* c, hipStream_t st, bool prof, const MsmPlan& m, 
   }
   if (encode && batch_encode) {
     ProfScope ps = scope(PF_MSM_REDUCE, 160.0 * (double)rows);
-    hipLaunchKernelGGL(k_pt_encode, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (const Pt*)sums, rows, dout);
+    // (the background launch of a co-resident pair encodes under the other launch: the variant that fits next to it)
+    if (m.queue && m.qrole == MSMQ_CORESIDENT && st != c->stream)
+      hipLaunchKernelGGL(k_pt_encode_lean, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (const Pt*)sums, rows, dout);
+    else
+      hipLaunchKernelGGL(k_pt_encode, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, (const Pt*)sums, rows, dout);
   }
 }
 // core: Z on device (row stride in elements), optional idx (device), optional blinds (device); synchronous
