@@ -56,7 +56,7 @@ python bench.py > $O/bench_line.json 2> $O/bench_line.err
 SPARTAN_OPTIONS=testing.unlock=1,host.callstats=1 timeout 300 python bench.py --no-cpu-baseline --concurrent 0 --steps 4 --warmup 1 --no-side-metrics --no-strong > /dev/null 2> $O/callstats.err; grep callstats $O/callstats.err | tail -56 > $O/callstats.txt
 for s in 16 18; do python bench.py --log2-cons $s --cpu-log2-cons 0 --no-cpu-baseline > $O/bench_line_2p$s.json 2> $O/bench_line_2p$s.err; done
 python bench.py --log2-cons 22 --no-cpu-baseline --steps 8 > $O/bench_line_2p22.json 2> $O/bench_line_2p22.err
-python bench.py --log2-cons 24 --no-cpu-baseline --steps 3 --concurrent 0 > $O/bench_line_2p24.json 2> $O/bench_line_2p24.err
+python bench.py --log2-cons 24 --no-cpu-baseline --steps 3 --concurrent 0 --no-side-metrics > $O/bench_line_2p24.json 2> $O/bench_line_2p24.err
 SPARTAN_OPTIONS=$SM python bench.py --no-cpu-baseline --concurrent 0 > $O/bench_line_small_memory.json 2> $O/bench_line_small_memory.err
 ./bench/ubench_fpmul > $O/ubench_fpmul.txt 2>&1
 rm -f $O/*.db $O/fetch*.csv $O/write*.csv $O/wait*.csv $O/tcc*.csv $O/probe_wait.csv
