@@ -1278,11 +1278,12 @@ static std::list<GensCacheEntry> g_gens_cache;
 //   * 17 windows only while the set's tables stay under msm.wide_gb (default 80: the 1025- and 2049-point streams of a 2^20 / 2^22
 //     instance keep them; the proof time of 17 against 18 windows for the larger stream was a tie in rounds 2-4 and costs 56 GB);
 //   * otherwise the fewest windows that fit msm.table_gb (default 180 per set: the 8194-point stream of a 2^22 instance at 18 windows is
-//     172 GB) and the free device memory less a reserve for the proof's own tables: 24 GB, or 2.2e-7 GB x n^2 when that is more — the
-//     working set of a proof grows with the square of its larger generator stream (59 GB for the 16386 points of a 2^24 instance); applied
-//     only to tables that are themselves large (a 1.5 MB table set must not be refused because another process holds the HBM).
+//     172 GB) and the free device memory less a reserve for the proof's own tables: 24 GB, or 4.2e-7 GB x n^2 when that is more — the
+//     working set of a proof grows with the square of its larger generator stream: 113 GB for the 16386 points of a 2^24 instance (instance,
+//     encode, proof tables and what the buffer pool keeps: measured — with 103 GB left a 2^24 proof ran out of memory, with 111 it did not);
+//     applied only to tables that are themselves large (a 1.5 MB table set must not be refused because another process holds the HBM).
 // 2^20: 17 / 18 windows (35.5 + 86.1 GB; rounds 2-5: uniform 15 / 14 bits = 17 / 19 windows, 36.6 + 81.6 GB); 2^22: 17 / 18 (70.9 + 172 GB;
-// before 17 / 19, 73 + 163); 2^24: 18 / 21 (86 + 99 GB; before 14 / 12 bits = 19 / 22 windows, 82 + 95). Option msm.windows forces a
+// before 17 / 19, 73 + 163); 2^24: 18 / 22 (86 + 73 GB; before 14 / 12 bits = 19 / 22 windows, 82 + 95). Option msm.windows forces a
 // number of windows, msm.wbits a uniform width (the tests use both). Fewer windows than the first choice are reported on stderr (once per
 // set): a silent narrowing would be a performance cliff nobody sees. Returns false when not even 32 windows fit in free memory.
 static bool choose_geom(const sp_ctx* c, size_t n, MsmGeom* out) {
@@ -1299,7 +1300,7 @@ static bool choose_geom(const sp_ctx* c, size_t n, MsmGeom* out) {
     if (nw == 17 && gb > wide) continue;
     if (gb > budget) continue;
     if (!first_choice) first_choice = nw;
-    double reserve = gb >= 1.0 ? std::max(24.0, 2.2e-7 * (double)n * (double)n) : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
+    double reserve = gb >= 1.0 ? std::max(24.0, 4.2e-7 * (double)n * (double)n) : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
     if (gb + reserve <= free_gb || (nw == 32 && gb * 1.05 <= free_gb)) {
       if (nw > first_choice)
         fprintf(stderr, "spartan_hip: window tables of %zu generators cut from %d to %d windows (%.1f GB of device memory free): %d instead of %d additions per scalar\n",
