@@ -44,11 +44,11 @@ for (k, g), ds in dur.items():
     if not k.startswith(FQ): continue
     fb = 2.0 * f.get((k, g), 0.0) * 1024 / max(nf.get((k, g), 1), 1)
     wb = w.get((k, g), 0.0) * 1024 / max(nw.get((k, g), 1), 1)
-    avg = sum(ds) / len(ds)
+    avg = sorted(ds)[len(ds) // 2]   # the MEDIAN launch: the first proof of a process pays its pool allocations inside some launches (one 7.5 ms outlier per run)
     rows.append((k, g, len(ds), avg, fb + wb))
-print("# F_q kernels by launch size: HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KiB counters) / average duration (kernel trace)")
+print("# F_q kernels by launch size: HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, KiB counters) / median duration (kernel trace)")
 print("# throughput-sized = a launch that moves >= 64 MB; the rest is launch-sized (latency-bound by construction: its TB/s says nothing)")
-hdr = "%-44s %10s %6s %10s %10s %8s  %s" % ("kernel", "grid", "calls", "avg_us", "MB/launch", "TB/s", "vgprs/waves_per_simd")
+hdr = "%-44s %10s %6s %10s %10s %8s  %s" % ("kernel", "grid", "calls", "median_us", "MB/launch", "TB/s", "vgprs/waves_per_simd")
 for title, sel in (("throughput-sized launches (>= 64 MB)", lambda r: r[4] >= 64e6), ("launch-sized (< 64 MB), the ten with the most total time", lambda r: r[4] < 64e6)):
     print("\n## " + title); print(hdr)
     part = [r for r in rows if sel(r)]
