@@ -118,6 +118,11 @@ size_t sp_gens_len(const sp_gens* g);
 size_t sp_gens_table_bytes(const sp_gens* g); /* HBM held by the window tables of this set */
 int sp_gens_window_bits(const sp_gens* g); /* the width c of the (narrow) windows the tables of this set were built with */
 int sp_gens_windows(const sp_gens* g);     /* windows per scalar = mixed additions per committed scalar (17 .. 32; the top windows may be one bit wider than c) */
+/* Window counts for two generator streams one prover holds side by side (SNARKGens: n_a / n_b points, committing w_a / w_b scalars per
+ * proof), chosen together: fewest mixed additions per proof among the pairs whose tables fit the free device memory less the proof's
+ * reserve. The caller sets option "msm.windows" to each result around the creation of that stream and back to 0 afterwards; 0 = no
+ * recommendation (a geometry is forced, option msm.plan_pair is 0, or the streams are too small to matter). */
+int32_t sp_gens_plan_pair(sp_ctx* ctx, size_t n_a, size_t n_b, double w_a, double w_b, int* windows_a, int* windows_b);
 void sp_gens_free(sp_gens* g);
 
 /* ---- Pedersen commitments (src/commitments.rs:73-92, src/dense_mlpoly.rs:164-177, src/group.rs:98-117) --

@@ -338,6 +338,10 @@ fn main() {
             assert rest.count("  pub fn prove(\n") == 1
             rest = rest.replace("  pub fn prove(\n", gate + "  pub fn prove(\n", 1)
             s = s[:i_snark] + snark + rest
+            # SNARKGens::new: the table geometries of its two generator streams are planned together before either is created
+            sig = "    let gens_r1cs_sat = R1CSGens::new(b\"gens_r1cs_sat\", num_cons, num_vars_padded);\n"
+            assert s.count(sig) == 2 and s.index(sig) > s.index("impl SNARKGens {") and s.index(sig) < s.index("impl NIZKGens {"), sig   # SNARKGens::new first, NIZKGens::new second
+            s = s.replace(sig, "    #[cfg(feature = \"gpu\")]\n    gpu::plan_snark_gens(num_cons, num_vars_padded, num_nz_entries);\n" + sig, 1)
         open(p, "w").write(s)
 
 

@@ -54,7 +54,7 @@ def options_table():
 
 # every symbol include/spartan_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["sp_ctx_set_option", "sp_ctx_get_option", "sp_ctx_copy_options", "sp_option_describe", "sp_host_msm2_probe", "sp_hash_layer_first", "sp_product_tree_many_from", "sp_sumcheck_eval_batched_eq", "sp_sumcheck_bind_eval_batched_eq", "sp_table_scale_prefix", "sp_sparse_entry_index", "sp_sparse_entry_values", "sp_tables_pack", "sp_tables_unpack_residues", "sp_table_residue_split", "sp_table_set_len", "sp_table_add_into", "sp_ctx_device", "sp_ctx_trips", "sp_gens_table_bytes", "sp_host_commit_small", "sp_host_commit_point", "sp_host_commit_probe",
-           "sp_host_zk_ahead_begin", "sp_host_zk_ahead_wait", "sp_host_zk_ahead_free", "sp_addr_timestamps", "sp_commit_rows", "sp_commit_rows_dev", "sp_commit_rows_dev_begin", "sp_commit_rows_dev_start", "sp_commit_rows_partial", "sp_host_points_sum_encode", "sp_commit_rows_upload_start", "sp_job_wait", "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_sync", "sp_dot", "sp_dot3", "sp_dot3_many", "sp_dot_many", "sp_eq_expand", "sp_evaluate", "sp_gather", "sp_gens_free", "sp_gens_from_uniform", "sp_gens_len", "sp_gens_window_bits", "sp_gens_windows", "sp_gens_upload", "sp_hash_layer", "sp_index_free", "sp_index_upload", "sp_ipa_begin", "sp_ipa_begin_dev", "sp_ipa_set_scale", "sp_ipa_commit_ghat", "sp_ipa_finish", "sp_ipa_finish_commit", "sp_ipa_free", "sp_ipa_round_fold", "sp_ipa_round_lr", "sp_ipa_round_prelaunch", "sp_msm_indexed", "sp_product_tree", "sp_product_tree_many", "sp_prof_enable", "sp_prof_read", "sp_prof_read_ops", "sp_prof_read_shapes", "sp_prof_read_spans", "sp_msm_window_bits", "sp_prof_reset", "sp_prof_select", "sp_sparse_eval_table", "sp_sparse_evaluate", "sp_sparse_evaluate_begin", "sp_sparse_free", "sp_sparse_mulvec", "sp_sparse_upload", "sp_strerror", "sp_sumcheck_bind_eval", "sp_sumcheck_bind_eval_start", "sp_sumcheck_bind_eval_collect", "sp_sumcheck_bind_eval_commit", "sp_sumcheck_bind_eval_batched", "sp_sumcheck_eval", "sp_sumcheck_eval_batched", "sp_sumcheck_eval_coeffs_batched", "sp_sumcheck_bind2_eval_batched", "sp_sumcheck_bind2_eval_tables_batched", "sp_table_alloc", "sp_table_alloc_uninit", "sp_table_bind_top", "sp_table_bind_top_heads", "sp_table_clone", "sp_table_copy", "sp_table_download", "sp_table_free", "sp_table_from_index", "sp_table_heads", "sp_table_gather", "sp_table_len", "sp_table_upload", "sp_table_view", "sp_table_write", "sp_vecmat", "sp_vecmat_dev", "sp_vecmat_tab", "sp_version"]
+           "sp_host_zk_ahead_begin", "sp_host_zk_ahead_wait", "sp_host_zk_ahead_free", "sp_addr_timestamps", "sp_commit_rows", "sp_commit_rows_dev", "sp_commit_rows_dev_begin", "sp_commit_rows_dev_start", "sp_commit_rows_partial", "sp_host_points_sum_encode", "sp_commit_rows_upload_start", "sp_job_wait", "sp_ctx_create", "sp_ctx_destroy", "sp_ctx_sync", "sp_dot", "sp_dot3", "sp_dot3_many", "sp_dot_many", "sp_eq_expand", "sp_evaluate", "sp_gather", "sp_gens_free", "sp_gens_from_uniform", "sp_gens_len", "sp_gens_window_bits", "sp_gens_windows", "sp_gens_plan_pair", "sp_gens_upload", "sp_hash_layer", "sp_index_free", "sp_index_upload", "sp_ipa_begin", "sp_ipa_begin_dev", "sp_ipa_set_scale", "sp_ipa_commit_ghat", "sp_ipa_finish", "sp_ipa_finish_commit", "sp_ipa_free", "sp_ipa_round_fold", "sp_ipa_round_lr", "sp_ipa_round_prelaunch", "sp_msm_indexed", "sp_product_tree", "sp_product_tree_many", "sp_prof_enable", "sp_prof_read", "sp_prof_read_ops", "sp_prof_read_shapes", "sp_prof_read_spans", "sp_msm_window_bits", "sp_prof_reset", "sp_prof_select", "sp_sparse_eval_table", "sp_sparse_evaluate", "sp_sparse_evaluate_begin", "sp_sparse_free", "sp_sparse_mulvec", "sp_sparse_upload", "sp_strerror", "sp_sumcheck_bind_eval", "sp_sumcheck_bind_eval_start", "sp_sumcheck_bind_eval_collect", "sp_sumcheck_bind_eval_commit", "sp_sumcheck_bind_eval_batched", "sp_sumcheck_eval", "sp_sumcheck_eval_batched", "sp_sumcheck_eval_coeffs_batched", "sp_sumcheck_bind2_eval_batched", "sp_sumcheck_bind2_eval_tables_batched", "sp_table_alloc", "sp_table_alloc_uninit", "sp_table_bind_top", "sp_table_bind_top_heads", "sp_table_clone", "sp_table_copy", "sp_table_download", "sp_table_free", "sp_table_from_index", "sp_table_heads", "sp_table_gather", "sp_table_len", "sp_table_upload", "sp_table_view", "sp_table_write", "sp_vecmat", "sp_vecmat_dev", "sp_vecmat_tab", "sp_version"]
 
 
 def _chk(rc):

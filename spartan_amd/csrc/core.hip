@@ -1243,6 +1243,37 @@ int32_t sp_prof_read_shapes(sp_ctx* c, const char* family, uint64_t* shape, doub
 int sp_msm_window_bits(void) { return MSM_WBITS; }
 int sp_gens_window_bits(const sp_gens* g) { return g ? g->geom.wbits : 0; }
 int sp_gens_windows(const sp_gens* g) { return g ? g->geom.nwin : 0; }
+// Window counts for TWO generator streams that one prover will hold side by side (SNARKGens: the gens_r1cs_sat stream, n_a points, commits
+// w_a scalars per proof; the gens_r1cs_eval stream, n_b points, w_b scalars — 2^s and 6 * 2^s for SNARK::prove). choose_geom sees one set at
+// a time: whichever is built first takes what it likes and the other what is left. Here the pair is chosen together: the (windows_a,
+// windows_b) that minimises the mixed additions of a proof, w_a * windows_a + w_b * windows_b, among the pairs whose tables fit the free
+// device memory less the proof's reserve (and msm.table_gb each); ties go to the smaller tables. 2^20: 17 / 17 (35.5 + 141.8 GB; one set
+// at a time: 17 / 18); 2^22: 17 / 18 (the only pair that fits); 2^24: 19 / 21 (55.8 + 98.8 GB; one at a time: 18 / 22, more memory AND more
+// additions; 20 / 20 — 183 GB, the fewest additions of all — leaves the 2^24 proof too little). The caller sets option msm.windows to each result around the creation of its stream (0 = leave it to the per-set policy:
+// returned when a geometry is forced by msm.wbits / msm.windows, or for streams too small to matter).
+int32_t sp_gens_plan_pair(sp_ctx* c, size_t n_a, size_t n_b, double w_a, double w_b, int* windows_a, int* windows_b) {
+  if (!c || !windows_a || !windows_b || n_a == 0 || n_b == 0) return SP_EINVAL;
+  *windows_a = *windows_b = 0;
+  if (c->opt.v[OPT_MSM_WBITS] >= 4 || c->opt.v[OPT_MSM_WINDOWS] >= 17 || c->opt.v[OPT_MSM_PLAN_PAIR] == 0) return SP_OK;
+  HIPCHK(hipSetDevice(c->dev));
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return SP_OK; }
+  const double budget = (double)c->opt.v[OPT_MSM_TABLE_GB];
+  const size_t n_max = n_a > n_b ? n_a : n_b;
+  auto gb = [](size_t n, int nw) { return (double)n * (double)msm_geom_windows(nw).pt_entries * sizeof(Niels) / 1e9; };
+  if (gb(n_max, 17) < 1.0) return SP_OK;  // small sets: everything fits, the per-set policy gives 17 windows anyway
+  const double avail = (double)free_b / 1e9 - std::max(24.0, 5.0e-7 * (double)n_max * (double)n_max);
+  static const int kCand[] = {17, 18, 19, 20, 21, 22, 24, 26, 32};
+  double best_cost = 1e300, best_gb = 1e300;
+  for (int wa : kCand)
+    for (int wb : kCand) {
+      const double ga = gb(n_a, wa), gbb = gb(n_b, wb);
+      if (ga > budget || gbb > budget || ga + gbb > avail) continue;
+      const double cost = w_a * wa + w_b * wb;
+      if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && ga + gbb < best_gb)) { best_cost = cost; best_gb = ga + gbb; *windows_a = wa; *windows_b = wb; }
+    }
+  return SP_OK;
+}
 int32_t sp_prof_read(sp_ctx* c, const char** names, double* total_ms, uint64_t* launches, double* alg_bytes, int cap) {
   if (!c) return SP_EINVAL;
   prof_drain(c);
@@ -1278,9 +1309,10 @@ static std::list<GensCacheEntry> g_gens_cache;
 //   * 17 windows only while the set's tables stay under msm.wide_gb (default 80: the 1025- and 2049-point streams of a 2^20 / 2^22
 //     instance keep them; the proof time of 17 against 18 windows for the larger stream was a tie in rounds 2-4 and costs 56 GB);
 //   * otherwise the fewest windows that fit msm.table_gb (default 180 per set: the 8194-point stream of a 2^22 instance at 18 windows is
-//     172 GB) and the free device memory less a reserve for the proof's own tables: 24 GB, or 4.2e-7 GB x n^2 when that is more — the
-//     working set of a proof grows with the square of its larger generator stream: 113 GB for the 16386 points of a 2^24 instance (instance,
-//     encode, proof tables and what the buffer pool keeps: measured — with 103 GB left a 2^24 proof ran out of memory, with 111 it did not);
+//     172 GB) and the free device memory less a reserve for the proof's own tables: 24 GB, or 5.0e-7 GB x n^2 when that is more — the
+//     working set of a proof grows with the square of its larger generator stream: 134 GB for the 16386 points of a 2^24 instance (instance,
+//     encode, proof tables and what the buffer pool keeps: measured on the 309 GB (= 288 GiB) the device reports — with 124 GB left the bench's
+//     2^24 run ran out of memory, with 132 it did not);
 //     applied only to tables that are themselves large (a 1.5 MB table set must not be refused because another process holds the HBM).
 // 2^20: 17 / 18 windows (35.5 + 86.1 GB; rounds 2-5: uniform 15 / 14 bits = 17 / 19 windows, 36.6 + 81.6 GB); 2^22: 17 / 18 (70.9 + 172 GB;
 // before 17 / 19, 73 + 163); 2^24: 18 / 22 (86 + 73 GB; before 14 / 12 bits = 19 / 22 windows, 82 + 95). Option msm.windows forces a
@@ -1300,7 +1332,7 @@ static bool choose_geom(const sp_ctx* c, size_t n, MsmGeom* out) {
     if (nw == 17 && gb > wide) continue;
     if (gb > budget) continue;
     if (!first_choice) first_choice = nw;
-    double reserve = gb >= 1.0 ? std::max(24.0, 4.2e-7 * (double)n * (double)n) : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
+    double reserve = gb >= 1.0 ? std::max(24.0, 5.0e-7 * (double)n * (double)n) : 0.25;  // room for the proof's working set next to a large table; a small table only has to fit
     if (gb + reserve <= free_gb || (nw == 32 && gb * 1.05 <= free_gb)) {
       if (nw > first_choice)
         fprintf(stderr, "spartan_hip: window tables of %zu generators cut from %d to %d windows (%.1f GB of device memory free): %d instead of %d additions per scalar\n",

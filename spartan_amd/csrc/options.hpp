@@ -20,6 +20,7 @@
   X(MSM_LDS_BITS, "msm.lds_bits", 0, 0, 10, 0, "window width of the LDS-staged form's tables built with a generator set (0 = not built; 10 = 48 KB sub-tables, double-buffered)") \
   X(MSM_WBITS, "msm.wbits", 0, 0, 15, 0, "force UNIFORM windows of this width (4..15: ceil(254 / width) additions per scalar); 0 = chosen by the policy below") \
   X(MSM_WINDOWS, "msm.windows", 0, 0, 32, 0, "force this many windows = additions per committed scalar (17..32; mixed widths, as narrow as 254 bits allow); 0 = the fewest that fit the budgets below") \
+  X(MSM_PLAN_PAIR, "msm.plan_pair", 1, 0, 1, 0, "SNARKGens: the window counts of the two generator streams are chosen together (sp_gens_plan_pair: fewest additions per proof within free memory); 0 = each set by the per-set policy below") \
   X(MSM_TABLE_GB, "msm.table_gb", 180, 1, 100000, 0, "HBM budget of one generator set's wide tables, GB")                                    \
   X(MSM_WIDE_GB, "msm.wide_gb", 80, 1, 100000, 0, "17 windows only while the set's tables stay under this many GB")                          \
   X(BG_EIGHTHS, "bg.eighths", 5, 0, 8, 0, "share of the CUs (in eighths) the background half of the derefs commitment runs on; 0 = plain low-priority launches") \

@@ -116,7 +116,7 @@ struct GensStream {  // one SHAKE256 stream of points (label), uploaded once wit
   sp_gens* g = nullptr;
   std::vector<uint8_t> compressed;
   GensStream() {}
-  GensStream(sp_ctx* c, const char* label, size_t npoints);
+  GensStream(sp_ctx* c, const char* label, size_t npoints, int windows = 0 /* table geometry planned by the caller, or 0: the library's per-set policy */);
   GensStream(GensStream&& o) noexcept : c(o.c), g(o.g), compressed(std::move(o.compressed)) { o.g = nullptr; }
   GensStream& operator=(GensStream&& o) noexcept;
   ~GensStream();

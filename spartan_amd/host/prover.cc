@@ -137,7 +137,11 @@ static DevTable tab_eq(sp_ctx* c, const FqVec& r) { sp_table* t; SPX(sp_eq_expan
 // ------------------------------------------------------------------ generators (commitments.rs:15-33)
 static const uint8_t kBasepointCompressed[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                                  0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
-GensStream::GensStream(sp_ctx* c_, const char* label, size_t npoints) : c(c_) {
+GensStream::GensStream(sp_ctx* c_, const char* label, size_t npoints, int windows) : c(c_) {
+  // windows != 0: the table geometry SNARKGens planned for this stream together with its sibling (sp_gens_plan_pair): handed to the
+  // library as option msm.windows for the time of this creation
+  struct WindowsFor { sp_ctx* c; bool on; WindowsFor(sp_ctx* c_, int w) : c(c_), on(w != 0) { if (on) SPX(sp_ctx_set_option(c, "msm.windows", std::to_string(w).c_str())); }
+                      ~WindowsFor() { if (on) (void)sp_ctx_set_option(c, "msm.windows", "0"); } } windows_for(c_, windows);
   Shake256 shake;  // commitments.rs:16-19
   shake.absorb(label, strlen(label));
   shake.absorb(kBasepointCompressed, 32);
@@ -189,10 +193,8 @@ static size_t sat_stream_points(size_t nvp) {
 NIZKGens::NIZKGens(Ctx& ctx, size_t, size_t num_vars, size_t num_inputs)
     : stream_sat(ctx.h, "gens_r1cs_sat", sat_stream_points(pad_vars(num_vars, num_inputs))),
       gens_r1cs_sat(make_r1cs_gens(stream_sat, pad_vars(num_vars, num_inputs))) {}
-SNARKGens::SNARKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, size_t nnz)
-    : stream_sat(ctx.h, "gens_r1cs_sat", sat_stream_points(pad_vars(num_vars, num_inputs))) {
+SNARKGens::SNARKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inputs, size_t nnz) {
   size_t nvp = pad_vars(num_vars, num_inputs);
-  gens_r1cs_sat = make_r1cs_gens(stream_sat, nvp);
   // r1cs.rs:33-48 -> sparse_mlpoly.rs:313-337, batch_size = 3
   size_t nvx = log_2(num_cons), nvy = log_2(2 * nvp);
   size_t num_vars_ops = log_2(next_pow2(nnz)) + log_2(next_pow2(3 * 5));
@@ -200,7 +202,13 @@ SNARKGens::SNARKGens(Ctx& ctx, size_t num_cons, size_t num_vars, size_t num_inpu
   size_t num_vars_derefs = log_2(next_pow2(nnz)) + log_2(next_pow2(3 * 2));
   size_t mx = 0;
   for (size_t v : {num_vars_ops, num_vars_mem, num_vars_derefs}) mx = std::max(mx, pow2(v - v / 2));
-  stream_eval = GensStream(ctx.h, "gens_r1cs_eval", mx + 2);
+  // the window tables of the two streams are sized TOGETHER (round 6): a proof commits num_vars scalars under the first stream and
+  // 6 * nnz (`derefs`) under the second; the library picks the pair of window counts with the fewest additions that fits the free HBM
+  int w_sat = 0, w_eval = 0;
+  SPX(sp_gens_plan_pair(ctx.h, sat_stream_points(nvp), mx + 2, (double)nvp, 6.0 * (double)next_pow2(nnz), &w_sat, &w_eval));
+  stream_sat = GensStream(ctx.h, "gens_r1cs_sat", sat_stream_points(nvp), w_sat);
+  gens_r1cs_sat = make_r1cs_gens(stream_sat, nvp);
+  stream_eval = GensStream(ctx.h, "gens_r1cs_eval", mx + 2, w_eval);
   gens_r1cs_eval.gens_ops = stream_eval.poly_commitment_gens(num_vars_ops);
   gens_r1cs_eval.gens_mem = stream_eval.poly_commitment_gens(num_vars_mem);
   gens_r1cs_eval.gens_derefs = stream_eval.poly_commitment_gens(num_vars_derefs);

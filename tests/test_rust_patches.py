@@ -43,6 +43,8 @@ def test_seed_hooks_and_gpu_feature_patches_apply_to_the_reference(tmp_path):
     assert open(os.path.join(d, "src", "gpu.rs")).read() == open(os.path.join(ROOT, "rust_shim", "src", "gpu.rs")).read()
     for seam in os.listdir(os.path.join(ROOT, "rust_shim", "seams")):
         assert open(os.path.join(d, "src", "gpu_seams", seam)).read() == open(os.path.join(ROOT, "rust_shim", "seams", seam)).read(), seam
+    libg = open(os.path.join(d, "src", "lib.rs")).read()
+    assert libg.count("gpu::plan_snark_gens(num_cons, num_vars_padded, num_nz_entries);") == 1 and libg.index("gpu::plan_snark_gens") < libg.index("impl NIZKGens {")
     assert 'include!("gpu_seams/sumcheck.rs");' in open(os.path.join(d, "src", "sumcheck.rs")).read()
     assert 'include!("../gpu_seams/bullet.rs");' in open(os.path.join(d, "src", "nizk", "bullet.rs")).read()
 
