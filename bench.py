@@ -450,7 +450,13 @@ def main():
         # entries per (point, window) sub-table = 2^(c-1); the stride of a table entry follows from the table's size
         ent = [(len(gens.stream(k)) // 32) * (-(-254 // wb[k])) * (1 << (wb[k] - 1)) for k in (0, 1)]
         stride = 128  # one 128-byte line per entry of the gathered tables (table_bytes also counts the packed LDS-form tables when they are built)
+        free0 = torch.cuda.mem_get_info(local_rank)[0]
         gath = gather_ceiling([gens.table_bytes(0) / 1e9, gens.table_bytes(1) / 1e9], [1 << (wb[0] - 1), 1 << (wb[1] - 1)], stride)
+        # the probe is a process of its own that takes what is free (up to the larger table's size): the driver hands its pages back a
+        # moment AFTER it exits — a 2^24 proof started straight behind it ran out of device memory with 150 GB nominally free
+        t_wait = time.time()
+        while torch.cuda.mem_get_info(local_rank)[0] < free0 - (1 << 30) and time.time() - t_wait < 60:
+            time.sleep(0.2)
     if sharded:
         proof = step()  # unsharded bytes: every sharded proof below must equal them
         shard_transport = enable_sharding(P, ctx, dist, rank, world)

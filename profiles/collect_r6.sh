@@ -33,7 +33,7 @@ for s in 20 22; do
   [ $s = 20 ] && pmc tcc$s "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" -- $B
   python profiles/pmc_summarize.py $O/fetch$s.csv $O/write$s.csv r6_pmc_hbm_traffic_2p$s.txt $s "" > $O/pmc_hbm_traffic_2p$s.txt 2>&1
   python profiles/pmc_counters.py $O/wait$s.csv $([ $s = 20 ] && echo $O/tcc$s.csv) > $O/pmc_kernels_2p$s.txt 2>&1
-  python profiles/fq_bandwidth.py $O/stats$s.db $O/fetch$s.csv $O/write$s.csv profiles/r6_kernel_resources.txt > $O/fq_bandwidth_2p$s.txt 2>&1
+  python profiles/fq_bandwidth.py $O/stats$s.db $O/fetch$s.csv $O/write$s.csv profiles/r6_kernel_resources.txt $O/wait$s.csv > $O/fq_bandwidth_2p$s.txt 2>&1
 done
 # the small-memory configuration (LDS-staged row MSM + 10-bit tables for the latency kernels) at 2^20: its own traffic entry
 SM=msm.form=1,msm.lds_bits=10,msm.wbits=10
@@ -56,7 +56,7 @@ python bench.py > $O/bench_line.json 2> $O/bench_line.err
 SPARTAN_OPTIONS=testing.unlock=1,host.callstats=1 timeout 300 python bench.py --no-cpu-baseline --concurrent 0 --steps 4 --warmup 1 --no-side-metrics --no-strong > /dev/null 2> $O/callstats.err; grep callstats $O/callstats.err | tail -56 > $O/callstats.txt
 for s in 16 18; do python bench.py --log2-cons $s --cpu-log2-cons 0 --no-cpu-baseline > $O/bench_line_2p$s.json 2> $O/bench_line_2p$s.err; done
 python bench.py --log2-cons 22 --no-cpu-baseline --steps 8 > $O/bench_line_2p22.json 2> $O/bench_line_2p22.err
-python bench.py --log2-cons 24 --no-cpu-baseline --steps 3 --concurrent 0 --no-side-metrics > $O/bench_line_2p24.json 2> $O/bench_line_2p24.err
+python bench.py --log2-cons 24 --no-cpu-baseline --steps 3 --concurrent 0 --no-side-metrics --no-strong > $O/bench_line_2p24.json 2> $O/bench_line_2p24.err
 SPARTAN_OPTIONS=$SM python bench.py --no-cpu-baseline --concurrent 0 > $O/bench_line_small_memory.json 2> $O/bench_line_small_memory.err
 ./bench/ubench_fpmul > $O/ubench_fpmul.txt 2>&1
 rm -f $O/*.db $O/fetch*.csv $O/write*.csv $O/wait*.csv $O/tcc*.csv $O/probe_wait.csv
