@@ -1,0 +1,109 @@
+// What one Fiat-Shamir round trip costs beyond its kernel, and what launching the NEXT round's kernel ahead of its challenge buys
+// ("declined on estimates, not measurements"). Standalone: hipcc --offload-arch=gfx950 -O3 -o trip_probe trip_probe.hip
+//   A  the product's mechanism: launch (challenge in the kernel arguments) -> kernel -> flag in the host page -> the proving thread sees it
+//   B  the kernel of round j+1 is enqueued while round j runs and spins on a doorbell word in the host page; the proving thread writes the
+//      challenge + doorbell when it has it. Launch and dispatch latency are off the chain; what stays is one PCIe read of the doorbell.
+// `work` = dependent 64-bit multiply-adds per thread (about 8 ns each): the kernel body a trip carries (7-9 us for k_cubic_bind2_eval).
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t body(uint64_t x, int work) {
+  for (int i = 0; i < work; i++) x = x * 6364136223846793005ull + 1442695040888963407ull;
+  return x;
+}
+__device__ __forceinline__ void done(volatile uint32_t* flag, uint32_t* counter, uint32_t seq) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    if (gridDim.x > 1) {
+      if (atomicAdd(counter, 1u) != gridDim.x - 1) return;
+      __threadfence_system();
+      *counter = 0;
+    }
+    *flag = seq;
+  }
+}
+__global__ void __launch_bounds__(256) k_args(volatile uint32_t* flag, uint32_t* counter, uint32_t seq, uint64_t challenge, uint64_t* sink, int work) {
+  uint64_t x = body(challenge + threadIdx.x, work);
+  if (x == 42) *sink = x;
+  done(flag, counter, seq);
+}
+__global__ void __launch_bounds__(256) k_bell(volatile uint32_t* flag, uint32_t* counter, uint32_t seq, const uint32_t* bell, const uint64_t* challenge, uint64_t* sink,
+                                              int work) {
+  __shared__ uint64_t ch;
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();  // 100 MHz
+    bool ok = true;
+    while (__hip_atomic_load(bell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (wall_clock64() - t0 > 200000000ll) { ok = false; break; }  // 2 s: never hang the box
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ch = ok ? __hip_atomic_load(challenge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0xdeadull;
+  }
+  __syncthreads();
+  uint64_t x = body(ch + threadIdx.x, work);
+  if (x == 42) *sink = x;
+  done(flag, counter, seq);
+}
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool wait_flag(volatile uint32_t* flag, uint32_t seq) {
+  const double t0 = now_us();
+  while (*flag != seq) {
+    if (now_us() - t0 > 3e6) { fprintf(stderr, "flag %u never arrived (have %u)\n", seq, *flag); return false; }
+  }
+  return true;
+}
+int main(int argc, char** argv) {
+  const int trips = argc > 1 ? atoi(argv[1]) : 2000;
+  uint8_t* page = nullptr;
+  CHK(hipHostMalloc((void**)&page, 4096, hipHostMallocMapped));
+  volatile uint32_t* flag = (volatile uint32_t*)page;          // device -> host
+  uint32_t* bell = (uint32_t*)(page + 256);                     // host -> device
+  uint64_t* challenge = (uint64_t*)(page + 512);
+  uint32_t* counter; uint64_t* sink;
+  CHK(hipMalloc((void**)&counter, 64)); CHK(hipMalloc((void**)&sink, 64)); CHK(hipMemset(counter, 0, 64));
+  hipStream_t st; CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const int works[3] = {0, 400, 900};
+  const int grids[2] = {1, 16};
+  for (int gi = 0; gi < 2; gi++)
+    for (int wi = 0; wi < 3; wi++) {
+      const int work = works[wi], grid = grids[gi];
+      double tA = 0, tB = 0;
+      for (int rep = 0; rep < 2; rep++) {  // rep 0 warms up
+        *flag = 0; *bell = 0; CHK(hipStreamSynchronize(st));
+        // A: launch with the challenge in the arguments, wait for the flag
+        double t0 = now_us();
+        for (uint32_t j = 1; j <= (uint32_t)trips; j++) {
+          hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, j, (uint64_t)j * 77, sink, work);
+          if (!wait_flag(flag, j)) return 1;
+        }
+        tA = (now_us() - t0) / trips;
+        CHK(hipStreamSynchronize(st));
+        // B: one launch ahead, doorbell in the host page
+        *flag = 0; *bell = 0;
+        hipLaunchKernelGGL(k_bell, dim3(grid), dim3(256), 0, st, flag, counter, 1u, bell, challenge, sink, work);
+        t0 = now_us();
+        for (uint32_t j = 1; j <= (uint32_t)trips; j++) {
+          *challenge = (uint64_t)j * 77;
+          __atomic_store_n(bell, j, __ATOMIC_RELEASE);  // the challenge of trip j is known: ring
+          if (j < (uint32_t)trips) hipLaunchKernelGGL(k_bell, dim3(grid), dim3(256), 0, st, flag, counter, j + 1, bell, challenge, sink, work);  // the next trip's kernel, ahead
+          if (!wait_flag(flag, j)) return 1;
+        }
+        tB = (now_us() - t0) / trips;
+        CHK(hipStreamSynchronize(st));
+      }
+      // the kernel alone (events over back-to-back launches)
+      hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+      CHK(hipEventRecord(e0, st));
+      for (int j = 0; j < 200; j++) hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, 0u, 1ull, sink, work);
+      CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
+      float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+      printf("grid %2d x 256, body %3d mul-adds: back-to-back launch %.2f us | A launch-per-trip %.2f us/trip | B launched ahead + doorbell %.2f us/trip\n", grid, work,
+             ms * 1e3 / 200, tA, tB);
+    }
+  return 0;
+}

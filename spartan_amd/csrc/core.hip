@@ -1248,8 +1248,8 @@ int sp_gens_windows(const sp_gens* g) { return g ? g->geom.nwin : 0; }
 // a time: whichever is built first takes what it likes and the other what is left. Here the pair is chosen together: the (windows_a,
 // windows_b) that minimises the mixed additions of a proof, w_a * windows_a + w_b * windows_b, among the pairs whose tables fit the free
 // device memory less the proof's reserve (and msm.table_gb each); ties go to the smaller tables. 2^20: 17 / 17 (35.5 + 141.8 GB; one set
-// at a time: 17 / 18); 2^22: 17 / 18 (the only pair that fits); 2^24: 19 / 21 (55.8 + 98.8 GB; one at a time: 18 / 22, more memory AND more
-// additions; 20 / 20 — 183 GB, the fewest additions of all — leaves the 2^24 proof too little). The caller sets option msm.windows to each result around the creation of its stream (0 = leave it to the per-set policy:
+// at a time: 17 / 18); 2^22: 17 / 18 (the only pair that fits); 2^24: 22 / 20 (18.3 + 146 GB with 299 GB free; one at a time: 18 / 22, as much memory
+// and 6 % more additions; 20 / 20 — 183 GB, fewer additions still — would leave the 2^24 proof too little). The caller sets option msm.windows to each result around the creation of its stream (0 = leave it to the per-set policy:
 // returned when a geometry is forced by msm.wbits / msm.windows, or for streams too small to matter).
 int32_t sp_gens_plan_pair(sp_ctx* c, size_t n_a, size_t n_b, double w_a, double w_b, int* windows_a, int* windows_b) {
   if (!c || !windows_a || !windows_b || n_a == 0 || n_b == 0) return SP_EINVAL;

@@ -204,14 +204,17 @@ def test_instance_new_matches_synthetic_and_rejects_bad_input(P, ctx, orc):
 @pytest.mark.parametrize("s", [16, 20, 22, 24])
 def test_snark_full_size_properties(P, ctx, orc, s):
     """BASELINE sizes (configs[1] 2^16, configs[2] 2^20, configs[4] 2^22) and 2^24 — the largest instance whose generator
-    tables fit one GPU's HBM (19 windows for the 4097-point stream, 21 for the 16386-point one: 155 GB of tables) — where the oracle prover is too slow to run in a test: size-independent properties — README proof
+    tables fit one GPU's HBM (about 160 GB of tables: 20-22 windows per stream) — where the oracle prover is too slow to run in a test: size-independent properties — README proof
     lengths, determinism, and the oracle's restated VERIFIER accepts the GPU proof bytes against the GPU computation commitment
     (and rejects a corrupted proof)."""
     N = 1 << s
     inst = P.Instance.produce_synthetic_r1cs(ctx, N, N, 10, seed=s)
     gens = P.SNARKGens(ctx, N, N, 10, N)
     if s == 24:
-        assert gens.windows(0) <= 19 and gens.windows(1) <= 22   # (19, 21) in a process of its own: planned together (sp_gens_plan_pair): 155 GB; one set at a time 18 / 22 (159 GB); rounds 2-5: uniform 14 / 12 bits = 19 / 22 windows, 177 GB
+        # planned together (sp_gens_plan_pair) against the memory that is free in THIS process: the pair with the fewest additions per proof (the
+        # witness's 2^24 scalars x windows(0) + the six derefs vectors x windows(1)) that fits: 22 / 20 (164 GB) in a process of its own, a
+        # neighbouring pair when earlier tests hold memory; rounds 2-5: uniform 14 / 12 bits = 19 / 22 windows (177 GB), the bound asserted here
+        assert gens.windows(0) + 6 * gens.windows(1) <= 19 + 6 * 22
     enc = P.SNARK.encode(ctx, inst, gens)
     tape = P.seed_scalar(b"tape", s)
     proof = P.SNARK.prove(ctx, inst, enc, inst.vars, inst.inputs, gens, b"snark_example", tape)
