@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 __device__ __forceinline__ uint64_t body(uint64_t x, int work) {
@@ -27,10 +28,21 @@ __device__ __forceinline__ void done(volatile uint32_t* flag, uint32_t* counter,
     *flag = seq;
   }
 }
-__global__ void __launch_bounds__(256) k_args(volatile uint32_t* flag, uint32_t* counter, uint32_t seq, uint64_t challenge, uint64_t* sink, int work) {
+// stamps[2*seq], [2*seq+1]: shader cycles (clock64) and 100 MHz ticks (wall_clock64) the body took in workgroup 0 -> the clock the body ran at
+__global__ void __launch_bounds__(256) k_args(volatile uint32_t* flag, uint32_t* counter, uint32_t seq, uint64_t challenge, uint64_t* sink, int work, long long* stamps) {
+  const long long c0 = clock64(), w0 = wall_clock64();
   uint64_t x = body(challenge + threadIdx.x, work);
   if (x == 42) *sink = x;
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) { stamps[2 * (seq & 4095)] = clock64() - c0; stamps[2 * (seq & 4095) + 1] = wall_clock64() - w0; }
   done(flag, counter, seq);
+}
+// C: something else keeps the chip busy meanwhile (one low-priority wavefront per SIMD on every CU doing dependent multiply-adds until told to stop)
+__global__ void __launch_bounds__(256) k_heater(const uint32_t* stop, uint64_t* sink) {
+  __builtin_amdgcn_s_setprio(0);
+  uint64_t x = threadIdx.x;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < 1000000000ll /* 10 s */) x = body(x, 2000);
+  if (x == 42) *sink = x;
 }
 __global__ void __launch_bounds__(256) k_bell(volatile uint32_t* flag, uint32_t* counter, uint32_t seq, const uint32_t* bell, const uint64_t* challenge, uint64_t* sink,
                                               int work) {
@@ -57,6 +69,15 @@ static bool wait_flag(volatile uint32_t* flag, uint32_t seq) {
   }
   return true;
 }
+#include <algorithm>
+#include <vector>
+static double median_mhz(const long long* stamps, int n) {  // stamps live in host-mapped memory
+  std::vector<double> v;
+  for (int i = 1; i < std::min(n, 4096); i++) if (stamps[2 * i + 1] > 0) v.push_back((double)stamps[2 * i] / (double)stamps[2 * i + 1] * 100.0);
+  if (v.empty()) return 0;
+  std::sort(v.begin(), v.end());
+  return v[v.size() / 2];
+}
 int main(int argc, char** argv) {
   const int trips = argc > 1 ? atoi(argv[1]) : 2000;
   uint8_t* page = nullptr;
@@ -66,23 +87,39 @@ int main(int argc, char** argv) {
   uint64_t* challenge = (uint64_t*)(page + 512);
   uint32_t* counter; uint64_t* sink;
   CHK(hipMalloc((void**)&counter, 64)); CHK(hipMalloc((void**)&sink, 64)); CHK(hipMemset(counter, 0, 64));
-  hipStream_t st; CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  const int works[3] = {0, 400, 900};
+  hipStream_t st, st2; CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); CHK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+  long long* stamps = nullptr; CHK(hipHostMalloc((void**)&stamps, 4096 * 16, hipHostMallocMapped)); memset(stamps, 0, 4096 * 16);
+  uint32_t* stopw = (uint32_t*)(page + 1024);
+  hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0)); const int ncu = prop.multiProcessorCount;
+  const int works[3] = {8, 400, 900};
   const int grids[2] = {1, 16};
   for (int gi = 0; gi < 2; gi++)
     for (int wi = 0; wi < 3; wi++) {
       const int work = works[wi], grid = grids[gi];
-      double tA = 0, tB = 0;
+      double tA = 0, tB = 0, tC = 0, mhzA = 0, mhzC = 0, mhzBB = 0;
       for (int rep = 0; rep < 2; rep++) {  // rep 0 warms up
         *flag = 0; *bell = 0; CHK(hipStreamSynchronize(st));
         // A: launch with the challenge in the arguments, wait for the flag
         double t0 = now_us();
         for (uint32_t j = 1; j <= (uint32_t)trips; j++) {
-          hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, j, (uint64_t)j * 77, sink, work);
+          hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, j, (uint64_t)j * 77, sink, work, stamps);
           if (!wait_flag(flag, j)) return 1;
         }
         tA = (now_us() - t0) / trips;
         CHK(hipStreamSynchronize(st));
+        mhzA = median_mhz(stamps, trips);
+        // C: A again while a heater kernel occupies one wavefront per SIMD of every CU
+        *flag = 0; *stopw = 0;
+        hipLaunchKernelGGL(k_heater, dim3(ncu), dim3(256), 0, st2, (const uint32_t*)stopw, sink);
+        t0 = now_us();
+        for (uint32_t j = 1; j <= (uint32_t)trips; j++) {
+          hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, j, (uint64_t)j * 77, sink, work, stamps);
+          if (!wait_flag(flag, j)) return 1;
+        }
+        tC = (now_us() - t0) / trips;
+        __atomic_store_n(stopw, 1u, __ATOMIC_RELEASE);
+        CHK(hipStreamSynchronize(st2)); CHK(hipStreamSynchronize(st));
+        mhzC = median_mhz(stamps, trips);
         // B: one launch ahead, doorbell in the host page
         *flag = 0; *bell = 0;
         hipLaunchKernelGGL(k_bell, dim3(grid), dim3(256), 0, st, flag, counter, 1u, bell, challenge, sink, work);
@@ -99,11 +136,12 @@ int main(int argc, char** argv) {
       // the kernel alone (events over back-to-back launches)
       hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
       CHK(hipEventRecord(e0, st));
-      for (int j = 0; j < 200; j++) hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, 0u, 1ull, sink, work);
+      for (int j = 0; j < 200; j++) hipLaunchKernelGGL(k_args, dim3(grid), dim3(256), 0, st, flag, counter, (uint32_t)j, 1ull, sink, work, stamps);
       CHK(hipEventRecord(e1, st)); CHK(hipEventSynchronize(e1));
       float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
-      printf("grid %2d x 256, body %3d mul-adds: back-to-back launch %.2f us | A launch-per-trip %.2f us/trip | B launched ahead + doorbell %.2f us/trip\n", grid, work,
-             ms * 1e3 / 200, tA, tB);
+      mhzBB = median_mhz(stamps, 200);
+      printf("grid %2d x 256, body %3d mul-adds: back-to-back launch %.2f us (body at %.0f MHz) | A launch-per-trip %.2f us/trip (body at %.0f MHz) | B launched ahead + doorbell %.2f us/trip | C = A beside a busy chip %.2f us/trip (%.0f MHz)\n",
+             grid, work, ms * 1e3 / 200, mhzBB, tA, mhzA, tB, tC, mhzC);
     }
   return 0;
 }

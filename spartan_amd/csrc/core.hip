@@ -126,6 +126,7 @@ __global__ void k_done(volatile uint32_t* flag, uint32_t seq) { SP_FG_PRIO();
 // Wait until everything queued on the main stream has run. The stream is in-order, so the flag kernel runs after the
 // kernels (and copies) before it have completed, and their results in host memory precede the flag on the way to the host.
 uint32_t sync_post(sp_ctx* c) {
+  ahead_cancel(c);
   uint32_t seq = ++c->done_seq;
   hipLaunchKernelGGL(k_done, dim3(1), dim3(1), 0, c->stream, c->done_flag, seq);
   return seq;
@@ -149,6 +150,7 @@ int32_t sync_wait(sp_ctx* c, uint32_t seq) {
 }
 int32_t sync_spin(sp_ctx* c) { return sync_wait(c, sync_post(c)); }
 DoneSig sig_make(sp_ctx* c, size_t total_workgroups) {
+  ahead_cancel(c);
   if (!c->done_counter) return sig_none();
   return DoneSig{c->done_flag, c->done_counter, ++c->done_seq, (uint32_t)total_workgroups, c->ktime};
 }
@@ -1092,11 +1094,13 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
     c->bg_blocks = c->n_cus * (int)c->opt.v[OPT_BG_EIGHTHS] / 8;
   }
   HIPCHK(hipHostMalloc((void**)&c->hmap, HMAP_SIZE, hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&c->done_flag, 64, hipHostMallocDefault));
-  *c->done_flag = 0;
+  HIPCHK(hipHostMalloc((void**)&c->done_flag, 128, hipHostMallocDefault));
+  memset((void*)c->done_flag, 0, 128);
+  HIPCHK(hipHostMalloc((void**)&c->bell, sizeof(AheadBell), hipHostMallocDefault));
+  memset(c->bell, 0, sizeof(AheadBell));
   c->done_seq = 0;
-  HIPCHK(hipMalloc((void**)&c->done_counter, 64));
-  HIPCHK(hipMemset(c->done_counter, 0, 64));
+  HIPCHK(hipMalloc((void**)&c->done_counter, 512));  // word 0: DoneSig::counter | words 4..: row tickets of the fused small commitment | word 64: AheadArgs::decision | words 80..95: AheadArgs::chal
+  HIPCHK(hipMemset(c->done_counter, 0, 512));
   HIPCHK(hipMalloc((void**)&c->q_heads, 4 * (size_t)MSMQ_BLOCK_WORDS * MSMQ_BLOCKS));
 #ifdef SP_KTIME
   if (c->opt.v[OPT_DEBUG_KTIME]) { HIPCHK(hipMalloc((void**)&c->ktime, 64 * 8)); HIPCHK(hipMemset(c->ktime, 0, 64 * 8)); }
@@ -1119,6 +1123,8 @@ extern "C" {
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
+  ahead_cancel(c);
+  (void)hipStreamSynchronize(c->stream);
   prof_drain(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   for (auto& kv : c->pool)
@@ -1129,6 +1135,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->hmap) (void)hipHostFree(c->hmap);
   if (c->done_flag) (void)hipHostFree((void*)c->done_flag);
+  if (c->bell) (void)hipHostFree((void*)c->bell);
   if (c->done_counter) (void)hipFree(c->done_counter);
   if (c->prof_epoch) (void)hipEventDestroy(c->prof_epoch);
   if (c->q_heads) (void)hipFree(c->q_heads);

@@ -62,6 +62,107 @@ struct sp_job {
   hipStream_t stream;  // the stream the job runs on (a background stream, or the main stream for sp_commit_rows_dev_start)
 };
 
+// ---- a trip's kernel launched AHEAD of its challenges (round 6; bench/trip_probe.hip: launch + dispatch are 3-6 us of a ~20 us trip) -------------
+// While the kernel of trip j runs, the kernel of trip j + 1 is already enqueued behind it on the main stream (in-order: it starts when j has
+// finished, with j's tables visible) and waits for the proving thread to write the challenges into `AheadBell` and ring it. The first workgroup
+// polls the bell in host memory and publishes the decision — go, or give up (cancelled by the host, or nothing heard for AHEAD_TIMEOUT) — in a device
+// word the other workgroups poll; a kernel that gives up touches nothing, says so in host memory (`gave_up`), and the host launches the trip the
+// ordinary way. Nothing can hang: every wait on either side is bounded.
+struct AheadBell {        // host memory, 128-byte aligned (its own pinned allocation): ONE snapshot of it carries the bell and the challenges
+  uint32_t bell;          // written last by the host: (sequence << 1) | cancel
+  uint32_t check;         // sequence ^ the xor of r[0..16): a snapshot that shows the bell but not yet all of r is recognised and read again
+  uint32_t r[16];         // the trip's challenges r0 | r1 as 32-bit words
+  uint32_t pad[14];
+};
+struct AheadArgs {        // kernel argument; bell == nullptr: an ordinary launch, challenges in the arguments
+  const AheadBell* bell;
+  uint32_t* decision;          // device word: (sequence << 2) | {1 go, 2 give up}: the FIRST proposal for a sequence stands, every workgroup follows it
+  uint32_t* chal;              // device: r0 | r1 (16 words) as a polling workgroup read them from the bell
+  volatile uint32_t* gave_up;  // host word: the sequence of the last launch that gave up
+  uint32_t seq;
+};
+static inline AheadArgs ahead_none() { return AheadArgs{nullptr, nullptr, nullptr, nullptr, 0}; }
+constexpr long long AHEAD_TIMEOUT = 2000000;  // 20 ms of the 100 MHz wall clock
+constexpr unsigned AHEAD_POLLERS = 32;        // workgroups (the first of the grid) that watch the bell in host memory themselves; the rest follow the decision word
+#if defined(__HIPCC__)
+// Threads 0..31 of every workgroup (half a wavefront, converged). Returns (to all of them) 1 = go: the challenges are in ah.chal; 2 = give up.
+// A polling workgroup loads the bell's 128 bytes with one instruction (32 lanes x 4 bytes) — bell, check and challenges in one PCIe round trip —
+// and proposes what it sees: go (a ring with a consistent snapshot), give up (a cancel, a bell that has moved on to a later launch, or nothing for
+// AHEAD_TIMEOUT). The first proposal for this sequence number wins the compare-and-swap on the decision word and EVERY workgroup follows it, so a
+// ring that arrives while some workgroup is timing out cannot split the grid.
+__device__ __forceinline__ uint32_t ahead_wait(const AheadArgs& ah) {
+  const long long t0 = wall_clock64();
+  const unsigned lane = threadIdx.x;
+  const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const bool poller = wg < AHEAD_POLLERS;
+  const uint32_t* line = reinterpret_cast<const uint32_t*>(ah.bell);
+  uint32_t d = 0;
+  uint32_t w = poller ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+  for (;;) {
+    // the next look at the bell is under way while this one is examined: a PCIe read takes ~2 us, and the ring should be seen one read after it lands
+    const uint32_t wn = poller ? __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    const uint32_t v = __hip_atomic_load(ah.decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((v >> 2) == ah.seq) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); d = v & 3; break; }
+    uint32_t mine = 0;
+    if (poller) {
+      const uint32_t b = __shfl(w, 0, 32), chk = __shfl(w, 1, 32);
+      if ((b >> 1) == ah.seq) {
+        if (b & 1) mine = 2;
+        else {
+          uint32_t x = (lane >= 2 && lane < 18) ? w : 0u;
+#pragma unroll
+          for (int m = 16; m > 0; m >>= 1) x ^= __shfl_xor(x, m, 32);
+          if ((x ^ ah.seq) == chk) {
+            mine = 1;
+            if (lane >= 2 && lane < 18) __hip_atomic_store(ah.chal + (lane - 2), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      } else if ((b >> 1) > ah.seq) mine = 2;  // the bell has moved on to a later launch: this one was abandoned
+    }
+    if (!mine && wall_clock64() - t0 > (poller ? AHEAD_TIMEOUT : 4 * AHEAD_TIMEOUT)) mine = 2;
+    if (mine) {
+      uint32_t got = 0;
+      if (lane == 0) {
+        uint32_t old = v;
+        const uint32_t want = (ah.seq << 2) | mine;
+        for (;;) {  // the first proposal for this sequence stands
+          if ((old >> 2) == ah.seq) { got = old & 3; break; }
+          if (__hip_atomic_compare_exchange_strong(ah.decision, &old, want, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+            got = mine;
+            if (mine == 2) { *ah.gave_up = ah.seq; __threadfence_system(); }
+            break;
+          }
+        }
+      }
+      d = __shfl(got, 0, 32);
+      break;
+    }
+    if (!poller) __builtin_amdgcn_s_sleep(2);
+    w = wn;
+  }
+  return d;
+}
+__device__ __forceinline__ Fq ahead_challenge(const uint32_t* p) {  // from ah.chal, after the decision was seen (acquire)
+  Fq x;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const uint64_t lo = __hip_atomic_load(p + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(p + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x.l[w] = lo | (hi << 32);
+  }
+  return x;
+}
+#endif
+struct sp_table;
+struct AheadArm {  // what the enqueued kernel was armed for: the next call has to be exactly this to ring it, anything else cancels it
+  bool on = false;
+  uint32_t seq = 0;
+  size_t ninst = 0, len = 0, nblk = 0;
+  bool host = false, weighted = false, tail = false;
+  sp_table *A[24], *B[24], *C[24];
+  Fq w[24];
+  uint32_t sig_seq = 0, sig_total = 0;
+};
+
 struct sp_ctx {
   int dev;
   SpOptions opt;  // options.hpp: a copy of the process-wide defaults at creation, changed by sp_ctx_set_option
@@ -101,6 +202,9 @@ struct sp_ctx {
   hipEvent_t vm_ev = nullptr;
   struct { bool active; int kind; size_t nblk; bool on_host; uint32_t seq; } pend_eval = {false, 0, 0, false, 0};  // sp_sumcheck_bind_eval_start .. _collect
   uint8_t* hmap;  // host-mapped (fine-grained) page: small kernel inputs are read, small results written, without a DMA hop
+  AheadBell* bell = nullptr;  // launches ahead of their challenges (AheadArm): the bell page; the decision word is done_counter[64], the relayed challenges done_counter[80..96), gave_up is done_flag[16]
+  AheadArm ahead;
+  uint32_t ahead_seq = 0;
 
 
   // size-class pool of device buffers: per-proof tables are recycled instead of hipMalloc/hipFree'd
@@ -119,6 +223,12 @@ struct sp_ctx {
   std::vector<ProfSpan> prof_spans;  // launches of the shape-tracked families (the row MSMs) as intervals: sp_prof_read_spans
   hipEvent_t prof_epoch = nullptr;
 };
+// an enqueued launch that waits for its bell is told to give up: called by whatever is about to queue other work on the main stream, or wait for it
+static inline void ahead_cancel(sp_ctx* c) {
+  if (!c->ahead.on) return;
+  c->ahead.on = false;
+  __atomic_store_n(&c->bell->bell, (c->ahead.seq << 1) | 1u, __ATOMIC_RELEASE);
+}
 struct sp_gens {
   sp_ctx* ctx;
   size_t n;
@@ -176,6 +286,7 @@ struct ProfScope {
   const unsigned long long* issued = nullptr;
   ProfScope(sp_ctx* c_, int fam_, double bytes_, hipStream_t st_ = nullptr, double ops_ = 0.0, uint64_t shape_ = 0)
       : c(c_), fam(fam_), on(fam_ >= 0 && c_->prof_on != 0 && ((c_->prof_mask >> fam_) & 1)), st(st_ ? st_ : c_->stream), shape(shape_), bytes(bytes_), ops(ops_) {
+    if (st == c->stream) ahead_cancel(c);  // a launch on the main stream that is not the one an enqueued kernel waits for (AheadArm)
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;

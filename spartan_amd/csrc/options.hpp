@@ -45,6 +45,7 @@
   X(SUMCHECK_INLINE_ARGS, "sumcheck.inline_args", 1, 0, 1, 1, "table pointers of the batched sum-check kernels in the kernel arguments (0: the staged form that more than 24 instances or 13 variables fall back to - its test hook)")      \
   X(SUMCHECK_DOUBLE_ROUND_MAX_LEN, "sumcheck.double_round_max_len", 4096, 0, 1073741824, 1, "two rounds per trip while the tables have at most this many entries") \
   X(SUMCHECK_HOST_TAIL, "sumcheck.host_tail", 1, 0, 1, 1, "last <= 3 rounds of a batched sum-check on the proving core")                     \
+  X(SUMCHECK_LAUNCH_AHEAD, "sumcheck.launch_ahead", 1, 0, 2, 1, "two-rounds-per-trip kernels are enqueued one trip ahead and wait for their challenges on a bell in host memory (0: launched when the challenges are known; 2: test hook - the bell is never rung, every such launch gives up and is repeated the ordinary way)") \
   X(SPARK_PROD_LAYER2, "spark.prod_layer2", 1, 0, 1, 1, "two product-circuit layers per launch in the launch-sized middle of the tree")       \
   X(SPARK_PROD_LAYER2_MAX_LOG2, "spark.prod_layer2_max_log2", 18, 0, 40, 1, "... for layers of at most 2^this entries")                      \
   X(SPARK_EQ_FACTOR, "spark.eq_factor", 1, 0, 1, 1, "the eq table as a factor in the throughput-sized batched rounds")                       \

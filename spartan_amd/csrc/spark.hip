@@ -364,8 +364,21 @@ struct Bind2Inline {
   Triple2 t[24];
   Fq w[24];
 };
+// ah.bell != nullptr: the launch was enqueued ahead of its challenges (AheadArm, internal.hpp): it waits for the bell, takes r0 and r1 from there, or
+// gives up without touching anything.
 __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, Bind2Inline IN, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
-                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig) { SP_FG_PRIO();
+                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig, AheadArgs ah) { SP_FG_PRIO();
+  if (ah.bell) {
+    __shared__ uint32_t go;
+    if (threadIdx.x < 32) {
+      const uint32_t d = ahead_wait(ah);
+      if (threadIdx.x == 0) go = d;
+    }
+    __syncthreads();
+    if (go != 1) return;
+    r0 = ahead_challenge(ah.chal);
+    r1 = ahead_challenge(ah.chal + 8);
+  }
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
   __shared__ Fq red[18][8];
@@ -869,7 +882,8 @@ int32_t sp_table_scale_prefix(sp_ctx* c, sp_table* t, size_t n, const uint64_t k
 }
 
 // partials[ninst][nblk][18] -> out[ninst][18], one block per instance: thread = (component k < 18 of 32, slice of blocks)
-__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out, DoneSig sig) { SP_FG_PRIO();
+__global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict__ partials, size_t nblk, Fq* __restrict__ out, DoneSig sig, AheadArgs ah) { SP_FG_PRIO();
+  if (ah.bell && (__hip_atomic_load(ah.decision, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ((ah.seq << 2) | 1u))) return;  // behind a launch that gave up
   __shared__ Fq sm[8][18];
   const int k = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const Fq* p = partials + (size_t)blockIdx.x * nblk * 18;
@@ -887,8 +901,40 @@ __global__ void __launch_bounds__(256) k_reduce_partials18(const Fq* __restrict_
   }
   signal_done(sig);
 }
-// shared by the two entry points below: launch k_cubic_bind2_eval, bring the 18 sums per instance to the host
 constexpr size_t TAIL_OFF = 12288, TAIL_MAX_INST = 21;  // the <= 8-entry tables of <= 21 instances behind the 18 sums per instance in the result page
+// The geometry of one k_cubic_bind2_eval trip over tables of length `len` (before its binds)
+struct Bind2Shape {
+  size_t n2, nblk;
+  bool host, tail;
+};
+static Bind2Shape bind2_shape(size_t len, int nbind, size_t ninst, bool want_tables) {
+  Bind2Shape s;
+  s.n2 = len >> nbind;
+  const size_t np = s.n2 < 4 ? s.n2 : 4, ng = s.n2 / np;
+  s.nblk = (ng + 7) / 8;
+  s.host = 32 * 18 * s.nblk * ninst <= HOST_SUM_BYTES;
+  s.tail = want_tables && s.n2 >= 2 && s.n2 <= 8 && ninst <= TAIL_MAX_INST && s.host && s.nblk == 1;
+  return s;
+}
+// enqueue the kernel(s) of one trip on the main stream; `ah.bell` set: ahead of its challenges (r0, r1 unused)
+static void bind2_enqueue(sp_ctx* c, const Bind2Inline& IN, bool inl, const Fq* dweights, size_t len, int nbind, const Fq& r0, const Fq& r1, size_t ninst,
+                          const Bind2Shape& sh, const DoneSig& sig, const AheadArgs& ah) {
+  const size_t ng = sh.n2 / (sh.n2 < 4 ? sh.n2 : 4);
+  Fq* partials = sh.host ? (Fq*)hres(c) : (Fq*)c->scratch;
+  Fq* dump = sh.tail ? (Fq*)(hres(c) + TAIL_OFF) : nullptr;
+  {
+    ProfScope ps(c, nbind ? PF_SC_BIND_EVAL : PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, (nbind ? 36.0 + 36.0 : 36.0) * (double)ng * (double)ninst);
+    hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)sh.nblk, (unsigned)ninst), dim3(256), 0, c->stream, inl ? (const Triple2*)nullptr : (const Triple2*)c->hmap, IN, dweights, len,
+                       nbind, r0, r1, partials, dump, sh.host ? sig : sig_none(), ah);
+  }
+  if (!sh.host) {
+    ProfScope ps(c, PF_REDUCE, 32.0 * 18 * (double)(sh.nblk * ninst));
+    hipLaunchKernelGGL(k_reduce_partials18, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, sh.nblk, (Fq*)hres(c), sig, ah);
+  }
+}
+// shared by the entry points below: one trip of k_cubic_bind2_eval, the 18 sums per instance brought to the host. Since round 6 the kernel of the
+// NEXT trip is enqueued before this one's results are waited for whenever the next trip is known to be a two-bind trip over the same tables
+// (the bound tables still have >= 4 entries): see AheadArm in internal.hpp. The next call rings it if it is that trip; anything else cancels it.
 static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, int nbind, const uint64_t* r0, const uint64_t* r1,
                             const uint64_t* weights, uint64_t* out_evals, uint64_t* out_coeffs, uint64_t* out_heads, uint64_t* out_tables = nullptr) {
   if (!c || !A || !B || !C || ninst == 0 || ninst > 64) return SP_EINVAL;
@@ -896,62 +942,136 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
   size_t len = A[0] ? A[0]->len : 0;
   if (len < ((size_t)1 << nbind) || len < 2 || !is_pow2(len)) return SP_EINVAL;
   const int do_bind = nbind;
-  size_t n2 = len >> nbind;
+  const size_t n2 = len >> nbind;
   if ((n2 >= 2 && !out_evals) || (n2 >= 4 && !out_coeffs) || (n2 == 1 && !out_heads)) return SP_EINVAL;
-  std::vector<Triple2> T(ninst);
-  std::vector<sp_table*> distinctC;
-  for (size_t k = 0; k < ninst; k++) {
+  for (size_t k = 0; k < ninst; k++)
     if (!A[k] || !B[k] || !C[k] || A[k]->len != len || B[k]->len != len || C[k]->len != len) return SP_EINVAL;
-    T[k] = Triple2{A[k]->d, B[k]->d, C[k]->d, nullptr};
-    bool first = true;
-    for (size_t m = 0; m < k; m++) first = first && C[m] != C[k];
-    if (first) {
-      distinctC.push_back(C[k]);
-      if (do_bind) {
-        SPCHK(table_ensure_alt(C[k], n2));
-        T[k].c_out = C[k]->alt;
-      }
-    }
-  }
   const bool inline_args = c->opt.v[OPT_SUMCHECK_INLINE_ARGS] != 0;  // A/B switch
   const bool inl = inline_args && ninst <= 24;
+  // is this the trip an enqueued kernel is waiting for?
+  AheadArm& arm = c->ahead;
+  bool rung = false;
+  if (arm.on) {
+    bool same = inl && nbind == 2 && r0 && r1 && arm.ninst == ninst && arm.len == len && arm.weighted == (weights != nullptr) &&
+                (!weights || memcmp(arm.w, weights, 32 * ninst) == 0);
+    for (size_t k = 0; same && k < ninst; k++) same = arm.A[k] == A[k] && arm.B[k] == B[k] && arm.C[k] == C[k];
+    if (same) rung = true;
+    else ahead_cancel(c);
+  }
+  // the instances' tables; a C shared between instances is bound once, out of place
+  std::vector<Triple2> T(ninst);
+  std::vector<sp_table*> distinctC;
+  auto triples = [&](size_t out_len) -> int32_t {
+    distinctC.clear();
+    for (size_t k = 0; k < ninst; k++) {
+      T[k] = Triple2{A[k]->d, B[k]->d, C[k]->d, nullptr};
+      bool first = true;
+      for (size_t m = 0; m < k; m++) first = first && C[m] != C[k];
+      if (first) {
+        distinctC.push_back(C[k]);
+        if (out_len) {
+          SPCHK(table_ensure_alt(C[k], out_len));
+          T[k].c_out = C[k]->alt;
+        }
+      }
+    }
+    return SP_OK;
+  };
+  SPCHK(triples(do_bind ? n2 : 0));
   Bind2Inline IN;
   const Fq* dweights = nullptr;
-  if (inl) {
-    memcpy(IN.t, T.data(), sizeof(Triple2) * ninst);
-    if (weights) { memcpy(IN.w, weights, 32 * ninst); dweights = (const Fq*)c->hmap; }  // non-null: "weighted"; the values come from IN.w
-  } else {
-    stage_small(c, 0, T.data(), sizeof(Triple2) * ninst);
-    dweights = weights ? (const Fq*)stage_small(c, sizeof(Triple2) * 64, weights, 32 * ninst) : nullptr;
-  }
-  size_t np = n2 < 4 ? n2 : 4, ng = n2 / np, nblk = (ng + 7) / 8;
-  SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 18 * (nblk + 1) * ninst));
-  bool host = 32 * 18 * nblk * ninst <= HOST_SUM_BYTES;
-  Fq* partials = host ? (Fq*)hres(c) : (Fq*)c->scratch;
-  const bool tail = out_tables && n2 >= 2 && n2 <= 8 && ninst <= TAIL_MAX_INST && host && nblk == 1;
-  Fq* dump = tail ? (Fq*)(hres(c) + TAIL_OFF) : nullptr;
-  Fq z = fq_zero();
-  DoneSig sig = sig_make(c, host ? nblk * ninst : ninst);  // raised by the last kernel of the trip
-  {
-    ProfScope ps(c, do_bind ? PF_SC_BIND_EVAL : PF_SC_EVAL, 96.0 * (double)len * (double)ninst, nullptr, (do_bind ? 36.0 + 36.0 : 36.0) * (double)ng * (double)ninst);
-    hipLaunchKernelGGL(k_cubic_bind2_eval, dim3((unsigned)nblk, (unsigned)ninst), dim3(256), 0, c->stream, inl ? (const Triple2*)nullptr : (const Triple2*)c->hmap, IN, dweights, len, nbind,
-                       r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, partials, dump, host ? sig : sig_none());
-  }
-  std::vector<Fq> sums(18 * ninst);
-  if (!host) {
-    {
-      ProfScope ps(c, PF_REDUCE, 32.0 * 18 * (double)(nblk * ninst));
-      hipLaunchKernelGGL(k_reduce_partials18, dim3((unsigned)ninst), dim3(256), 0, c->stream, (const Fq*)partials, nblk, (Fq*)hres(c), sig);
+  auto stage = [&]() {
+    if (inl) {
+      memcpy(IN.t, T.data(), sizeof(Triple2) * ninst);
+      if (weights) { memcpy(IN.w, weights, 32 * ninst); dweights = (const Fq*)c->hmap; }  // non-null: "weighted"; the values come from IN.w
+    } else {
+      stage_small(c, 0, T.data(), sizeof(Triple2) * ninst);
+      dweights = weights ? (const Fq*)stage_small(c, sizeof(Triple2) * 64, weights, 32 * ninst) : nullptr;
     }
+  };
+  const Bind2Shape sh = bind2_shape(len, nbind, ninst, out_tables != nullptr);
+  const Fq z = fq_zero();
+  DoneSig sig;
+  uint32_t rung_seq = 0;
+  if (rung) {
+    // the kernel is in the stream already: hand it the challenges
+    sig = DoneSig{c->done_flag, c->done_counter, arm.sig_seq, arm.sig_total, nullptr};
+    rung_seq = arm.seq;
+    arm.on = false;
+    uint32_t words[16], fold = rung_seq;
+    memcpy(words, r0, 32);
+    memcpy(words + 8, r1, 32);
+    for (int k = 0; k < 16; k++) { c->bell->r[k] = words[k]; fold ^= words[k]; }
+    c->bell->check = fold;
+    if (c->opt.v[OPT_SUMCHECK_LAUNCH_AHEAD] != 2) __atomic_store_n(&c->bell->bell, rung_seq << 1, __ATOMIC_RELEASE);  // 2: the test hook never rings
+  } else {
+    stage();
+    SPCHK(ensure(&c->scratch, &c->scratch_cap, 32 * 18 * (sh.nblk + 1) * ninst));
+    sig = sig_make(c, sh.host ? sh.nblk * ninst : ninst);  // raised by the last kernel of the trip
+    bind2_enqueue(c, IN, inl, dweights, len, nbind, r0 ? limbs(r0) : z, r1 ? limbs(r1) : z, ninst, sh, sig, ahead_none());
+  }
+  const bool tail = rung ? (arm.tail && out_tables) : sh.tail;
+  // the tables as this trip leaves them (host bookkeeping: the kernels are stream-ordered)
+  if (do_bind) {
+    for (size_t k = 0; k < ninst; k++) { A[k]->len = n2; B[k]->len = n2; }
+    for (sp_table* t : distinctC) table_swap_to_alt(t, n2);
+  }
+  // the next trip, ahead of its challenges: a two-bind trip over the same tables follows whenever they still have >= 4 entries (and were not handed
+  // over for the last rounds on the host core)
+  const bool prof_here = c->prof_on != 0 && (((c->prof_mask >> PF_SC_BIND_EVAL) & 1) || ((c->prof_mask >> PF_REDUCE) & 1));
+  if (c->opt.v[OPT_SUMCHECK_LAUNCH_AHEAD] != 0 && c->bell && c->done_counter && !c->ktime && !prof_here && inl && n2 >= 4 && !tail) {
+    const Bind2Shape nx = bind2_shape(n2, 2, ninst, true);
+    if (ensure(&c->scratch, &c->scratch_cap, 32 * 18 * (nx.nblk + 1) * ninst) == SP_OK && c->scratch_cap >= 32 * 18 * (sh.nblk + 1) * ninst) {
+      std::vector<Triple2> Tkeep = T;
+      if (triples(nx.n2) == SP_OK) {
+        stage();
+        const DoneSig nsig = sig_make(c, nx.host ? nx.nblk * ninst : ninst);
+        const AheadArgs ah{c->bell, c->done_counter + 64, c->done_counter + 80, c->done_flag + 16, ++c->ahead_seq};
+        bind2_enqueue(c, IN, inl, dweights, n2, 2, z, z, ninst, nx, nsig, ah);
+        arm.on = true;
+        arm.seq = ah.seq;
+        arm.ninst = ninst; arm.len = n2; arm.nblk = nx.nblk; arm.host = nx.host; arm.tail = nx.tail; arm.weighted = weights != nullptr;
+        for (size_t k = 0; k < ninst; k++) { arm.A[k] = A[k]; arm.B[k] = B[k]; arm.C[k] = C[k]; }
+        if (weights) memcpy(arm.w, weights, 32 * ninst);
+        arm.sig_seq = nsig.seq; arm.sig_total = nsig.total;
+      }
+      T = Tkeep;
+    }
+  }
+  // wait for this trip
+  if (rung) {
+    bool gave_up = false;
+    for (uint64_t spins = 1;; spins++) {
+      if (*c->done_flag == sig.seq) { c->sync_epoch++; break; }
+      if (c->done_flag[16] == rung_seq) { gave_up = true; break; }
+      if ((spins & 0xFFFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
+        if (*c->done_flag == sig.seq) { c->sync_epoch++; break; }
+        if (c->done_flag[16] == rung_seq) { gave_up = true; break; }
+        return SP_EHIP;
+      }
+    }
+    if (gave_up) {
+      // nothing was touched: the trip again, the ordinary way (behind whatever was enqueued for the trip after it, which is told to give up too)
+      ahead_cancel(c);
+      memcpy(IN.t, T.data(), sizeof(Triple2) * ninst);
+      if (weights) { memcpy(IN.w, weights, 32 * ninst); dweights = (const Fq*)c->hmap; }
+      sig = sig_make(c, sh.host ? sh.nblk * ninst : ninst);
+      bind2_enqueue(c, IN, true, dweights, len, nbind, limbs(r0), limbs(r1), ninst, sh, sig, ahead_none());
+      SPCHK(sig_wait(c, sig));
+    }
+  } else {
     SPCHK(sig_wait(c, sig));
+  }
+  const Bind2Shape& got = sh;
+  std::vector<Fq> sums(18 * ninst);
+  if (!got.host) {
     memcpy(sums.data(), hres(c), 32 * 18 * ninst);
   } else {
-    SPCHK(sig_wait(c, sig));
     const Fq* p = (const Fq*)hres(c);
     for (size_t i = 0; i < ninst; i++)
       for (int k = 0; k < 18; k++) {
-        Fq acc = p[(i * nblk) * 18 + k];
-        for (size_t b = 1; b < nblk; b++) acc = fq_add(acc, p[(i * nblk + b) * 18 + k]);
+        Fq acc = p[(i * got.nblk) * 18 + k];
+        for (size_t b = 1; b < got.nblk; b++) acc = fq_add(acc, p[(i * got.nblk + b) * 18 + k]);
         sums[18 * i + k] = acc;
       }
   }
@@ -964,10 +1084,6 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
     } else {
       out_tables[0] = ~0ULL;
     }
-  }
-  if (do_bind) {
-    for (size_t k = 0; k < ninst; k++) { A[k]->len = n2; B[k]->len = n2; }
-    for (sp_table* t : distinctC) table_swap_to_alt(t, n2);
   }
   if (weights) {  // the instances' weighted sums added up: 3 evaluations and 12 coefficients in all
     Fq tot[15];

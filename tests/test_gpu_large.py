@@ -538,6 +538,54 @@ def test_two_rounds_per_launch_match_reference_arithmetic(ctx, ell):
         t.free()
 
 
+@pytest.mark.parametrize("ell,ni", [(13, 5), (12, 20), (9, 24), (6, 3)])
+def test_trips_launched_ahead_of_their_challenges_give_the_same_rounds(ell, ni):
+    """Round 6: while one two-rounds trip of prove_cubic_batched runs, the kernel of the next is already enqueued and waits for its challenges on
+    a bell in host memory (internal.hpp AheadArm; option sumcheck.launch_ahead). An uninterrupted chain of trips — nothing else touches the context
+    between them, as in the prover — must return the same sums, coefficients, final claims and tables whether each kernel is launched with its
+    challenges (0), launched ahead and rung (1), or launched ahead and never rung (2: the test hook — every such kernel gives up after its 20 ms
+    and the trip is repeated the ordinary way). ell = 13 / 12 with 20 instances: the grids whose partial sums need a second kernel."""
+    import time
+    from spartan_amd import capi
+    n = 1 << ell
+    rng = random.Random(77000 + ell)
+    A0 = [fast_scalars(rng, n) for _ in range(ni)]; B0 = [fast_scalars(rng, n) for _ in range(ni)]
+    C0 = [fast_scalars(rng, n) for _ in range(2)]
+    w = fast_scalars(rng, ni)
+    chal = [(rng.getrandbits(251), rng.getrandbits(250)) for _ in range(ell)]
+    results = {}
+    for mode in (0, 1, 2):
+        ctx = capi.Ctx(0)
+        ctx.set_option("testing.unlock", 1); ctx.set_option("sumcheck.launch_ahead", mode)
+        tA, tB, tC = [up(ctx, a) for a in A0], [up(ctx, b) for b in B0], [up(ctx, c) for c in C0]
+        hA = (vp * ni)(*[t.h for t in tA]); hB = (vp * ni)(*[t.h for t in tB])
+        hC = (vp * ni)(*[tC[0].h if k < ni - 1 else tC[1].h for k in range(ni)])   # all but the last instance share their C
+        ev = (ctypes.c_uint64 * 12)(); co = (ctypes.c_uint64 * 48)(); heads = (ctypes.c_uint64 * (4 * (2 * ni + 2)))()
+        out = []
+        assert capi.lib.sp_sumcheck_eval_coeffs_batched(ctx.h, hA, hB, hC, sz(ni), mont_bulk(w), ev, co) == 0
+        out.append((bytes(ev), bytes(co)))
+        length, k = n, 0
+        t0 = time.time()
+        while length >= 4:
+            r0, r1 = chal[k]; k += 1
+            length //= 4
+            assert capi.lib.sp_sumcheck_bind2_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(r0), fq1(r1), mont_bulk(w), ev if length >= 2 else None,
+                                                           co if length >= 4 else None, heads if length == 1 else None) == 0
+            out.append((bytes(ev) if length >= 2 else b"", bytes(co) if length >= 4 else b"", bytes(heads) if length == 1 else b""))
+        dt = time.time() - t0
+        if length >= 2:  # an odd number of variables: the last round binds once
+            assert capi.lib.sp_sumcheck_bind2_eval_batched(ctx.h, hA, hB, hC, sz(ni), fq1(chal[k][0]), None, mont_bulk(w), None, None, heads) == 0
+            out.append(bytes(heads))
+        out.append(bytes(tA[0].download(1)) + bytes(tB[ni - 1].download(1)) + bytes(tC[0].download(1)) + bytes(tC[1].download(1)))
+        results[mode] = out
+        if mode == 1:
+            assert dt < 0.018, "a trip launched ahead waited for its 20 ms time-out: %.1f ms for %d trips" % (dt * 1e3, k)
+        for t in tA + tB + tC:
+            t.free()
+        ctx.close()
+    assert results[1] == results[0] and results[2] == results[0]
+
+
 @pytest.mark.parametrize("ell,nbind", [(5, 2), (4, 2), (3, 2), (4, 1), (3, 1), (2, 1), (3, 0), (2, 0), (1, 0), (6, 2)])
 def test_short_tables_are_handed_over_with_the_round(ctx, ell, nbind):
     """sp_sumcheck_bind2_eval_tables_batched: the call of the two-rounds-per-trip path that also returns the tables once they have
