@@ -12,3 +12,4 @@ for n in 1 2 4 8 9; do
 done
 cat $O/queue_diag.txt
 timeout 600 python bench/ktime_probe.py > $O/ktime_probe.txt 2>&1; tail -30 $O/ktime_probe.txt
+timeout 200 ./bench/trip_probe 1500 > $O/trip_probe.txt 2>&1; cat $O/trip_probe.txt

@@ -2,7 +2,7 @@
 # copies the collection of profiles/collect_r6.sh + collect_r6_diag.sh (gpurun_out/r6prof, scratch) to the committed names
 O=gpurun_out/r6prof
 for f in kernel_stats_2p20 kernel_stats_2p22 kernel_stats_2p24 pmc_hbm_traffic_2p20 pmc_hbm_traffic_2p22 pmc_hbm_traffic_small_memory pmc_kernels_2p20 pmc_kernels_2p22 \
-         fq_bandwidth_2p20 fq_bandwidth_2p22 queue_diag ktime_probe callstats probe_pmc_kernels queue_probe_2p20 queue_probe_2p22 ubench_fpmul pytest_gpu_tail; do
+         fq_bandwidth_2p20 fq_bandwidth_2p22 queue_diag ktime_probe callstats probe_pmc_kernels queue_probe_2p20 queue_probe_2p22 ubench_fpmul pytest_gpu_tail trip_probe; do
   [ -s $O/$f.txt ] && cp $O/$f.txt profiles/r6_$f.txt
 done
 for f in bench_line bench_line_2p16 bench_line_2p18 bench_line_2p22 bench_line_2p24 bench_line_small_memory; do [ -s $O/$f.json ] && cp $O/$f.json profiles/r6_$f.json; done
