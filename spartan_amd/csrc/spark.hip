@@ -367,8 +367,9 @@ struct Bind2Inline {
 // ah.bell != nullptr: the launch was enqueued ahead of its challenges (AheadArm, internal.hpp): it waits for the bell, takes r0 and r1 from there, or
 // gives up without touching anything.
 __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restrict__ T, Bind2Inline IN, const Fq* __restrict__ weights, size_t len, int nbind, Fq r0, Fq r1,
-                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig, AheadArgs ah) {
-  if (ah.bell) {  // the wait runs at the default issue priority: it shares SIMDs with the background MSM's wavefronts and has nothing to hurry for
+                                                          Fq* __restrict__ partials, Fq* __restrict__ dump, DoneSig sig, AheadArgs ah) { SP_FG_PRIO();
+  if (ah.bell) {  // the wait keeps the latency kernels' issue priority: at the default priority the wavefront that watches the bell queues behind the
+                  // co-resident MSM's older wavefronts and the gain of the early launch is gone (measured: profiles/r6_ab_launch_ahead.txt)
     __shared__ uint32_t go;
     if (threadIdx.x < 32) {
       const uint32_t d = ahead_wait(ah);
@@ -379,7 +380,6 @@ __global__ void __launch_bounds__(256) k_cubic_bind2_eval(const Triple2* __restr
     r0 = ahead_challenge(ah.chal);
     r1 = ahead_challenge(ah.chal + 8);
   }
-  SP_FG_PRIO();
   __shared__ Fq first[8][12][2];  // [group][table*4 + position][half]: the entries bound at r0
   __shared__ Fq bnd[8][12];       // [group][table*4 + slot]: the entries bound at r0 and r1 (slots 0..3 = x0..x3)
   __shared__ Fq red[18][8];
