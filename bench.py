@@ -102,6 +102,14 @@ def cpu_baseline(log2_cons, threads=1, want_digest=False):
     from tests import helpers as H
     orc = H.load_oracle()
     N = 1 << log2_cons
+    # the CPU baseline gets every core of the box: the library narrows this (the proving) thread's affinity to the GPU's NUMA node (option
+    # host.pin_thread) and OpenMP threads created from here would inherit that mask
+    mask = None
+    try:
+        mask = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, range(os.cpu_count()))
+    except (AttributeError, OSError):
+        mask = None
     orc.orc_set_threads(ctypes.c_int(threads))
     inst = H.vp(orc.orc_instance_synthetic(H.sz(N), H.sz(N), H.sz(10), ctypes.c_uint64(0)))
     g = H.vp(orc.orc_snark_gens_new(H.sz(N), H.sz(N), H.sz(10), H.sz(N)))
@@ -118,6 +126,11 @@ def cpu_baseline(log2_cons, threads=1, want_digest=False):
         digest = hashlib.sha256(bytes(b)).hexdigest()
     orc.orc_proof_free(p); orc.orc_encode_free(e); orc.orc_snark_gens_free(g); orc.orc_instance_free(inst)
     orc.orc_set_threads(ctypes.c_int(1))
+    if mask is not None:
+        try:
+            os.sched_setaffinity(0, mask)
+        except OSError:
+            pass
     model = ""
     try:
         for line in open("/proc/cpuinfo"):

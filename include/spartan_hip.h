@@ -408,9 +408,9 @@ int32_t sp_table_scale_prefix(sp_ctx* ctx, sp_table* table, size_t n, const uint
  *     their instance's weight on the device and summed over the instances — out_evals[12] and out_coeffs[48] in all, which is
  *     all the protocol uses.
  * While the bound tables still have >= 4 entries (and were not handed over, see below) the next call of this family on the
- * same tables is known to be a two-bind call: since round 6 its kernel is enqueued before this call returns and waits for
- * r0, r1 in host memory (option sumcheck.launch_ahead; bounded wait). That call then only hands the challenges over; any
- * other call on the context makes the waiting kernel give up first. Nothing changes in what the calls return. */
+ * same tables is known to be a two-bind call: with option sumcheck.launch_ahead = 1 (not the default) its kernel is enqueued
+ * before this call returns and waits for r0, r1 in host memory (bounded wait). That call then only hands the challenges
+ * over; any other use of the context makes the waiting kernel give up first. Nothing changes in what the calls return. */
 int32_t sp_sumcheck_eval_coeffs_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t* weights,
                                         uint64_t* out_evals, uint64_t* out_coeffs);
 int32_t sp_sumcheck_bind2_eval_batched(sp_ctx* ctx, sp_table* const* A, sp_table* const* B, sp_table* const* C, size_t ninst, const uint64_t r0[4],

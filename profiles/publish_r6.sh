@@ -8,7 +8,7 @@ done
 for f in bench_line bench_line_2p16 bench_line_2p18 bench_line_2p22 bench_line_2p24 bench_line_small_memory; do [ -s $O/$f.json ] && cp $O/$f.json profiles/r6_$f.json; done
 [ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/pmc_traffic.json
 ls profiles/r6_* | wc -l
-[ -s $O/ab_launch_ahead.txt ] && { echo "# Round 6: option sumcheck.launch_ahead (the two-rounds-per-trip kernels enqueued one trip ahead of their challenges) against 0 (launched when the challenges are known): interleaved in one session, 2^20 (4 x 20 proofs each) then 2^22 (2 x 6)"; cat $O/ab_launch_ahead.txt; } > profiles/r6_ab_launch_ahead.txt
+
 python - <<'PY' > profiles/r6_trip_budget.txt
 import json, subprocess, sys
 j = json.load(open("gpurun_out/r6prof/bench_line.json"))

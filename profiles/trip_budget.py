@@ -15,7 +15,7 @@ for line in open(os.path.join(d, "callstats.txt")):
 rows.sort(key=lambda r: -r[2])
 groups = [
     ("waiting for a commitment's MSM (sp_job_wait: the part of the two big commitments nothing could be overlapped with)", ("sp_job_wait",)),
-    ("batched cubic sum-check, two-rounds-per-trip kernels (k_cubic_bind2_eval; launched ahead since round 6)", ("sp_sumcheck_bind2_eval_batched", "sp_sumcheck_bind2_eval_tables_batched", "sp_sumcheck_eval_coeffs_batched")),
+    ("batched cubic sum-check, two-rounds-per-trip kernels (k_cubic_bind2_eval)", ("sp_sumcheck_bind2_eval_batched", "sp_sumcheck_bind2_eval_tables_batched", "sp_sumcheck_eval_coeffs_batched")),
     ("batched cubic sum-check, throughput-sized rounds", ("sp_sumcheck_bind_eval_batched_eq", "sp_sumcheck_eval_batched_eq", "sp_sumcheck_bind_eval_batched", "sp_sumcheck_eval_batched")),
     ("inner-product argument (45 rounds + set-up + last round)", ("sp_ipa_round_lr", "sp_ipa_begin_dev", "sp_ipa_finish_commit", "sp_ipa_round_fold", "sp_ipa_set_scale")),
     ("ZK sum-checks of R1CSProof (the device leg runs under the round's commitments: start .. collect)", ("sp_sumcheck_bind_eval_collect", "sp_sumcheck_bind_eval_start", "sp_sumcheck_eval")),
@@ -50,11 +50,11 @@ if kt:
     print("\n## inside the two latency kernels (in-kernel stamps, bench/ktime_probe.py; the whole file: r6_ktime_probe.txt)")
     for line in kt.splitlines():
         if line.startswith("====") or "host time of the call" in line or "whole workgroup" in line or "critical path" in line: print(line.rstrip()[:230])
-ab = grab("ab_launch_ahead.txt")
+ab = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "r6_ab_launch_ahead.txt")).read() if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "r6_ab_launch_ahead.txt")) else ""
 if ab:
-    print("\n## option sumcheck.launch_ahead, interleaved A/B in one session (scripts/gpu_ab.sh; 2^20 first, then 2^22)")
+    print("\n## option sumcheck.launch_ahead = 1 against 0, interleaved A/B sessions (profiles/r6_ab_launch_ahead.txt holds all of them)")
     for line in ab.splitlines():
-        if line.startswith(("ahead", "off")): print(line.rstrip()[:200])
+        if "mean" in line or "Verdict" in line or "final protocol" in line or "latency kernels' priority" in line: print(line.lstrip("# ").rstrip()[:200])
 # ---- what the options are worth (numbers from the tables above)
 def tot(*names): return sum(by[k][2] for k in names if k in by)
 def cnt(*names): return sum(by[k][1] for k in names if k in by)
@@ -67,10 +67,11 @@ if fixed:
     print("* A trip costs %.1f us beyond its kernel's body (launch call, dispatch, completion flag over PCIe, the proving thread's wake-up: trip_probe A with an" % fixed[0])
     print("  empty body); %d trips x %.1f us = %.1f ms of the %.1f ms proof is the ceiling of ANY scheme that keeps the arithmetic where it is." % (trips, fixed[0], trips * fixed[0] / 1e3, ms_proof))
 n2 = cnt("sp_sumcheck_bind2_eval_batched", "sp_sumcheck_bind2_eval_tables_batched")
-print("* (built) Launching the next two-rounds kernel ahead of its challenges (sumcheck.launch_ahead; %d of the %d trips qualify: every two-bind trip whose" % (n2, trips))
-print("  predecessor is a trip over the same tables): the probe's B against A is 1.3-6 us per trip depending on the body; in the proof it is ~2.5 us per trip")
-print("  (the bell is one PCIe read away, the decision is relayed to the other workgroups through a device word) = the A/B above. The same treatment of the")
-print("  %d inner-product rounds and the %d throughput-sized rounds would be worth another (45 + 58) x 2.5 us = 0.26 ms: not built." % (cnt("sp_ipa_round_lr"), cnt("sp_sumcheck_bind_eval_batched_eq", "sp_sumcheck_bind_eval_batched", "sp_sumcheck_eval_batched_eq")))
+print("* (built, not the default) Launching the next two-rounds kernel ahead of its challenges (sumcheck.launch_ahead = 1; %d of the %d trips qualify: every two-bind" % (n2, trips))
+print("  trip whose predecessor is a trip over the same tables): the probe's B against A is 1.3-6 us per trip depending on the body; in the proof the entry")
+print("  point's time falls by ~2.5 us per trip when it helps (the bell is one PCIe read away, the decision is relayed to the other workgroups through a")
+print("  device word) — 0.3 ms per proof in the first five A/B sessions, nothing in the four later ones: inside the +-0.4 ms run-to-run spread of the proof.")
+print("  The same treatment of the %d inner-product rounds and the %d throughput-sized rounds would add (45 + 58) x 2.5 us = 0.26 ms at best: not built." % (cnt("sp_ipa_round_lr"), cnt("sp_sumcheck_bind_eval_batched_eq", "sp_sumcheck_bind_eval_batched", "sp_sumcheck_eval_batched_eq")))
 zk = by.get("sp_sumcheck_bind_eval_collect")
 if zk:
     print("* Two rounds per trip in the ZK sum-checks: the proving thread's exclusive wait is sp_sumcheck_bind_eval_collect, %d calls, %.2f ms in all = %.1f us per round" % (zk[1], zk[2], zk[3]))
@@ -82,7 +83,7 @@ if ipa:
     print("  rounds cannot move to the proving core (2 x 2048 terms x 26 additions per round there); folding the generators on the device for a short tail would")
     print("  trade 6 rounds x %.0f us per opening for ~0.5 ms of variable-base arithmetic on the core. Closed with these numbers." % ipa[3])
 print("* Fiat-Shamir on the device (transcript, challenges and the round logic in a resident kernel) would remove the trips altogether: at most the %.1f ms of the" % ((trips * fixed[0] / 1e3) if fixed else 0.0))
-print("  first bullet, less what launch-ahead already took. It moves Merlin/Keccak, the round polynomials, the %d few-term commitments (%.1f us each on the" % (cnt("sp_host_commit_small"), by["sp_host_commit_small"][3] if "sp_host_commit_small" in by else 0.0))
+print("  first bullet. It moves Merlin/Keccak, the round polynomials, the %d few-term commitments (%.1f us each on the" % (cnt("sp_host_commit_small"), by["sp_host_commit_small"][3] if "sp_host_commit_small" in by else 0.0))
 print("  core, ~100 us each as device launches, DESIGN 4) and the Sigma-protocols into one kernel's serial thread at a quarter of the core's clock: not built.")
 jw = by.get("sp_job_wait")
 if jw:

@@ -1,4 +1,6 @@
 // spartan_amd: context, generators (window tables), fixed-base MSM, device tables.
+#include <sched.h>
+#include <cctype>
 #include "internal.hpp"
 #include <atomic>
 #include <list>
@@ -135,7 +137,7 @@ int32_t sync_wait(sp_ctx* c, uint32_t seq) {
   for (uint64_t spins = 1;; spins++) {
     if (*c->done_flag == seq) { c->sync_epoch++; return SP_OK; }
     if ((spins & 0xFFFFF) == 0) {  // every ~ms: a faulted queue never delivers the flag
-      hipError_t e = hipStreamQuery(c->stream);
+      hipError_t e = hipStreamQuery(c->stream.s);  // the raw handle: the trip after this one may be waiting for its bell behind it
       if (e == hipSuccess) {
         if (*c->done_flag != seq) return SP_EHIP;
         c->sync_epoch++;
@@ -1049,6 +1051,38 @@ int32_t sp_ctx_create(int device_id, sp_ctx** out) {
   *out = c;
   return SP_OK;
 }
+// The proving thread and the device exchange ~330 small messages per proof over PCIe (launches, the completion flag, challenges): with the thread on
+// the other socket every one of them crosses the inter-socket link as well — 22.2-22.8 ms per 2^20 proof from the GPU's own node against 22.7-23.4 from
+// the other one or unpinned on one box of the pool, no difference on another (profiles/r6_ab_numa.txt): part of the "box-to-box" spread of the earlier rounds. Narrow the CALLING thread's affinity (threads it
+// creates later inherit it; the pinned host pages allocated below are then first touched on that node) to the CPUs sysfs lists as local to the
+// device's PCI function. Never widens a mask, does nothing when the lists do not intersect or sysfs has no answer.
+static void pin_thread_to_device_node(int device_id) {
+  char bus[32] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device_id) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (char* p = bus; *p; p++) *p = (char)tolower((unsigned char)*p);
+  char path[128];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char list[1024] = {0};
+  const bool got = fgets(list, sizeof list, f) != nullptr;
+  fclose(f);
+  if (!got) return;
+  cpu_set_t have, want;
+  if (sched_getaffinity(0, sizeof have, &have) != 0) return;
+  CPU_ZERO(&want);
+  int n = 0;
+  for (char* p = list; *p && *p != '\n';) {  // "64-127,192-255"
+    char* end = nullptr;
+    long lo = strtol(p, &end, 10), hi = lo;
+    if (end == p) break;
+    if (*end == '-') { p = end + 1; hi = strtol(p, &end, 10); if (end == p) break; }
+    for (long k = lo; k <= hi && k < CPU_SETSIZE; k++)
+      if (k >= 0 && CPU_ISSET((int)k, &have)) { CPU_SET((int)k, &want); n++; }
+    p = *end == ',' ? end + 1 : end;
+  }
+  if (n >= 8 && n < CPU_COUNT(&have)) (void)sched_setaffinity(0, sizeof want, &want);  // a handful of CPUs would starve the threads this one creates (uploader, small-commitment worker)
+}
 static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->dev = device_id;
   c->stream = c->stream_bg = c->stream_side = nullptr;
@@ -1063,6 +1097,7 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
   c->eq_next = 0;
   for (int k = 0; k < 8; k++) c->eq_slot_epoch[k] = 0;
   c->opt = sp_default_options();
+  if (c->opt.v[OPT_HOST_PIN_THREAD]) pin_thread_to_device_node(device_id);  // before the pinned host pages below are allocated
   c->device_encode = c->opt.v[OPT_ENCODE_DEVICE] != 0;  // diagnostic: keep every RFC 9496 encode on the GPU
   c->prof_on = 0;
   c->prof_mask = ~0ULL;
@@ -1077,7 +1112,8 @@ static int32_t ctx_init(sp_ctx* c, int device_id) {
     // platform: it succeeds, and a 1/8 mask runs an MSM exactly as fast as 8/8 — bench/bg_probe.py.)
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->stream.s, hipStreamNonBlocking, hi));
+    c->stream.owner = c;
     HIPCHK(hipStreamCreateWithPriority(&c->stream_side, hipStreamNonBlocking, hi));
     HIPCHK(hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithPriority(&c->stream_bg, hipStreamNonBlocking, lo));
@@ -1125,6 +1161,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   (void)hipSetDevice(c->dev);
   ahead_cancel(c);
   (void)hipStreamSynchronize(c->stream);
+  if (c->ahead.n_armed && sp_default_options().v[OPT_HOST_CALLSTATS])
+    fprintf(stderr, "[callstats] kernels enqueued ahead of their challenges: %llu, rung %llu, cancelled %llu, gave up %llu\n", (unsigned long long)c->ahead.n_armed,
+            (unsigned long long)c->ahead.n_rung, (unsigned long long)c->ahead.n_cancelled, (unsigned long long)c->ahead.n_gave_up);
   prof_drain(c);
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   for (auto& kv : c->pool)
@@ -2041,6 +2080,7 @@ extern "C" {
 void sp_table_free(sp_table* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->dev);
+  ahead_cancel(t->ctx);  // a kernel enqueued ahead of its challenges may hold this table's buffers
   if (t->owner) pool_release(t->ctx, t->d, t->d_bytes);
   if (t->alt) pool_release(t->ctx, t->alt, t->alt_bytes);
   delete t;

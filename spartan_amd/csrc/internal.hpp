@@ -153,21 +153,33 @@ __device__ __forceinline__ Fq ahead_challenge(const uint32_t* p) {  // from ah.c
 }
 #endif
 struct sp_table;
+struct sp_ctx;
+// The context's main stream. A kernel that was enqueued ahead of its challenges (AheadArm) is only valid while NOTHING else is queued on, or waits
+// for, that stream: every use of the handle — a launch, a copy, an event, a synchronisation, a comparison — first tells such a kernel to give up
+// (`.s` is the raw handle, for the two places that poll the stream while they wait for the very trip that was enqueued ahead).
+struct MainStream {
+  hipStream_t s = nullptr;
+  sp_ctx* owner = nullptr;
+  inline operator hipStream_t() const;
+  MainStream& operator=(hipStream_t v) { s = v; return *this; }
+};
 struct AheadArm {  // what the enqueued kernel was armed for: the next call has to be exactly this to ring it, anything else cancels it
   bool on = false;
   uint32_t seq = 0;
   size_t ninst = 0, len = 0, nblk = 0;
   bool host = false, weighted = false, tail = false;
   sp_table *A[24], *B[24], *C[24];
+  const void* buf[24][4];  // the device buffers the enqueued kernel was given (a, b, c, c_out per instance): handles can be freed and their addresses reused
   Fq w[24];
   uint32_t sig_seq = 0, sig_total = 0;
+  uint64_t n_armed = 0, n_rung = 0, n_cancelled = 0, n_gave_up = 0;  // printed with the call statistics (option host.callstats)
 };
 
 struct sp_ctx {
   int dev;
   SpOptions opt;  // options.hpp: a copy of the process-wide defaults at creation, changed by sp_ctx_set_option
   int n_cus = 256;
-  hipStream_t stream;
+  MainStream stream;
   hipStream_t stream_side;  // same priority as `stream`: small commitments that run NEXT TO a sum-check kernel of the same round
   hipEvent_t side_ev;
   hipStream_t stream_bg;  // lower-priority background stream: throughput MSMs overlapped with latency-bound rounds
@@ -227,7 +239,12 @@ struct sp_ctx {
 static inline void ahead_cancel(sp_ctx* c) {
   if (!c->ahead.on) return;
   c->ahead.on = false;
+  c->ahead.n_cancelled++;
   __atomic_store_n(&c->bell->bell, (c->ahead.seq << 1) | 1u, __ATOMIC_RELEASE);
+}
+inline MainStream::operator hipStream_t() const {
+  if (owner) ahead_cancel(owner);
+  return s;
 }
 struct sp_gens {
   sp_ctx* ctx;

@@ -82,7 +82,7 @@ int32_t sp_ctx_set_option(sp_ctx* c, const char* key, const char* value) {
   }
   {  // options that are process-wide by nature live in the process-wide table only: set on a context they would be accepted and ignored
     const int i = opt_find(key ? key : "");
-    if (i == OPT_HOST_KECCAK || i == OPT_HOST_PROOF_GATE || i == OPT_HOST_CALLSTATS) {
+    if (i == OPT_HOST_KECCAK || i == OPT_HOST_PROOF_GATE || i == OPT_HOST_CALLSTATS || i == OPT_HOST_PIN_THREAD) {
       fprintf(stderr, "spartan_hip: option %s is process-wide: set it with a NULL context (before the first proof)\n", key);
       return SP_EINVAL;
     }

@@ -30,6 +30,7 @@
   X(SHARD_RESIDUE_MIN_LOG2, "shard.residue_min_log2", 22, 0, 64, 0, "over multi-process transports: shard a sum-check when its tables have >= 2^this entries (0 = always, 64 = never)") \
   X(HOST_KECCAK, "host.keccak", 0, 0, 3, 0, "PROC. Keccak-f[1600] form of the host transcript: 0 = fastest by calibration, 1 = plain, 2 = BMI2, 3 = AVX-512") \
   X(HOST_PROOF_GATE, "host.proof_gate", 0, 0, 1, 0, "PROC. several proofs in flight on one device: admit one at a time to the throughput-bound part") \
+  X(HOST_PIN_THREAD, "host.pin_thread", 1, 0, 1, 0, "PROC. sp_ctx_create narrows the calling thread's CPU affinity to the cores of the GPU's own NUMA node (sysfs local_cpulist of its PCI function): a proof is ~330 PCIe round trips between that thread and the device; 0 = leave the affinity alone") \
   X(IPA_UNIFIED_TREE, "ipa.unified_tree", 0, 0, 1, 1, "inner-product rounds always with the unified (complete) addition tree")               \
   X(IPA_DEDICATED_UPLOADED, "ipa.dedicated_uploaded", 0, 0, 1, 1, "dedicated (incomplete, two-multiplication) addition tree also for caller-supplied generator lists (default: only for sets the library derived by hash-to-curve)") \
   X(IPA_FUSED, "ipa.fused", 1, 0, 1, 1, "one launch per inner-product round (0: prepare + lookups + reduce, the form vectors longer than 16384 fall back to - its test hook)")                                \
@@ -45,7 +46,7 @@
   X(SUMCHECK_INLINE_ARGS, "sumcheck.inline_args", 1, 0, 1, 1, "table pointers of the batched sum-check kernels in the kernel arguments (0: the staged form that more than 24 instances or 13 variables fall back to - its test hook)")      \
   X(SUMCHECK_DOUBLE_ROUND_MAX_LEN, "sumcheck.double_round_max_len", 4096, 0, 1073741824, 1, "two rounds per trip while the tables have at most this many entries") \
   X(SUMCHECK_HOST_TAIL, "sumcheck.host_tail", 1, 0, 1, 1, "last <= 3 rounds of a batched sum-check on the proving core")                     \
-  X(SUMCHECK_LAUNCH_AHEAD, "sumcheck.launch_ahead", 1, 0, 2, 1, "two-rounds-per-trip kernels are enqueued one trip ahead and wait for their challenges on a bell in host memory (0: launched when the challenges are known; 2: test hook - the bell is never rung, every such launch gives up and is repeated the ordinary way)") \
+  X(SUMCHECK_LAUNCH_AHEAD, "sumcheck.launch_ahead", 0, 0, 2, 1, "1: two-rounds-per-trip kernels are enqueued one trip ahead and wait for their challenges on a bell in host memory (measured: -0.3 ms per 2^20 proof in five sessions, +-0 in four others, inside the run-to-run spread: not the default); 0: launched when the challenges are known; 2: test hook - the bell is never rung, every such launch gives up and is repeated the ordinary way") \
   X(SPARK_PROD_LAYER2, "spark.prod_layer2", 1, 0, 1, 1, "two product-circuit layers per launch in the launch-sized middle of the tree")       \
   X(SPARK_PROD_LAYER2_MAX_LOG2, "spark.prod_layer2_max_log2", 18, 0, 40, 1, "... for layers of at most 2^this entries")                      \
   X(SPARK_EQ_FACTOR, "spark.eq_factor", 1, 0, 1, 1, "the eq table as a factor in the throughput-sized batched rounds")                       \

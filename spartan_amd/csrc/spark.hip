@@ -949,16 +949,7 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
     if (!A[k] || !B[k] || !C[k] || A[k]->len != len || B[k]->len != len || C[k]->len != len) return SP_EINVAL;
   const bool inline_args = c->opt.v[OPT_SUMCHECK_INLINE_ARGS] != 0;  // A/B switch
   const bool inl = inline_args && ninst <= 24;
-  // is this the trip an enqueued kernel is waiting for?
   AheadArm& arm = c->ahead;
-  bool rung = false;
-  if (arm.on) {
-    bool same = inl && nbind == 2 && r0 && r1 && arm.ninst == ninst && arm.len == len && arm.weighted == (weights != nullptr) &&
-                (!weights || memcmp(arm.w, weights, 32 * ninst) == 0);
-    for (size_t k = 0; same && k < ninst; k++) same = arm.A[k] == A[k] && arm.B[k] == B[k] && arm.C[k] == C[k];
-    if (same) rung = true;
-    else ahead_cancel(c);
-  }
   // the instances' tables; a C shared between instances is bound once, out of place
   std::vector<Triple2> T(ninst);
   std::vector<sp_table*> distinctC;
@@ -979,6 +970,17 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
     return SP_OK;
   };
   SPCHK(triples(do_bind ? n2 : 0));
+  // is this the trip an enqueued kernel is waiting for? The same handles, the same device buffers behind them, the same length, weights and form.
+  bool rung = false;
+  if (arm.on) {
+    bool same = inl && nbind == 2 && r0 && r1 && arm.ninst == ninst && arm.len == len && arm.weighted == (weights != nullptr) &&
+                (!weights || memcmp(arm.w, weights, 32 * ninst) == 0);
+    for (size_t k = 0; same && k < ninst; k++)
+      same = arm.A[k] == A[k] && arm.B[k] == B[k] && arm.C[k] == C[k] && arm.buf[k][0] == T[k].a && arm.buf[k][1] == T[k].b && arm.buf[k][2] == T[k].c &&
+             arm.buf[k][3] == T[k].c_out;
+    if (same) rung = true;
+    else ahead_cancel(c);
+  }
   Bind2Inline IN;
   const Fq* dweights = nullptr;
   auto stage = [&]() {
@@ -999,6 +1001,7 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
     sig = DoneSig{c->done_flag, c->done_counter, arm.sig_seq, arm.sig_total, nullptr};
     rung_seq = arm.seq;
     arm.on = false;
+    arm.n_rung++;
     uint32_t words[16], fold = rung_seq;
     memcpy(words, r0, 32);
     memcpy(words + 8, r1, 32);
@@ -1030,9 +1033,13 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
         const AheadArgs ah{c->bell, c->done_counter + 64, c->done_counter + 80, c->done_flag + 16, ++c->ahead_seq};
         bind2_enqueue(c, IN, inl, dweights, n2, 2, z, z, ninst, nx, nsig, ah);
         arm.on = true;
+        arm.n_armed++;
         arm.seq = ah.seq;
         arm.ninst = ninst; arm.len = n2; arm.nblk = nx.nblk; arm.host = nx.host; arm.tail = nx.tail; arm.weighted = weights != nullptr;
-        for (size_t k = 0; k < ninst; k++) { arm.A[k] = A[k]; arm.B[k] = B[k]; arm.C[k] = C[k]; }
+        for (size_t k = 0; k < ninst; k++) {
+          arm.A[k] = A[k]; arm.B[k] = B[k]; arm.C[k] = C[k];
+          arm.buf[k][0] = T[k].a; arm.buf[k][1] = T[k].b; arm.buf[k][2] = T[k].c; arm.buf[k][3] = T[k].c_out;
+        }
         if (weights) memcpy(arm.w, weights, 32 * ninst);
         arm.sig_seq = nsig.seq; arm.sig_total = nsig.total;
       }
@@ -1045,13 +1052,14 @@ static int32_t bind2_launch(sp_ctx* c, sp_table* const* A, sp_table* const* B, s
     for (uint64_t spins = 1;; spins++) {
       if (*c->done_flag == sig.seq) { c->sync_epoch++; break; }
       if (c->done_flag[16] == rung_seq) { gave_up = true; break; }
-      if ((spins & 0xFFFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
+      if ((spins & 0xFFFFFF) == 0 && hipStreamQuery(c->stream.s) != hipErrorNotReady) {
         if (*c->done_flag == sig.seq) { c->sync_epoch++; break; }
         if (c->done_flag[16] == rung_seq) { gave_up = true; break; }
         return SP_EHIP;
       }
     }
     if (gave_up) {
+      arm.n_gave_up++;
       // nothing was touched: the trip again, the ordinary way (behind whatever was enqueued for the trip after it, which is told to give up too)
       ahead_cancel(c);
       memcpy(IN.t, T.data(), sizeof(Triple2) * ninst);

@@ -132,7 +132,7 @@ def test_option_table_and_tiers():
     import subprocess, sys
     from spartan_amd import capi
     table = capi.options_table()
-    assert 30 <= len(table) <= 42 and len({k for k, *_ in table}) == len(table)   # (51 at the start of round 6: the A/B switches of paths that lost every comparison since round 3 went with their kernels)
+    assert 30 <= len(table) <= 44 and len({k for k, *_ in table}) == len(table)   # (51 at the start of round 6: the A/B switches of paths that lost every comparison since round 3 went with their kernels)
     for key, default, lo, hi, tier, doc in table:
         assert lo <= default <= hi and tier in (0, 1) and len(doc) > 10, key
     code = r"""

@@ -503,7 +503,8 @@ def test_every_ab_switch_gives_the_same_proof(orc):
                 {"spark.eq_factor": 0, "spark.hash_fuse": 0, "ipa.unified_tree": 1, "ipa.finish_device": 1},
                 {"sumcheck.inline_args": 0}, {"ipa.fused": 0}, {"encode.device": 1}, {"commit.small_device": 1},
                 {"sumcheck.double_round_max_len": 0, "sumcheck.host_tail": 0}, {"sumcheck.double_round_max_len": 512},
-                {"sumcheck.launch_ahead": 0}, {"sumcheck.launch_ahead": 2}, {"sumcheck.launch_ahead": 2, "sumcheck.host_tail": 0}, {"sumcheck.launch_ahead": 1, "sumcheck.host_tail": 0},
+                {"sumcheck.launch_ahead": 1}, {"sumcheck.launch_ahead": 2}, {"sumcheck.launch_ahead": 2, "sumcheck.host_tail": 0}, {"sumcheck.launch_ahead": 1, "sumcheck.host_tail": 0},
+                {"host.pin_thread": 0},
                 {"spark.prod_layer2": 0}, {"spark.prod_layer2_max_log2": 14}, {"upload.overlap": 0, "upload.thread": 0}, {"upload.chunks": 2},
                 {"overlap.derefs": 0}, {"overlap.eval_ahead": 0}, {"polyeval.eval_from_opening": 0}, {"bg.eighths": 4}, {"bg.eighths": 0},
                 {"msm.form": 3}, {"msm.form": 3, "bg.eighths": 3, "upload.chunks": 1},
