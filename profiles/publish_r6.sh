@@ -15,3 +15,4 @@ j = json.load(open("gpurun_out/r6prof/bench_line.json"))
 sys.stdout.write(subprocess.run([sys.executable, "profiles/trip_budget.py", "gpurun_out/r6prof", "%.2f" % j["ms_per_step"], str(j["config"]["fs_trips_per_proof"])], capture_output=True, text=True).stdout)
 PY
 wc -l profiles/r6_trip_budget.txt
+{ echo "# VERDICT r5 #2's file: the F_q kernels launch by launch at 2^20 and 2^22 (the two tables below are r6_fq_bandwidth_2p20.txt and _2p22.txt)"; echo; echo "#### 2^20"; cat profiles/r6_fq_bandwidth_2p20.txt; echo; echo "#### 2^22"; cat profiles/r6_fq_bandwidth_2p22.txt; } > profiles/r6_fq_bandwidth.txt
